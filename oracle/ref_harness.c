@@ -1,0 +1,395 @@
+/*
+ * ref_harness.c -- TEST INFRASTRUCTURE ONLY (not part of the product path).
+ *
+ * Drives the *unmodified* reference implementation (compiled from its sources
+ * where they lie under /root/reference/src by oracle/Makefile, output only
+ * into oracle/_ref/) so that
+ *   (1) golden vectors can be generated from the real reference
+ *       (tests/golden/, generator: tests/golden/make_goldens.sh), and
+ *   (2) the reference's own per-locus CPU path can be timed as the
+ *       cpu_baseline of bench.py ("kind": "reference").
+ *
+ * No reference source text is copied here: this file only #includes the
+ * reference headers / one .c at build time and calls their public functions
+ * in the order the reference's own main() and performMCMC() call them
+ * (GPhoCS.c:147-235 start-up, GPhoCS.c:1476-1821 one MCMC iteration).
+ *
+ * Sub-commands (argv[1]):
+ *   pack  <ctl> <out.gpk>            dump model + processed loci ("pack")
+ *   run   <ctl> <iters> <out.trace> [statefile] [state_iter]
+ *                                    replay iterations, one record per proposal
+ *   time  <ctl> <iters>              timed iterations (cpu_baseline)
+ *   rng   <seed> <count>             RNG golden stream
+ *   reflect                          reflect() golden table
+ *   main  <args...>                  the reference's own main()
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <time.h>
+
+#include "PopulationTree.h"
+#include "GenericTree.h"
+#include "MCMCcontrol.h"
+#include "AlignmentProcessor.h"
+#include "utils.h"
+/* Including the .c (instead of linking its object) gives this harness access
+ * to the file-local struct LOCUS_LIKELIHOOD so that conditional-likelihood
+ * arrays can be dumped.  The reference object for this file is NOT linked. */
+#include "LocusDataLikelihood.c"
+#include "patch.h"
+#include "GPhoCS.h"
+
+extern RandGeneratorContext RndCtx;
+extern int gphocs_main(int argc, char *argv[]);
+extern int initializeMCMC();
+extern int sampleMigRates(PopulationTree *popTree);
+extern int freeAlignmentData();
+extern int readSeqFile(const char *seqFileName, int numSamples,
+                       char **sampleNames, int numLociToRead);
+
+/* ------------------------------------------------------------------ */
+/* start-up: same call order as the reference's main(), GPhoCS.c:147-235 */
+static void startup(char *ctl)
+{
+  int res;
+  debug = 0;
+  initGeneralInfo();
+  res = readControlFile(ctl);
+  if (res != 0) { fprintf(stderr, "harness: readControlFile failed\n"); exit(2); }
+  res = checkSettings();
+  finalizeNumParameters();
+  if (res > 0) { fprintf(stderr, "harness: %d control errors\n", res); exit(2); }
+  if (mcmcSetup.randomSeed < 0) mcmcSetup.randomSeed = 12345;
+  res = processAlignments();
+  if (res < 0) { fprintf(stderr, "harness: processAlignments failed\n"); exit(2); }
+  allocateAllMemory();
+  initRandomGenerator(dataSetup.numLoci, mcmcSetup.randomSeed);
+}
+
+/* ------------------------------------------------------------------ */
+static void write_model(FILE *f)
+{
+  PopulationTree *pt = dataSetup.popTree;
+  int pop, b;
+  fprintf(f, "GPHOCS-PACK 1\n");
+  fprintf(f, "numLoci %d\nnumSamples %d\nnumCurPops %d\nnumPops %d\nnumMigBands %d\nrootPop %d\n",
+          dataSetup.numLoci, dataSetup.numSamples, pt->numCurPops, pt->numPops,
+          pt->numMigBands, pt->rootPop);
+  fprintf(f, "samplesPerPop");
+  for (pop = 0; pop < pt->numCurPops; pop++) fprintf(f, " %d", dataSetup.numSamplesPerPop[pop]);
+  fprintf(f, "\n");
+  for (pop = 0; pop < pt->numPops; pop++) {
+    Population *p = pt->pops[pop];
+    fprintf(f, "pop %d %s %d %d %d %a %d %a %a %a %a %a %a\n", pop, p->name,
+            p->father ? p->father->id : -1,
+            p->sons[0] ? p->sons[0]->id : -1, p->sons[1] ? p->sons[1]->id : -1,
+            p->sampleAge, (int)(p->updateSampleAge ? 1 : 0),
+            p->thetaPrior.alpha, p->thetaPrior.beta, p->thetaPrior.sampleStart,
+            p->agePrior.alpha, p->agePrior.beta, p->agePrior.sampleStart);
+  }
+  for (b = 0; b < pt->numMigBands; b++) {
+    fprintf(f, "band %d %d %d %a %a\n", b, pt->migBands[b].sourcePop,
+            pt->migBands[b].targetPop, pt->migBands[b].migRatePrior.alpha,
+            pt->migBands[b].migRatePrior.beta);
+  }
+  fprintf(f, "mcmc %d %d %d %d %d %d %d %d\n", mcmcSetup.randomSeed, mcmcSetup.burnin,
+          mcmcSetup.numSamples, mcmcSetup.sampleSkip, mcmcSetup.startMig,
+          (int)mcmcSetup.doMixing, ioSetup.samplesPerLog, (int)mcmcSetup.mutRateMode);
+  fprintf(f, "finetunes %a %a %a %a %a", mcmcSetup.finetunes.coalTime,
+          mcmcSetup.finetunes.migTime, mcmcSetup.finetunes.theta,
+          mcmcSetup.finetunes.migRate, mcmcSetup.finetunes.mixing);
+  for (pop = 0; pop < pt->numPops; pop++) fprintf(f, " %a", mcmcSetup.finetunes.taus[pop]);
+  fprintf(f, "\n");
+  fprintf(f, "printFactors %d", mcmcSetup.numParameters);
+  for (pop = 0; pop < mcmcSetup.numParameters; pop++) fprintf(f, " %a", mcmcSetup.printFactors[pop]);
+  fprintf(f, "\n");
+}
+
+/* pack: per locus, the phased pattern table exactly as initializeLocusData
+ * stored it (LocusDataLikelihood.c:239-305): one row per phased pattern with
+ * the leaf characters, numPhases (non-zero on the first phase only) and count */
+static int cmd_pack(char *ctl, char *out)
+{
+  int g, p, leaf, c;
+  FILE *f;
+  startup(ctl);
+  f = fopen(out, "w");
+  if (!f) { perror(out); return 2; }
+  write_model(f);
+  for (g = 0; g < dataSetup.numLoci; g++) {
+    LocusData *ld = dataState.lociData[g];
+    int P = ld->seqData.numPatterns;
+    fprintf(f, "locus %d %d %a\n", g, P, ld->mutationRate);
+    for (p = 0; p < P; p++) {
+      for (leaf = 0; leaf < ld->numLeaves; leaf++) {
+        double *cp = ld->nodeArray[leaf]->conditionalProbs + 4 * p;
+        double s = cp[0] + cp[1] + cp[2] + cp[3];
+        if (s >= 4) c = 'N';
+        else if (cp[0] == 1.0) c = 'T';
+        else if (cp[1] == 1.0) c = 'C';
+        else if (cp[2] == 1.0) c = 'A';
+        else c = 'G';
+        fputc(c, f);
+      }
+      fprintf(f, " %d %d\n", ld->seqData.numPhases[p], ld->seqData.patternCount[p]);
+    }
+  }
+  fprintf(f, "end\n");
+  fclose(f);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* canonical per-locus state dump (shared format with the oracle restatement
+ * and the HIP engine's download; compared field by field in tests) */
+static void dump_state(FILE *f, int withCond)
+{
+  PopulationTree *pt = dataSetup.popTree;
+  int g, i, pop, b, ev, N = 2 * dataSetup.numSamples - 1;
+  fprintf(f, "STATE %d\n", dataSetup.numLoci);
+  fprintf(f, "MODEL");
+  for (pop = 0; pop < pt->numPops; pop++)
+    fprintf(f, " %a %a %a", pt->pops[pop]->theta, pt->pops[pop]->age, pt->pops[pop]->sampleAge);
+  for (b = 0; b < pt->numMigBands; b++)
+    fprintf(f, " %a %a %a", pt->migBands[b].migRate, pt->migBands[b].startTime, pt->migBands[b].endTime);
+  fprintf(f, "\n");
+  fprintf(f, "GLOBAL %a %a %u %u %u\n", dataState.logLikelihood, dataState.dataLogLikelihood,
+          RndCtx.rndu_x[RndCtx.nOfSlots - 1], RndCtx.rndu_y[RndCtx.nOfSlots - 1],
+          RndCtx.rndu_z[RndCtx.nOfSlots - 1]);
+  fprintf(f, "TOTALS");
+  for (pop = 0; pop < pt->numPops; pop++)
+    fprintf(f, " %a %d", genetree_stats_total.coal_stats[pop], genetree_stats_total.num_coals[pop]);
+  for (b = 0; b < pt->numMigBands; b++)
+    fprintf(f, " %a %d", genetree_stats_total.mig_stats[b], genetree_stats_total.num_migs[b]);
+  fprintf(f, "\n");
+  for (g = 0; g < dataSetup.numLoci; g++) {
+    LocusData *ld = dataState.lociData[g];
+    fprintf(f, "LOCUS %d root %d dataLnL %a genLnL %a rng %u %u %u\n", g, ld->root,
+            ld->dataLogLikelihood, locus_data[g].genLogLikelihood,
+            RndCtx.rndu_x[g], RndCtx.rndu_y[g], RndCtx.rndu_z[g]);
+    for (i = 0; i < N; i++) {
+      fprintf(f, "N %d %d %d %d %a %d %d\n", i, ld->nodeArray[i]->father,
+              ld->nodeArray[i]->leftSon, ld->nodeArray[i]->rightSon,
+              ld->nodeArray[i]->age, nodePops[g][i], i < dataSetup.numSamples ? -1 : nodeEvents[g][i]);
+    }
+    for (pop = 0; pop < pt->numPops; pop++) {
+      fprintf(f, "C %d", pop);
+      for (ev = event_chains[g].first_event[pop]; ev >= 0; ev = event_chains[g].events[ev].next) {
+        Event *e = &event_chains[g].events[ev];
+        fprintf(f, " %d:%d:%d:%d:%a", ev, (int)e->type, e->node_id, e->num_lineages, e->elapsed_time);
+      }
+      fprintf(f, "\n");
+    }
+    fprintf(f, "S");
+    for (pop = 0; pop < pt->numPops; pop++)
+      fprintf(f, " %a %d", genetree_stats[g].coal_stats[pop], genetree_stats[g].num_coals[pop]);
+    for (b = 0; b < pt->numMigBands; b++)
+      fprintf(f, " %a %d", genetree_stats[g].mig_stats[b], genetree_stats[g].num_migs[b]);
+    fprintf(f, "\n");
+    fprintf(f, "M %d", genetree_migs[g].num_migs);
+    for (i = 0; i < genetree_migs[g].num_migs; i++) {
+      int m = genetree_migs[g].living_mignodes[i];
+      struct MIGNODE *mn = &genetree_migs[g].mignodes[m];
+      fprintf(f, " %d:%d:%d:%d:%d:%d:%d:%a", m, mn->gtree_branch, mn->migration_band,
+              mn->source_pop, mn->target_pop, mn->source_event, mn->target_event, mn->age);
+    }
+    fprintf(f, "\n");
+    if (withCond) {
+      int P = ld->seqData.numPatterns, p, a;
+      for (i = dataSetup.numSamples; i < N; i++) {
+        fprintf(f, "K %d", i);
+        for (p = 0; p < P; p++)
+          for (a = 0; a < 4; a++)
+            fprintf(f, " %a", ld->nodeArray[i]->conditionalProbs[4 * p + a]);
+        fprintf(f, "\n");
+      }
+    }
+  }
+  fprintf(f, "ENDSTATE\n");
+}
+
+/* one line per proposal call: what the reference's return value and the
+ * dataState accumulators were right after it (GPhoCS.h:84-100 contract) */
+static void rec(FILE *f, int it, const char *what, int acc)
+{
+  fprintf(f, "IT %d %s %d %a %a\n", it, what, acc, dataState.dataLogLikelihood,
+          dataState.logLikelihood);
+}
+
+static double *g_paramVals = NULL;
+
+/* the per-iteration call sequence of performMCMC, GPhoCS.c:1476-1821,
+ * (genetreeSamples == 1; no find-finetunes; no admixture; CONST/FIXED rates) */
+static int one_iteration(FILE *tf, int iteration, int *acceptCountArray, int verboseTrace)
+{
+  PopulationTree *pt = dataSetup.popTree;
+  int pop, gen, acc;
+  acc = UpdateGB_InternalNode(mcmcSetup.finetunes.coalTime);
+  if (verboseTrace) rec(tf, iteration, "INT", acc);
+  acc = UpdateGB_MigrationNode(mcmcSetup.finetunes.migTime);
+  if (verboseTrace) rec(tf, iteration, "MIGN", acc);
+  acc = UpdateGB_MigSPR();
+  if (verboseTrace) rec(tf, iteration, "SPR", acc);
+  if (mcmcSetup.mutRateMode == 1) {
+    acc = UpdateLocusRate(mcmcSetup.finetunes.locusRate);
+    if (verboseTrace) rec(tf, iteration, "LRATE", acc);
+  }
+  acc = UpdateTheta(mcmcSetup.finetunes.theta);
+  if (verboseTrace) rec(tf, iteration, "THETA", acc);
+  if (iteration > mcmcSetup.startMig) {
+    acc = UpdateMigRates(mcmcSetup.finetunes.migRate);
+    if (verboseTrace) rec(tf, iteration, "MIGR", acc);
+  }
+  UpdateTau(mcmcSetup.finetunes.taus, acceptCountArray);
+  if (verboseTrace) {
+    for (pop = pt->numCurPops; pop < pt->numPops; pop++) {
+      char nm[32];
+      snprintf(nm, sizeof nm, "TAU%d", pop);
+      rec(tf, iteration, nm, acceptCountArray[pop]);
+    }
+    fprintf(tf, "CONFLICTS %d\n", misc_stats.rubberband_mig_conflicts);
+  }
+  UpdateSampleAge(mcmcSetup.finetunes.taus, acceptCountArray);
+  if (mcmcSetup.doMixing) {
+    acc = mixing(mcmcSetup.finetunes.mixing);
+    if (verboseTrace) rec(tf, iteration, "MIX", acc);
+  }
+  for (gen = 0; gen < dataSetup.numLoci; gen++) {
+    if (!synchronizeEvents(gen)) { fprintf(stderr, "harness: synchronizeEvents failed gen %d\n", gen); exit(3); }
+  }
+  /* parameters are recorded BEFORE the start-mig resampling (GPhoCS.c:1730 vs 1738) */
+  if (!g_paramVals) g_paramVals = (double *)malloc(sizeof(double) * (mcmcSetup.numParameters + 1));
+  recordParamVals(g_paramVals);
+  if (iteration == mcmcSetup.startMig) {
+    sampleMigRates(pt);
+    for (gen = 0; gen < dataSetup.numLoci; gen++) {
+      dataState.logLikelihood -= locus_data[gen].genLogLikelihood / dataSetup.numLoci;
+      locus_data[gen].genLogLikelihood = gtreeLnLikelihood(gen);
+      dataState.logLikelihood += locus_data[gen].genLogLikelihood / dataSetup.numLoci;
+    }
+  }
+  if ((iteration + 1) % ioSetup.samplesPerLog == 0) {
+    if (!checkAll()) { fprintf(stderr, "harness: checkAll failed at iteration %d\n", iteration); exit(3); }
+    if (verboseTrace) rec(tf, iteration, "CHECK", 1);
+  }
+  return 0;
+}
+
+static void trace_line(FILE *tf, int iteration)
+{
+  fprintf(tf, "TRACE %d\t", iteration);
+  printParamVals(g_paramVals, 0, mcmcSetup.numParameters, tf);
+  fprintf(tf, "\t%.6f\t%.6f\n", dataState.logLikelihood, dataState.dataLogLikelihood);
+}
+
+static int cmd_run(int argc, char **argv)
+{
+  char *ctl = argv[2];
+  int iters = atoi(argv[3]);
+  FILE *tf = fopen(argv[4], "w");
+  char *statefile = argc > 5 ? argv[5] : NULL;
+  int stateIter = argc > 6 ? atoi(argv[6]) : iters - 1; /* dump after this iteration; -1 = after init */
+  int withCond = argc > 7 ? atoi(argv[7]) : 0;
+  int it, totalCoals, *acceptCountArray;
+  if (!tf) { perror(argv[4]); return 2; }
+  startup(ctl);
+  acceptCountArray = (int *)calloc(dataSetup.popTree->numPops, sizeof(int));
+  misc_stats.rubberband_mig_conflicts = 0;
+  misc_stats.not_enough_migs = 0;
+  totalCoals = initializeMCMC();
+  rec(tf, -1, "INIT", totalCoals);
+  if (statefile && stateIter < 0) { FILE *sf = fopen(statefile, "w"); dump_state(sf, withCond); fclose(sf); }
+  for (it = 0; it < iters; it++) {
+    one_iteration(tf, it, acceptCountArray, 1);
+    trace_line(tf, it);
+    if (statefile && stateIter == it) { FILE *sf = fopen(statefile, "w"); dump_state(sf, withCond); fclose(sf); }
+  }
+  fclose(tf);
+  return 0;
+}
+
+static double now_s(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+/* cpu_baseline: time `iters` full iterations after `warm` warm-up iterations */
+static int cmd_time(int argc, char **argv)
+{
+  char *ctl = argv[2];
+  int iters = atoi(argv[3]);
+  int warm = argc > 4 ? atoi(argv[4]) : 2;
+  int it, *acceptCountArray;
+  double t0, t1;
+  long evalsPerLocusIter;
+  startup(ctl);
+  acceptCountArray = (int *)calloc(dataSetup.popTree->numPops, sizeof(int));
+  initializeMCMC();
+  for (it = 0; it < warm; it++) one_iteration(NULL, it, acceptCountArray, 0);
+  t0 = now_s();
+  for (; it < warm + iters; it++) one_iteration(NULL, it, acceptCountArray, 0);
+  t1 = now_s();
+  /* nominal count of computeLocusDataLikelihood(useOld=1) calls per locus and
+   * iteration: (n-1) + (2n-2) + A + mixing */
+  evalsPerLocusIter = (dataSetup.numSamples - 1) + (2 * dataSetup.numSamples - 2) +
+                      (dataSetup.popTree->numPops - dataSetup.popTree->numCurPops) +
+                      (mcmcSetup.doMixing ? 1 : 0);
+  printf("{\"loci\": %d, \"iters\": %d, \"seconds\": %.6f, \"iters_per_s\": %.6f, "
+         "\"evals_per_s\": %.3f, \"nominal_evals_per_locus_iter\": %ld, \"dataLnL\": %.6f}\n",
+         dataSetup.numLoci, iters, t1 - t0, iters / (t1 - t0),
+         (double)evalsPerLocusIter * dataSetup.numLoci * iters / (t1 - t0), evalsPerLocusIter,
+         dataState.dataLogLikelihood);
+  return 0;
+}
+
+static int cmd_rng(int argc, char **argv)
+{
+  unsigned int seed = (unsigned int)strtoul(argv[2], NULL, 10);
+  int count = atoi(argv[3]), i;
+  initRandomGenerator(1, seed);
+  /* slot 0: rndu; slot 1 (general): interleaved rnd2normal8 / rndexp / rndnormal */
+  for (i = 0; i < count; i++) printf("U %a\n", rndu(0));
+  for (i = 0; i < count; i++) {
+    printf("N8 %a\n", rnd2normal8(1));
+    printf("E %a\n", rndexp(1, 0.37));
+    printf("NN %a\n", rndnormal(1));
+  }
+  printf("X %u %u %u %u %u %u\n", RndCtx.rndu_x[0], RndCtx.rndu_y[0], RndCtx.rndu_z[0],
+         RndCtx.rndu_x[1], RndCtx.rndu_y[1], RndCtx.rndu_z[1]);
+  return 0;
+}
+
+static int cmd_reflect(void)
+{
+  /* deterministic table of (x,a,b) triples exercising every branch */
+  static const double as[] = {0.0, 1e-5, 0.25, -3.0};
+  static const double ws[] = {1e-10, 2.5e-9, 1e-6, 0.01, 1.0, 7.5};
+  int ia, iw, k;
+  debug = 0;
+  for (ia = 0; ia < 4; ia++)
+    for (iw = 0; iw < 6; iw++)
+      for (k = -40; k <= 40; k++) {
+        double a = as[ia], b = a + ws[iw];
+        double x = a + ws[iw] * (0.37 * k + 0.011 * k * k * (k % 3 - 1));
+        printf("R %a %a %a %a\n", x, a, b, reflect(x, a, b));
+      }
+  return 0;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 2) { fprintf(stderr, "usage: gphocs_ref pack|run|time|rng|reflect|main ...\n"); return 1; }
+  if (!strcmp(argv[1], "pack") && argc >= 4) return cmd_pack(argv[2], argv[3]);
+  if (!strcmp(argv[1], "run") && argc >= 5) return cmd_run(argc, argv);
+  if (!strcmp(argv[1], "time") && argc >= 4) return cmd_time(argc, argv);
+  if (!strcmp(argv[1], "rng") && argc >= 4) return cmd_rng(argc, argv);
+  if (!strcmp(argv[1], "reflect")) return cmd_reflect();
+  if (!strcmp(argv[1], "main")) return gphocs_main(argc - 1, argv + 1);
+  fprintf(stderr, "bad arguments\n");
+  return 1;
+}

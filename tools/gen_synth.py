@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Synthetic G-PhoCS inputs (own code, seeded, deterministic): a control file in the
+reference's unchanged format (MCMCcontrol.c:575-1256) plus a sequence file in the
+reference's unchanged format (AlignmentProcessor.c:468-860).
+
+Recipe = SURVEY.md section 8(d): per locus, simulate a genealogy under the config's
+population tree at the prior means (theta = alpha/beta, tau = tau-initial, no migration),
+drop JC69 mutations (mu = 1) on a `seqlen`-bp sequence, pair haplotypes into diploids
+(IUPAC het codes Y R M K S W), mask `nmask` of genotypes as N.
+
+Configs mirror BASELINE.json `configs` (index 1..5); --loci overrides L so the same
+shapes can be produced at fixture size.
+"""
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+
+BASES = "TCAG"
+IUPAC = {frozenset("CT"): "Y", frozenset("AG"): "R", frozenset("AC"): "M",
+         frozenset("GT"): "K", frozenset("CG"): "S", frozenset("AT"): "W"}
+
+# name -> (diploid samples per current pop, #bands, ancient-pop index or None)
+CONFIGS = {
+    1: dict(pops=[1, 1, 1, 1], bands=[("D", "B")], loci=1000, sample_ctl=True),
+    2: dict(pops=[2, 1, 1], bands=[], loci=10000),
+    3: dict(pops=[2, 2, 2], bands=[(0, 1), (2, 1)], loci=40000),
+    4: dict(pops=[2, 2, 2, 1, 1], bands=[(0, 1), (1, 0), (3, 2), (4, 3)], loci=100000),
+    5: dict(pops=[2, 2, 2, 1, 1, 1, 1], bands=[(0, 1), (1, 0), (3, 2), (4, 3)], loci=200000,
+            ancient=6),
+}
+
+
+def pop_names(kc):
+    cur = [chr(ord("A") + i) for i in range(kc)]
+    anc = []
+    name = cur[0]
+    for i in range(1, kc):
+        name = name + cur[i]
+        anc.append(name if i < kc - 1 else "root")
+    return cur, anc
+
+
+def build_tree(cfg):
+    """caterpillar population tree: ((((A,B),C),D),...); tau-initial doubles per level"""
+    kc = len(cfg["pops"])
+    cur, anc = pop_names(kc)
+    taus = []
+    t = 5e-6
+    for i in range(kc - 1):
+        taus.append(t)
+        t *= 2.0 if i < kc - 3 else 5.0 if i == kc - 3 else 1.0
+    return cur, anc, taus
+
+
+def write_ctl(path, cfg, seqfile, tracefile, loci, seed, iters, samples_per_log, no_mixing=False,
+              start_mig=0):
+    cur, anc, taus = build_tree(cfg)
+    kc = len(cur)
+    out = []
+    out.append("GENERAL-INFO-START\n")
+    out.append(f"\tseq-file            {seqfile}")
+    out.append(f"\ttrace-file          {tracefile}")
+    out.append("\tlocus-mut-rate          CONST")
+    out.append(f"\tnum-loci            {loci}")
+    out.append(f"\trandom-seed         {seed}")
+    out.append(f"\tmcmc-iterations\t  {iters}")
+    out.append(f"\titerations-per-log  {samples_per_log}")
+    out.append("\tlogs-per-line       10")
+    if start_mig:
+        out.append(f"\tstart-mig           {start_mig}")
+    if no_mixing:
+        out.append("\tno-mixing           1")
+    out.append("")
+    out.append("\tfind-finetunes\t\tFALSE")
+    out.append("\tfinetune-coal-time\t0.01\t\t")
+    out.append("\tfinetune-mig-time\t0.3\t\t")
+    out.append("\tfinetune-theta\t\t0.04")
+    out.append("\tfinetune-mig-rate\t0.02")
+    out.append("\tfinetune-tau\t\t0.0000008")
+    out.append("\tfinetune-mixing\t\t0.003")
+    out.append("")
+    out.append("\ttau-theta-print\t\t10000.0")
+    out.append("\ttau-theta-alpha\t\t1.0")
+    out.append("\ttau-theta-beta\t\t10000.0")
+    out.append("")
+    out.append("\tmig-rate-print\t\t0.001")
+    out.append("\tmig-rate-alpha\t\t0.002")
+    out.append("\tmig-rate-beta\t\t0.00001")
+    out.append("\nGENERAL-INFO-END\n")
+    out.append("CURRENT-POPS-START\t\n")
+    sid = 0
+    for i, nm in enumerate(cur):
+        out.append("\tPOP-START")
+        out.append(f"\t\tname\t\t{nm}")
+        samples = " ".join(f"s{sid + j} d" for j in range(cfg["pops"][i]))
+        sid += cfg["pops"][i]
+        out.append(f"\t\tsamples\t\t{samples}")
+        if cfg.get("ancient") == i:
+            out.append("\t\tage\t\t0.000002 f")
+        out.append("\tPOP-END\n")
+    out.append("CURRENT-POPS-END\n")
+    out.append("ANCESTRAL-POPS-START\n")
+    prev = cur[0]
+    for i, nm in enumerate(anc):
+        out.append("\tPOP-START")
+        out.append(f"\t\tname\t\t\t{nm}")
+        out.append(f"\t\tchildren\t\t{prev}\t\t{cur[i + 1]}")
+        out.append(f"\t\ttau-initial\t{taus[i]:.9f}")
+        out.append("\t\ttau-beta\t\t20000.0\t")
+        ft = 0.0000008 if i < len(anc) - 1 else 0.00000286
+        out.append(f"\t\tfinetune-tau\t\t\t{ft:.8f}")
+        out.append("\tPOP-END\n")
+        prev = nm
+    out.append("ANCESTRAL-POPS-END\n")
+    if cfg["bands"]:
+        out.append("MIG-BANDS-START\t")
+        for (s, t) in cfg["bands"]:
+            sn = s if isinstance(s, str) else cur[s]
+            tn = t if isinstance(t, str) else cur[t]
+            out.append("\tBAND-START\t\t")
+            out.append(f"       source  {sn}")
+            out.append(f"       target  {tn}")
+            out.append("       mig-rate-print 0.1")
+            out.append("\tBAND-END\n")
+        out.append("MIG-BANDS-END")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
+def simulate_locus(rng, cfg, taus, theta, seqlen, ancient_age):
+    """returns list of haploid sequences (np.uint8 arrays of base indices), leaf order =
+    population order then sample order, two haploids per diploid sample"""
+    kc = len(cfg["pops"])
+    # nodes: list of (age, left, right); leaves first
+    nleaf = 2 * sum(cfg["pops"])
+    age = [0.0] * nleaf
+    left = [-1] * nleaf
+    right = [-1] * nleaf
+    leaf = 0
+    pop_lineages = []
+    for i in range(kc):
+        k = 2 * cfg["pops"][i]
+        a0 = ancient_age if cfg.get("ancient") == i else 0.0
+        for j in range(k):
+            age[leaf + j] = a0
+        pop_lineages.append((list(range(leaf, leaf + k)), a0))
+        leaf += k
+
+    def coalesce(lins, t0, t1):
+        t = t0
+        lins = list(lins)
+        while len(lins) > 1:
+            k = len(lins)
+            t += rng.exponential(theta / (k * (k - 1.0)))
+            if t1 is not None and t > t1:
+                break
+            a, b = rng.choice(k, size=2, replace=False)
+            na, nb = lins[a], lins[b]
+            age.append(t)
+            left.append(na)
+            right.append(nb)
+            new = len(age) - 1
+            lins = [x for idx, x in enumerate(lins) if idx not in (a, b)] + [new]
+        return lins
+
+    lins, t0 = pop_lineages[0]
+    lins = coalesce(lins, t0, taus[0])
+    for i in range(1, kc):
+        l2, t2 = pop_lineages[i]
+        l2 = coalesce(l2, t2, taus[i - 1])
+        top = taus[i] if i < kc - 1 else None
+        lins = coalesce(lins + l2, taus[i - 1], top)
+    root = lins[0]
+    seqs = {}
+    seqs[root] = rng.integers(0, 4, size=seqlen, dtype=np.uint8)
+    stack = [root]
+    while stack:
+        nd = stack.pop()
+        for ch in (left[nd], right[nd]):
+            if ch < 0:
+                continue
+            bl = age[nd] - age[ch]
+            p = 0.75 * (1.0 - math.exp(-4.0 * bl / 3.0))
+            s = seqs[nd].copy()
+            hit = rng.random(seqlen) < p
+            nh = int(hit.sum())
+            if nh:
+                s[hit] = (s[hit] + rng.integers(1, 4, size=nh, dtype=np.uint8)) % 4
+            seqs[ch] = s
+            stack.append(ch)
+    return [seqs[i] for i in range(nleaf)]
+
+
+def genotype_strings(haps, rng, nmask):
+    nd = len(haps) // 2
+    out = []
+    for d in range(nd):
+        a, b = haps[2 * d], haps[2 * d + 1]
+        chars = np.array(list(BASES))[a].copy()
+        het = a != b
+        for i in np.nonzero(het)[0]:
+            chars[i] = IUPAC[frozenset((BASES[a[i]], BASES[b[i]]))]
+        mask = rng.random(len(a)) < nmask
+        chars[mask] = "N"
+        out.append("".join(chars))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, required=True, choices=sorted(CONFIGS))
+    ap.add_argument("--loci", type=int, default=None)
+    ap.add_argument("--seqlen", type=int, default=1000)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--per-log", type=int, default=100)
+    ap.add_argument("--mcmc-seed", type=int, default=12345)
+    ap.add_argument("--nmask", type=float, default=0.002)
+    ap.add_argument("--no-mixing", action="store_true")
+    ap.add_argument("--start-mig", type=int, default=0)
+    ap.add_argument("--mut-scale", type=float, default=1.0,
+                    help="scale branch lengths when dropping mutations (more patterns)")
+    ap.add_argument("--out", required=True, help="output prefix: <out>.ctl, <out>.seq")
+    a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    L = a.loci or cfg["loci"]
+    rng = np.random.default_rng(20261002 + a.config)
+    cur, anc, taus = build_tree(cfg)
+    theta = 1e-4
+    seqfile = os.path.basename(a.out) + ".seq"
+    write_ctl(a.out + ".ctl", cfg, seqfile, os.path.basename(a.out) + ".trace", L, a.mcmc_seed,
+              a.iters, a.per_log, no_mixing=a.no_mixing, start_mig=a.start_mig)
+    nd = sum(cfg["pops"])
+    with open(a.out + ".seq", "w") as f:
+        f.write(f"{L}\n\n")
+        for g in range(L):
+            haps = simulate_locus(rng, cfg, [t * a.mut_scale for t in taus], theta * a.mut_scale,
+                                  a.seqlen, 0.000002 * a.mut_scale)
+            gts = genotype_strings(haps, rng, a.nmask)
+            f.write(f"locus{g + 1} {nd} {a.seqlen}\n")
+            for d in range(nd):
+                f.write(f"s{d}\t{gts[d]}\n")
+            f.write("\n")
+    print(f"wrote {a.out}.ctl {a.out}.seq  L={L} samples={nd} diploid", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
