@@ -374,6 +374,7 @@ static int cmd_reflect(void)
   for (ia = 0; ia < 4; ia++)
     for (iw = 0; iw < 6; iw++)
       for (k = -40; k <= 40; k++) {
+        if (k == 0) continue; /* x == a with a 0.5e-9-wide window ping-pongs forever in the reference */
         double a = as[ia], b = a + ws[iw];
         double x = a + ws[iw] * (0.37 * k + 0.011 * k * k * (k % 3 - 1));
         printf("R %a %a %a %a\n", x, a, b, reflect(x, a, b));

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Regenerates every golden vector in this directory from the REAL reference
+# (oracle/_ref/gphocs_ref = /root/reference/src compiled by oracle/Makefile).
+# Only runs where /root/reference exists (the build container).  The fixtures
+# are data: inputs (ctl/seq), the processed-locus pack, per-proposal records
+# (accept counts + accumulators as hex floats) and per-locus state dumps.
+set -euo pipefail
+cd "$(dirname "$0")"
+REPO=$(cd ../.. && pwd)
+make -C "$REPO/oracle" ref >/dev/null
+REF="$REPO/oracle/_ref/gphocs_ref"
+GEN="python3 $REPO/tools/gen_synth.py"
+
+timeout 60 $REF rng 12345 300 > rng_12345.txt
+timeout 60 $REF rng 777 300 > rng_777.txt
+timeout 60 $REF reflect > reflect.txt
+
+gen() { # name config loci seqlen iters perlog extra...
+  local name=$1 cfg=$2 loci=$3 seqlen=$4 iters=$5 perlog=$6; shift 6
+  $GEN --config $cfg --loci $loci --seqlen $seqlen --iters $iters --per-log $perlog --out $name "$@" 2>/dev/null
+  timeout 600 $REF pack $name.ctl $name.gpk >/dev/null
+  timeout 600 $REF run $name.ctl 0 $name.init.rtrace $name.init.state -1 1 >/dev/null
+  timeout 1800 $REF run $name.ctl $iters $name.rtrace $name.state $((iters-1)) 1 >/dev/null
+  rm -f $name.init.rtrace
+}
+gen g1 1 24 400 30 10
+gen g2 2 20 400 30 15
+gen m3 3 16 300 120 40 --mig-beta 0.00000004
+gen m4 4 12 300 60 20 --mig-beta 0.00000004
+gen c5 5 10 300 30 10
+gen s3 3 12 300 40 20 --start-mig 10 --mig-beta 0.0000001 --no-mixing
+ls -la

@@ -56,7 +56,7 @@ def build_tree(cfg):
 
 
 def write_ctl(path, cfg, seqfile, tracefile, loci, seed, iters, samples_per_log, no_mixing=False,
-              start_mig=0):
+              start_mig=0, mig_beta=0.00001):
     cur, anc, taus = build_tree(cfg)
     kc = len(cur)
     out = []
@@ -88,7 +88,7 @@ def write_ctl(path, cfg, seqfile, tracefile, loci, seed, iters, samples_per_log,
     out.append("")
     out.append("\tmig-rate-print\t\t0.001")
     out.append("\tmig-rate-alpha\t\t0.002")
-    out.append("\tmig-rate-beta\t\t0.00001")
+    out.append(f"\tmig-rate-beta\t\t{mig_beta:.10f}")
     out.append("\nGENERAL-INFO-END\n")
     out.append("CURRENT-POPS-START\t\n")
     sid = 0
@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--nmask", type=float, default=0.002)
     ap.add_argument("--no-mixing", action="store_true")
     ap.add_argument("--start-mig", type=int, default=0)
+    ap.add_argument("--mig-beta", type=float, default=0.00001,
+                    help="mig-rate-beta (prior mean = 0.002/beta); small beta = many migration events")
     ap.add_argument("--mut-scale", type=float, default=1.0,
                     help="scale branch lengths when dropping mutations (more patterns)")
     ap.add_argument("--out", required=True, help="output prefix: <out>.ctl, <out>.seq")
@@ -231,7 +233,7 @@ def main():
     theta = 1e-4
     seqfile = os.path.basename(a.out) + ".seq"
     write_ctl(a.out + ".ctl", cfg, seqfile, os.path.basename(a.out) + ".trace", L, a.mcmc_seed,
-              a.iters, a.per_log, no_mixing=a.no_mixing, start_mig=a.start_mig)
+              a.iters, a.per_log, no_mixing=a.no_mixing, start_mig=a.start_mig, mig_beta=a.mig_beta)
     nd = sum(cfg["pops"])
     with open(a.out + ".seq", "w") as f:
         f.write(f"{L}\n\n")
