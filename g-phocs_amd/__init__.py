@@ -1,0 +1,334 @@
+"""g-phocs_amd: host-side Python mirror of the C ABI of libgphocs_hip.so (include/gphocs_hip.h),
+the MI355X-native per-locus likelihood engine for G-PhoCS-style MCMC.
+
+The package directory name contains a hyphen (it is fixed by the project layout), so import it
+through the repo-root alias module `gphocs_amd` (gphocs_amd.py) or importlib.
+
+Python is plumbing only: parsing packs, handing plain buffers to the C ABI, and (multi-GPU)
+providing the RCCL all-reduce through torch.distributed.  All computation is in the HIP library;
+if the library (or a GPU) is missing, construction fails loudly -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libgphocs_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wno-unused-result"]
+
+
+def build(verbose=False):
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, "gph_engine.hip"), os.path.join(CSRC, "gph_mcmc.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(REPO, "include", "gphocs_hip.h")]
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc"] + HIPCC_FLAGS + srcs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+# ------------------------------------------------------------------------------------ C types
+class GphConfig(C.Structure):
+    _fields_ = [("n", C.c_int32), ("Kc", C.c_int32), ("K", C.c_int32), ("B", C.c_int32),
+                ("rootPop", C.c_int32),
+                ("samplesPerPop", C.POINTER(C.c_int32)), ("popFather", C.POINTER(C.c_int32)),
+                ("popSon0", C.POINTER(C.c_int32)), ("popSon1", C.POINTER(C.c_int32)),
+                ("bandSrc", C.POINTER(C.c_int32)), ("bandTgt", C.POINTER(C.c_int32)),
+                ("device", C.c_int32), ("L_total", C.c_int64), ("locus_begin", C.c_int64)]
+
+
+class GphSweepResult(C.Structure):
+    _fields_ = [("accepted_internal", C.c_int64), ("accepted_mignode", C.c_int64),
+                ("accepted_spr", C.c_int64), ("dData_internal", C.c_double),
+                ("dLog_internal", C.c_double), ("dLog_mignode", C.c_double),
+                ("dData_spr", C.c_double), ("dLog_spr", C.c_double), ("total_mig_nodes", C.c_int64)]
+
+
+class GphCounters(C.Structure):
+    _fields_ = [("evals", C.c_int64), ("eval_nodes", C.c_int64), ("eval_bytes", C.c_double),
+                ("not_enough_migs", C.c_int64)]
+
+
+class GphMcmcConfig(C.Structure):
+    _fields_ = [("thetaAlpha", C.POINTER(C.c_double)), ("thetaBeta", C.POINTER(C.c_double)),
+                ("thetaStart", C.POINTER(C.c_double)), ("ageAlpha", C.POINTER(C.c_double)),
+                ("ageBeta", C.POINTER(C.c_double)), ("ageStart", C.POINTER(C.c_double)),
+                ("sampleAge", C.POINTER(C.c_double)), ("mrAlpha", C.POINTER(C.c_double)),
+                ("mrBeta", C.POINTER(C.c_double)),
+                ("ftCoalTime", C.c_double), ("ftMigTime", C.c_double), ("ftTheta", C.c_double),
+                ("ftMigRate", C.c_double), ("ftMixing", C.c_double),
+                ("ftTaus", C.POINTER(C.c_double)),
+                ("seed", C.c_int32), ("startMig", C.c_int32), ("doMixing", C.c_int32),
+                ("samplesPerLog", C.c_int32), ("numParameters", C.c_int32),
+                ("printFactors", C.POINTER(C.c_double))]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32,
+                           C.POINTER(C.c_double), C.c_int32)
+
+EXPORTS = [  # every symbol include/gphocs_hip.h declares
+    "gph_engine_create", "gph_engine_destroy", "gph_engine_set_allreduce", "gph_engine_load_loci",
+    "gph_engine_set_model", "gph_engine_seed", "gph_engine_init_genealogies",
+    "gph_engine_genealogy_sweep", "gph_engine_tau_evaluate", "gph_engine_tau_commit",
+    "gph_engine_tau_revert", "gph_engine_mixing_evaluate", "gph_engine_mixing_commit",
+    "gph_engine_mixing_revert", "gph_engine_apply_theta", "gph_engine_apply_migrate",
+    "gph_engine_get_totals", "gph_engine_synchronize", "gph_engine_check_all",
+    "gph_engine_get_counters", "gph_engine_dump_loci", "gph_engine_last_kernel_ms",
+    "gph_engine_num_loci", "gph_engine_hbm_bytes",
+    "gph_mcmc_create", "gph_mcmc_destroy", "gph_mcmc_initialize", "gph_mcmc_set_record_file",
+    "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
+]
+
+
+def load_library(path=None):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError if an ABI symbol is missing
+    lib.gph_engine_num_loci.restype = C.c_int64
+    lib.gph_engine_destroy.restype = None
+    lib.gph_mcmc_destroy.restype = None
+    lib.gph_engine_seed.argtypes = [C.c_void_p, C.c_uint32]
+    lib.gph_engine_tau_revert.argtypes = [C.c_void_p, C.c_int64]
+    lib.gph_engine_mixing_evaluate.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_double)]
+    lib.gph_engine_mixing_commit.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.gph_engine_genealogy_sweep.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double,
+                                               C.POINTER(GphSweepResult)]
+    lib.gph_engine_apply_theta.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double]
+    lib.gph_engine_apply_migrate.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double]
+    lib.gph_engine_load_loci.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
+    lib.gph_mcmc_iteration.argtypes = [C.c_void_p, C.c_int32]
+    lib.gph_mcmc_dump_state.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    lib.gph_engine_dump_loci.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
+    lib.gph_mcmc_set_record_file.argtypes = [C.c_void_p, C.c_char_p]
+    lib.gph_engine_last_kernel_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
+    lib.gph_engine_get_counters.argtypes = [C.c_void_p, C.POINTER(GphCounters), C.c_int32]
+    lib.gph_engine_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    return lib
+
+
+# ------------------------------------------------------------------------------------ packs
+class Pack:
+    """Model + processed loci (the input of gph_engine_load_loci): what the reference holds
+    after readControlFile + processAlignments (GPhoCS.c:147-235).  Text format written by
+    oracle/ref_harness.c `pack`; synthetic packs for the benchmark come from make_synthetic()."""
+
+    CODES = {"T": 0, "C": 1, "A": 2, "G": 3, "N": 4}
+
+    def __init__(self):
+        self.L = 0
+
+    @staticmethod
+    def load(path):
+        p = Pack()
+        with open(path) as f:
+            tok = f.read().split()
+        it = iter(tok)
+
+        def nxt():
+            return next(it)
+
+        def fl():
+            return float.fromhex(nxt())
+        assert nxt() == "GPHOCS-PACK" and nxt() == "1"
+        for key in ("numLoci", "numSamples", "numCurPops", "numPops", "numMigBands", "rootPop"):
+            assert nxt() == key
+            setattr(p, key, int(nxt()))
+        p.L, p.n, p.Kc, p.K, p.B = p.numLoci, p.numSamples, p.numCurPops, p.numPops, p.numMigBands
+        assert nxt() == "samplesPerPop"
+        p.samplesPerPop = np.array([int(nxt()) for _ in range(p.Kc)], dtype=np.int32)
+        K, B = p.K, p.B
+        p.popName = []
+        p.popFather = np.zeros(K, np.int32)
+        p.popSon0 = np.zeros(K, np.int32)
+        p.popSon1 = np.zeros(K, np.int32)
+        p.sampleAge = np.zeros(K)
+        p.thetaAlpha, p.thetaBeta, p.thetaStart = np.zeros(K), np.zeros(K), np.zeros(K)
+        p.ageAlpha, p.ageBeta, p.ageStart = np.zeros(K), np.zeros(K), np.zeros(K)
+        for k in range(K):
+            assert nxt() == "pop" and int(nxt()) == k
+            p.popName.append(nxt())
+            p.popFather[k], p.popSon0[k], p.popSon1[k] = int(nxt()), int(nxt()), int(nxt())
+            p.sampleAge[k] = fl()
+            nxt()  # updateSampleAge
+            p.thetaAlpha[k], p.thetaBeta[k], p.thetaStart[k] = fl(), fl(), fl()
+            p.ageAlpha[k], p.ageBeta[k], p.ageStart[k] = fl(), fl(), fl()
+        p.bandSrc, p.bandTgt = np.zeros(max(B, 1), np.int32), np.zeros(max(B, 1), np.int32)
+        p.mrAlpha, p.mrBeta = np.zeros(max(B, 1)), np.ones(max(B, 1))
+        for b in range(B):
+            assert nxt() == "band" and int(nxt()) == b
+            p.bandSrc[b], p.bandTgt[b] = int(nxt()), int(nxt())
+            p.mrAlpha[b], p.mrBeta[b] = fl(), fl()
+        assert nxt() == "mcmc"
+        (p.seed, p.burnin, p.numSamplesMcmc, p.sampleSkip, p.startMig, p.doMixing, p.samplesPerLog,
+         p.mutRateMode) = [int(nxt()) for _ in range(8)]
+        assert nxt() == "finetunes"
+        p.ftCoalTime, p.ftMigTime, p.ftTheta, p.ftMigRate, p.ftMixing = fl(), fl(), fl(), fl(), fl()
+        p.ftTaus = np.array([fl() for _ in range(K)])
+        assert nxt() == "printFactors"
+        p.numParameters = int(nxt())
+        p.printFactors = np.array([fl() for _ in range(p.numParameters)])
+        offs, leaf, phases, counts, rates = [0], [], [], [], []
+        for g in range(p.L):
+            assert nxt() == "locus" and int(nxt()) == g
+            P = int(nxt())
+            rates.append(fl())
+            for _ in range(P):
+                s = nxt()
+                assert len(s) == p.n
+                leaf.append([Pack.CODES[ch] for ch in s])
+                phases.append(int(nxt()))
+                counts.append(int(nxt()))
+            offs.append(offs[-1] + P)
+        p.pattern_offsets = np.array(offs, dtype=np.int64)
+        p.leafcodes = np.array(leaf, dtype=np.uint8).reshape(-1, p.n)
+        p.numPhases = np.array(phases, dtype=np.uint8)
+        p.counts = np.array(counts, dtype=np.int32)
+        p.mutRates = np.array(rates)
+        return p
+
+    def shard(self, rank, world):
+        """contiguous block of ceil(L/world) loci (mirrors OpenMP static scheduling,
+        MultiCoreUtils.h:8); returns (begin, end)"""
+        per = (self.L + world - 1) // world
+        return min(rank * per, self.L), min((rank + 1) * per, self.L)
+
+
+def _dp(a):
+    return np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Sampler:
+    """Engine + host MCMC driver for one rank's shard of a Pack."""
+
+    def __init__(self, pack, lib=None, device=0, rank=0, world=1, allreduce=None):
+        self.lib = lib or load_library()
+        self.pack = pack
+        self.rank, self.world = rank, world
+        self.begin, self.end = pack.shard(rank, world)
+        p = pack
+        self._keep = dict(spp=np.ascontiguousarray(p.samplesPerPop, np.int32),
+                          pf=np.ascontiguousarray(p.popFather, np.int32),
+                          s0=np.ascontiguousarray(p.popSon0, np.int32),
+                          s1=np.ascontiguousarray(p.popSon1, np.int32),
+                          bs=np.ascontiguousarray(p.bandSrc, np.int32),
+                          bt=np.ascontiguousarray(p.bandTgt, np.int32))
+        k = self._keep
+        self.cfg = GphConfig(p.n, p.Kc, p.K, p.B, p.rootPop, _ip(k["spp"]), _ip(k["pf"]), _ip(k["s0"]),
+                             _ip(k["s1"]), _ip(k["bs"]), _ip(k["bt"]), device, p.L, self.begin)
+        self.engine = C.c_void_p()
+        self._chk(self.lib.gph_engine_create(C.byref(self.cfg), C.byref(self.engine)), "engine_create")
+        self._cb = None
+        if allreduce is not None:
+            def _cb(user, sums, nsum, mins, nmin):
+                try:
+                    s = np.ctypeslib.as_array(sums, shape=(nsum,)) if nsum else np.zeros(0)
+                    m = np.ctypeslib.as_array(mins, shape=(nmin,)) if nmin else np.zeros(0)
+                    allreduce(s, m)
+                    return 0
+                except Exception as ex:  # pragma: no cover
+                    print("allreduce callback failed:", ex)
+                    return 1
+            self._cb = ALLREDUCE_FN(_cb)
+            self._chk(self.lib.gph_engine_set_allreduce(self.engine, self._cb, None), "set_allreduce")
+        b, e = self.begin, self.end
+        o0, o1 = p.pattern_offsets[b], p.pattern_offsets[e]
+        offs = np.ascontiguousarray(p.pattern_offsets[b:e + 1] - o0, dtype=np.int64)
+        leaf = np.ascontiguousarray(p.leafcodes[o0:o1])
+        ph = np.ascontiguousarray(p.numPhases[o0:o1])
+        cn = np.ascontiguousarray(p.counts[o0:o1])
+        rates = np.ascontiguousarray(p.mutRates[b:e], dtype=np.float64)
+        use_rates = bool(np.any(rates != 1.0))
+        self._chk(self.lib.gph_engine_load_loci(self.engine, e - b, offs.ctypes.data, leaf.ctypes.data,
+                                                ph.ctypes.data, cn.ctypes.data,
+                                                rates.ctypes.data if use_rates else None), "load_loci")
+        k.update(ta=p.thetaAlpha, tb=p.thetaBeta, ts=p.thetaStart, aa=p.ageAlpha, ab=p.ageBeta,
+                 as_=p.ageStart, sa=p.sampleAge, ma=p.mrAlpha, mb=p.mrBeta, ft=p.ftTaus, pf_=p.printFactors)
+        self.mcfg = GphMcmcConfig(_dp(k["ta"]), _dp(k["tb"]), _dp(k["ts"]), _dp(k["aa"]), _dp(k["ab"]),
+                                  _dp(k["as_"]), _dp(k["sa"]), _dp(k["ma"]), _dp(k["mb"]),
+                                  p.ftCoalTime, p.ftMigTime, p.ftTheta, p.ftMigRate, p.ftMixing,
+                                  _dp(k["ft"]), p.seed, p.startMig, p.doMixing, p.samplesPerLog,
+                                  p.numParameters, _dp(k["pf_"]))
+        self.mcmc = C.c_void_p()
+        self._chk(self.lib.gph_mcmc_create(self.engine, C.byref(self.cfg), C.byref(self.mcfg),
+                                           C.byref(self.mcmc)), "mcmc_create")
+
+    @staticmethod
+    def _chk(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"gphocs_hip: {what} failed with status {rc}")
+
+    def set_record_file(self, path):
+        self._chk(self.lib.gph_mcmc_set_record_file(self.mcmc, path.encode() if path else None), "record")
+
+    def initialize(self):
+        tc = C.c_int64()
+        self._chk(self.lib.gph_mcmc_initialize(self.mcmc, C.byref(tc)), "initialize")
+        return tc.value
+
+    def iteration(self, it):
+        self._chk(self.lib.gph_mcmc_iteration(self.mcmc, it), f"iteration {it}")
+
+    def state(self):
+        ll, dl = C.c_double(), C.c_double()
+        th, ag, mr = np.zeros(self.pack.K), np.zeros(self.pack.K), np.zeros(max(self.pack.B, 1))
+        self._chk(self.lib.gph_mcmc_get_state(self.mcmc, C.byref(ll), C.byref(dl), _dp(th), _dp(ag), _dp(mr)),
+                  "get_state")
+        return dict(logLikelihood=ll.value, dataLogLikelihood=dl.value, theta=th, popAge=ag,
+                    migRate=mr[:self.pack.B])
+
+    def dump_state(self, path, with_cond=False):
+        self._chk(self.lib.gph_mcmc_dump_state(self.mcmc, path.encode(), int(with_cond)), "dump_state")
+
+    def counters(self, reset=False):
+        c = GphCounters()
+        self._chk(self.lib.gph_engine_get_counters(self.engine, C.byref(c), int(reset)), "counters")
+        return dict(evals=c.evals, eval_nodes=c.eval_nodes, eval_bytes=c.eval_bytes,
+                    not_enough_migs=c.not_enough_migs)
+
+    def accept_counts(self):
+        a = (C.c_int64 * 9)()
+        self._chk(self.lib.gph_mcmc_accept_counts(self.mcmc, a), "accept_counts")
+        return list(a)
+
+    def last_kernel_ms(self, which):
+        ms = C.c_double()
+        self._chk(self.lib.gph_engine_last_kernel_ms(self.engine, which, C.byref(ms)), "kernel_ms")
+        return ms.value
+
+    def hbm_bytes(self):
+        b = C.c_double()
+        self._chk(self.lib.gph_engine_hbm_bytes(self.engine, C.byref(b)), "hbm_bytes")
+        return b.value
+
+    def close(self):
+        if self.mcmc:
+            self.lib.gph_mcmc_destroy(self.mcmc)
+            self.mcmc = None
+        if self.engine:
+            self.lib.gph_engine_destroy(self.engine)
+            self.engine = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,760 @@
+// gph_engine.hip -- host side of the engine + __global__ wrappers (C ABI: include/gphocs_hip.h).
+//
+// Launch geometry: one 64-lane workgroup (one wavefront) per locus, grid = loci; the
+// per-wave dynamic LDS holds the whole mutable state of the locus, so the number of
+// resident waves per CU is LDS-bound (160 KiB / lds_bytes) -- L >> 256 CUs x waves/CU
+// keeps every XCD busy and needs no blockIdx remap (loci are independent, nothing is
+// shared between workgroups, so L2 affinity is irrelevant).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "gph_kernels.h"
+#include "../../include/gphocs_hip.h"
+
+#ifdef GPH_HOSTEMU
+thread_local char *gph_sm = nullptr;
+GphLayout g_lay;
+GphModel g_model;
+#define GPH_KERNEL(name, ...) static void name(int gph_blk, __VA_ARGS__)
+#define GPH_BLK gph_blk
+#else
+__constant__ GphLayout g_lay;
+__constant__ GphModel g_model;
+#define GPH_KERNEL(name, ...) __global__ __launch_bounds__(GPH_WAVE) void name(__VA_ARGS__)
+#define GPH_BLK ((int)blockIdx.x)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "gphocs_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return GPH_EHIP; } } while (0)
+#endif
+
+GPH_KERNEL(k_init, GphDev D, uint32_t seedz, const double *mutRate) { kb_init(D, GPH_BLK, seedz, mutRate ? mutRate[GPH_BLK] : 1.0); }
+GPH_KERNEL(k_sweep, GphDev D, int flags, double ftCoal, double ftMig) { kb_sweep(D, GPH_BLK, flags, ftCoal, ftMig); }
+GPH_KERNEL(k_tau_eval, GphDev D, GphTauArgs A) { kb_tau_eval(D, GPH_BLK, A); }
+GPH_KERNEL(k_tau_commit, GphDev D, GphTauArgs A) { kb_tau_commit(D, GPH_BLK, A); }
+GPH_KERNEL(k_tau_revert, GphDev D, int limit) { kb_tau_revert(D, GPH_BLK, limit); }
+GPH_KERNEL(k_mix_eval, GphDev D, double c) { kb_mix_eval(D, GPH_BLK, c); }
+GPH_KERNEL(k_mix_commit, GphDev D, double c, double lnc) { kb_mix_commit(D, GPH_BLK, c, lnc); }
+GPH_KERNEL(k_sync, GphDev D, int refresh) { kb_sync(D, GPH_BLK, refresh); }
+GPH_KERNEL(k_check, GphDev D) { kb_check(D, GPH_BLK); }
+
+// ---------------------------------------------------------------- small elementwise / reduction kernels
+#define GPH_RED_BLOCKS 256
+#define GPH_RED_COLS 128   // >= 2K+2B and >= GPH_OUT_SLOTS
+
+#ifndef GPH_HOSTEMU
+// UpdateTheta accepted: genLogLikelihood touch-up, GPhoCS.c:3084-3093 (one thread per locus)
+__global__ void k_apply_theta(GphDev D, int pop, double lnc, double inv_diff)
+{
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= D.L) return;
+  char *pg = D.pages + (size_t)g * g_lay.page_bytes;
+  double *fs = (double *)(pg + g_lay.o_fscal);
+  int nc = ((int16_t *)(pg + g_lay.o_ncoal))[pop];
+  double cs = ((double *)(pg + g_lay.o_coal))[pop];
+  fs[FS_GENLNL] -= (lnc * nc + inv_diff * cs);
+}
+// UpdateMigRates accepted: GPhoCS.c:3192-3200
+__global__ void k_apply_migrate(GphDev D, int band, double lnc, double rate_diff)
+{
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= D.L) return;
+  char *pg = D.pages + (size_t)g * g_lay.page_bytes;
+  double *fs = (double *)(pg + g_lay.o_fscal);
+  int nm = ((int16_t *)(pg + g_lay.o_nmig))[band];
+  double ms = ((double *)(pg + g_lay.o_migst))[band];
+  fs[FS_GENLNL] += (lnc * nm - rate_diff * ms);
+}
+// column value of locus g: mode 0 = out slots, mode 1 = page statistics
+// (coal_stats[K], num_coals[K], mig_stats[B], num_migs[B])
+__device__ inline double red_value(const GphDev &D, int mode, int g, int col)
+{
+  if (mode == 0) return D.out[(size_t)g * GPH_OUT_SLOTS + col];
+  const char *pg = D.pages + (size_t)g * g_lay.page_bytes;
+  const int K = g_lay.K, B = g_lay.B;
+  if (col < K) return ((const double *)(pg + g_lay.o_coal))[col];
+  if (col < 2 * K) return (double)((const int16_t *)(pg + g_lay.o_ncoal))[col - K];
+  if (col < 2 * K + B) return ((const double *)(pg + g_lay.o_migst))[col - 2 * K];
+  return (double)((const int16_t *)(pg + g_lay.o_nmig))[col - 2 * K - B];
+}
+// fixed-shape two-level reduction (deterministic run to run): block b sums a contiguous
+// chunk of loci in index order per column; the final pass adds the 256 partials in order.
+// part: [3][GPH_RED_BLOCKS][GPH_RED_COLS] (sum, min, max)
+__global__ void k_reduce_partial(GphDev D, int mode, int ncols, double *part)
+{
+  int col = threadIdx.x, b = blockIdx.x;
+  if (col >= ncols) return;
+  int chunk = (D.L + GPH_RED_BLOCKS - 1) / GPH_RED_BLOCKS;
+  int g0 = b * chunk, g1 = g0 + chunk < D.L ? g0 + chunk : D.L;
+  double s = 0.0, mn = 1e300, mx = -1e300;
+  for (int g = g0; g < g1; g++) {
+    double v = red_value(D, mode, g, col);
+    s += v;
+    mn = v < mn ? v : mn;
+    mx = v > mx ? v : mx;
+  }
+  part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = s;
+  part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = mn;
+  part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = mx;
+}
+__global__ void k_reduce_final(int ncols, const double *part, double *red)
+{
+  int col = threadIdx.x;
+  if (col >= ncols) return;
+  double s = 0.0, mn = 1e300, mx = -1e300;
+  for (int b = 0; b < GPH_RED_BLOCKS; b++) {
+    s += part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
+    double v = part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
+    mn = v < mn ? v : mn;
+    v = part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
+    mx = v > mx ? v : mx;
+  }
+  red[col] = s;
+  red[GPH_RED_COLS + col] = mn;
+  red[2 * GPH_RED_COLS + col] = mx;
+}
+#endif
+
+// ---------------------------------------------------------------- engine object
+struct gph_engine {
+  gph_config cfg;
+  std::vector<int32_t> samplesPerPop, popFather, popSon0, popSon1, bandSrc, bandTgt;
+  GphLayout lay;
+  GphModel model;
+  GphDev dev;
+  GphTauArgs tau;          // args of the pending tau proposal
+  int64_t L = 0;
+  size_t cond_bytes = 0, pages_bytes = 0;
+  std::vector<uint64_t> h_cond_off;
+  std::vector<int32_t> h_P;
+  double *d_mutRate = nullptr;
+  double *d_part = nullptr, *d_red = nullptr;
+  double h_red[3 * GPH_RED_COLS];
+  gph_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
+  uint32_t seedz = 0;
+  bool loaded = false, seeded = false, model_set = false, initialized = false;
+  gph_counters counters = {0, 0, 0.0, 0};
+  double last_ms[8] = {0};
+#ifndef GPH_HOSTEMU
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+#else
+  std::vector<char> lds;
+#endif
+};
+
+static int align_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// page + LDS layout for (n, K, B): everything sized by the ACTUAL dimensions, not by the
+// reference's MAX_* caps (sizeof(Locus_SuperStruct) alone is 9.7 KB there)
+static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop, int Pmax)
+{
+  memset(&y, 0, sizeof y);
+  y.n = n; y.N = 2 * n - 1; y.K = K; y.Kc = Kc; y.B = B; y.rootPop = rootPop;
+  y.E = 2 * n + 4 * GPH_MAX_MIGS + 3 * B + K + 10;   // event pool, patch.c:92
+  y.RB = GPH_MAX_MIGS + 2 * B;
+  int o = 0;
+  auto f64 = [&](int cnt) { o = align_up(o, 8); int r = o; o += 8 * cnt; return r; };
+  auto i16 = [&](int cnt) { o = align_up(o, 2); int r = o; o += 2 * cnt; return r; };
+  auto i32 = [&](int cnt) { o = align_up(o, 4); int r = o; o += 4 * cnt; return r; };
+  auto u8 = [&](int cnt) { int r = o; o += cnt; return r; };
+  y.o_age = f64(y.N); y.o_sv_age = f64(y.N); y.o_ev_time = f64(y.E); y.o_mig_age = f64(GPH_MAX_MIGS);
+  y.o_coal = f64(K); y.o_migst = f64(B > 0 ? B : 1); y.o_rb_age = f64(y.RB); y.o_fscal = f64(FS_COUNT);
+  y.o_iscal = i32(IS_COUNT);
+  y.o_father = i16(y.N); y.o_left = i16(y.N); y.o_right = i16(y.N); y.o_npop = i16(y.N); y.o_nev = i16(y.N);
+  y.o_sv_father = i16(y.N); y.o_sv_left = i16(y.N); y.o_sv_right = i16(y.N);
+  y.o_changed = i16(2 * y.N); y.o_changedc = i16(2 * y.N);
+  y.o_ev_next = i16(y.E); y.o_ev_prev = i16(y.E); y.o_ev_node = i16(y.E); y.o_ev_nlin = i16(y.E);
+  y.o_first = i16(K);
+  y.o_mig_i = i16(GPH_MAX_MIGS * MG_COUNT); y.o_living = i16(GPH_MAX_MIGS);
+  y.o_ncoal = i16(K); y.o_nmig = i16(B > 0 ? B : 1); y.o_rb_i = i16(3 * y.RB);
+  y.o_ev_type = u8(y.E); y.o_condbit = u8(y.N); y.o_dirty = u8(y.N);
+  y.page_bytes = align_up(o, 16);
+  // LDS-only scratch
+  o = y.page_bytes;
+  y.o_scratch = o;
+  for (int k = 0; k < 2; k++) {
+    y.s_dcoal[k] = f64(K); y.s_dmig[k] = f64(B > 0 ? B : 1);
+  }
+  y.s_sprf = f64(GPH_MAX_MIGS + 2); y.s_terms = f64(Pmax); y.s_chkcoal = f64(K); y.s_chkmig = f64(B > 0 ? B : 1);
+  y.s_cntf = f64(2);
+  for (int k = 0; k < 2; k++) y.s_di[k] = i32(DI_COUNT);
+  y.s_spri = i32(SI_COUNT); y.s_cnt = i32(CN_COUNT);
+  for (int k = 0; k < 2; k++) { y.s_dev[k] = i16(y.E); y.s_dpops[k] = i16(K); y.s_dbands[k] = i16(B > 0 ? B : 1); }
+  y.s_spri16 = i16(4 * GPH_MAX_MIGS); y.s_ord = i16(y.N + 1); y.s_stack = i16(y.N + 1); y.s_targets = i16(y.N + 1);
+  y.s_chknc = i16(K); y.s_chknm = i16(B > 0 ? B : 1);
+  o = align_up(o, 16);
+  y.scratch_bytes = o - y.page_bytes;
+  // sequence block (fixed size per locus, also the HBM block size)
+  y.o_seq = o;
+  y.q_leaf = o; o += Pmax * n;
+  y.q_phases = o; o += Pmax;
+  o = align_up(o, 4);
+  y.q_count = o; o += 4 * Pmax;
+  o = align_up(o, 16);
+  // conditionals [2][n-1][P][4] fp64
+  y.o_cond = o;
+  o += 2 * (n - 1) * Pmax * 32;
+  y.Pmax = Pmax;
+  y.lds_bytes = align_up(o, 16);
+}
+
+static void build_model_static(gph_engine *e)
+{
+  GphModel &m = e->model;
+  const gph_config &c = e->cfg;
+  memset(&m, 0, sizeof m);
+  for (int p = 0; p < c.K; p++) {
+    m.popFather[p] = (int16_t)e->popFather[p];
+    m.popSon0[p] = (int16_t)e->popSon0[p];
+    m.popSon1[p] = (int16_t)e->popSon1[p];
+    uint32_t mask = 0;
+    for (int d = 0; d < c.K; d++) {           // isAncestralTo, self-inclusive (MCMCcontrol.c:851,977,1015-1024)
+      int x = d;
+      while (x >= 0) { if (x == p) { mask |= 1u << d; break; } x = e->popFather[x]; }
+    }
+    m.isAnc[p] = mask;
+  }
+  int cum = 0;
+  for (int p = 0; p < c.Kc; p++) { m.samplesPerPop[p] = (int16_t)e->samplesPerPop[p]; cum += e->samplesPerPop[p]; m.cumSamples[p] = cum; }
+  for (int b = 0; b < c.B; b++) { m.bandSrc[b] = (int16_t)e->bandSrc[b]; m.bandTgt[b] = (int16_t)e->bandTgt[b]; }
+  // populationPostOrder(rootPop), patch.c:1936-1951
+  std::vector<int> order;
+  struct Rec { static void go(gph_engine *e, int pop, std::vector<int> &o) {
+    if (pop >= e->cfg.Kc) { go(e, e->popSon0[pop], o); go(e, e->popSon1[pop], o); }
+    o.push_back(pop); } };
+  Rec::go(e, c.rootPop, order);
+  for (size_t i = 0; i < order.size(); i++) m.postOrder[i] = (int16_t)order[i];
+}
+
+// ---------------------------------------------------------------- runtime shim
+#ifdef GPH_HOSTEMU
+static int dev_alloc(void **p, size_t bytes) { *p = calloc(1, bytes ? bytes : 1); return *p ? 0 : GPH_EHIP; }
+static void dev_free(void *p) { free(p); }
+static int h2d(gph_engine *, void *d, const void *h, size_t n) { memcpy(d, h, n); return 0; }
+static int d2h(gph_engine *, void *h, const void *d, size_t n) { memcpy(h, d, n); return 0; }
+static int upload_tables(gph_engine *e) { g_lay = e->lay; g_model = e->model; return 0; }
+#define LAUNCH(e, which, name, ...) do { upload_tables(e); (e)->lds.assign((e)->lay.lds_bytes + 64, 0); \
+    gph_sm = (e)->lds.data(); for (int b_ = 0; b_ < (int)(e)->L; b_++) name(b_, __VA_ARGS__); } while (0)
+#else
+static int dev_alloc(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess ? 0 : GPH_EHIP; }
+static void dev_free(void *p) { if (p) (void)hipFree(p); }
+static int h2d(gph_engine *e, void *d, const void *h, size_t n)
+{
+  HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+static int d2h(gph_engine *e, void *h, const void *d, size_t n)
+{
+  HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+static int upload_tables(gph_engine *e)
+{
+  HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lay), &e->lay, sizeof(GphLayout), 0, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_model), &e->model, sizeof(GphModel), 0, hipMemcpyHostToDevice, e->stream));
+  return 0;
+}
+// timed launch: HIP events on the engine's own stream bracket the kernel
+#define LAUNCH(e, which, name, ...) do { int rc_ = upload_tables(e); if (rc_) return rc_; \
+    HIPCHK(hipEventRecord((e)->ev0, (e)->stream)); \
+    hipLaunchKernelGGL(name, dim3((unsigned)(e)->L), dim3(GPH_WAVE), (e)->lay.lds_bytes, (e)->stream, __VA_ARGS__); \
+    HIPCHK(hipGetLastError()); \
+    HIPCHK(hipEventRecord((e)->ev1, (e)->stream)); \
+    HIPCHK(hipEventSynchronize((e)->ev1)); \
+    float ms_ = 0; HIPCHK(hipEventElapsedTime(&ms_, (e)->ev0, (e)->ev1)); (e)->last_ms[which] = ms_; } while (0)
+#endif
+
+// reduce the per-locus outputs (mode 0) or page statistics (mode 1) over local loci
+static int reduce_local(gph_engine *e, int mode, int ncols)
+{
+#ifdef GPH_HOSTEMU
+  for (int c = 0; c < ncols; c++) {
+    double s = 0, mn = 1e300, mx = -1e300;
+    for (int64_t g = 0; g < e->L; g++) {
+      double v;
+      if (mode == 0) v = e->dev.out[(size_t)g * GPH_OUT_SLOTS + c];
+      else {
+        const char *pg = e->dev.pages + (size_t)g * e->lay.page_bytes;
+        const int K = e->lay.K, B = e->lay.B;
+        if (c < K) v = ((const double *)(pg + e->lay.o_coal))[c];
+        else if (c < 2 * K) v = ((const int16_t *)(pg + e->lay.o_ncoal))[c - K];
+        else if (c < 2 * K + B) v = ((const double *)(pg + e->lay.o_migst))[c - 2 * K];
+        else v = ((const int16_t *)(pg + e->lay.o_nmig))[c - 2 * K - B];
+      }
+      s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+    }
+    e->h_red[c] = s; e->h_red[GPH_RED_COLS + c] = mn; e->h_red[2 * GPH_RED_COLS + c] = mx;
+  }
+  return 0;
+#else
+  hipLaunchKernelGGL(k_reduce_partial, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_COLS), 0, e->stream, e->dev, mode, ncols, e->d_part);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(GPH_RED_COLS), 0, e->stream, ncols, e->d_part, e->d_red);
+  HIPCHK(hipGetLastError());
+  return d2h(e, e->h_red, e->d_red, sizeof(double) * 3 * GPH_RED_COLS);
+#endif
+}
+#define RSUM(e, c) ((e)->h_red[(c)])
+#define RMIN(e, c) ((e)->h_red[GPH_RED_COLS + (c)])
+#define RMAX(e, c) ((e)->h_red[2 * GPH_RED_COLS + (c)])
+
+static int finish_kernel(gph_engine *e)
+{
+  int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
+  if (rc) return rc;
+  e->counters.evals += (int64_t)RSUM(e, 8);
+  e->counters.eval_nodes += (int64_t)RSUM(e, 9);
+  e->counters.eval_bytes += RSUM(e, 10);
+  e->counters.not_enough_migs += (int64_t)RSUM(e, 13);
+  if (RMAX(e, 11) != 0.0) {
+    fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by a locus kernel\n", (int)RMAX(e, 11));
+    return GPH_EKERNEL;
+  }
+  return 0;
+}
+static int xreduce(gph_engine *e, double *sums, int nsum, double *mins, int nmin)
+{
+  if (e->allreduce) return e->allreduce(e->allreduce_user, sums, nsum, mins, nmin) ? GPH_EHIP : 0;
+  return 0;
+}
+
+// ---------------------------------------------------------------- C ABI
+extern "C" {
+
+int gph_engine_create(const gph_config *cfg, gph_engine **out)
+{
+  if (!cfg || !out) return GPH_EARG;
+  if (cfg->n < 2 || cfg->n > 32 || cfg->K > GPH_MAXK || cfg->B > GPH_MAXB || cfg->K != 2 * cfg->Kc - 1) {
+    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (caps: n<=32, K<=%d, B<=%d)\n", cfg->n, cfg->K, cfg->B, GPH_MAXK, GPH_MAXB);
+    return GPH_EARG;
+  }
+  gph_engine *e = new gph_engine();
+  e->cfg = *cfg;
+  e->samplesPerPop.assign(cfg->samplesPerPop, cfg->samplesPerPop + cfg->Kc);
+  e->popFather.assign(cfg->popFather, cfg->popFather + cfg->K);
+  e->popSon0.assign(cfg->popSon0, cfg->popSon0 + cfg->K);
+  e->popSon1.assign(cfg->popSon1, cfg->popSon1 + cfg->K);
+  if (cfg->B > 0) { e->bandSrc.assign(cfg->bandSrc, cfg->bandSrc + cfg->B); e->bandTgt.assign(cfg->bandTgt, cfg->bandTgt + cfg->B); }
+  e->cfg.samplesPerPop = e->samplesPerPop.data();
+  e->cfg.popFather = e->popFather.data();
+  e->cfg.popSon0 = e->popSon0.data();
+  e->cfg.popSon1 = e->popSon1.data();
+  e->cfg.bandSrc = e->bandSrc.data();
+  e->cfg.bandTgt = e->bandTgt.data();
+  memset(&e->dev, 0, sizeof e->dev);
+  build_model_static(e);
+#ifndef GPH_HOSTEMU
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) {
+    fprintf(stderr, "gphocs_hip: no usable HIP device %d (found %d) -- this library has no CPU path\n", cfg->device, ndev);
+    delete e;
+    return GPH_EHIP;
+  }
+  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess ||
+      hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) { delete e; return GPH_EHIP; }
+#endif
+  *out = e;
+  return 0;
+}
+
+void gph_engine_destroy(gph_engine *e)
+{
+  if (!e) return;
+  dev_free(e->dev.pages); dev_free(e->dev.shadow); dev_free(e->dev.cond); dev_free((void *)e->dev.cond_off);
+  dev_free((void *)e->dev.seq); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->d_mutRate);
+  dev_free(e->d_part); dev_free(e->d_red);
+#ifndef GPH_HOSTEMU
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+#endif
+  delete e;
+}
+
+int gph_engine_set_allreduce(gph_engine *e, gph_allreduce_fn fn, void *user)
+{
+  if (!e) return GPH_EARG;
+  e->allreduce = fn;
+  e->allreduce_user = user;
+  return 0;
+}
+
+int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const uint8_t *leafcodes,
+                         const uint8_t *numPhases, const int32_t *counts, const double *mutRates)
+{
+  if (!e || L <= 0 || !poff || !leafcodes || !numPhases || !counts) return GPH_EARG;
+  const int n = e->cfg.n;
+  int Pmax = 1;
+  for (int64_t g = 0; g < L; g++) { int P = (int)(poff[g + 1] - poff[g]); if (P > Pmax) Pmax = P; if (P < 1) return GPH_EARG; }
+  build_layout(e->lay, n, e->cfg.Kc, e->cfg.K, e->cfg.B, e->cfg.rootPop, Pmax);
+  if (e->lay.lds_bytes > 160 * 1024) {
+    fprintf(stderr, "gphocs_hip: a locus with %d phased patterns needs %d bytes of LDS (> 160 KiB)\n", Pmax, e->lay.lds_bytes);
+    return GPH_EARG;
+  }
+  e->L = L;
+  const int seq_bytes = e->lay.o_cond - e->lay.o_seq;
+  std::vector<char> seq((size_t)L * seq_bytes, 0);
+  e->h_cond_off.resize(L + 1);
+  e->h_P.resize(L);
+  uint64_t off = 0;
+  for (int64_t g = 0; g < L; g++) {
+    int P = (int)(poff[g + 1] - poff[g]);
+    e->h_P[g] = P;
+    e->h_cond_off[g] = off;
+    off += (uint64_t)2 * (n - 1) * P * 32;
+    char *blk = seq.data() + (size_t)g * seq_bytes;
+    for (int p = 0; p < P; p++) {
+      for (int i = 0; i < n; i++) {
+        uint8_t c = leafcodes[(size_t)(poff[g] + p) * n + i];
+        if (c > 4) return GPH_EARG;
+        blk[(e->lay.q_leaf - e->lay.o_seq) + p * n + i] = (char)c;
+      }
+      blk[(e->lay.q_phases - e->lay.o_seq) + p] = (char)numPhases[poff[g] + p];
+      ((int32_t *)(blk + (e->lay.q_count - e->lay.o_seq)))[p] = counts[poff[g] + p];
+    }
+  }
+  e->h_cond_off[L] = off;
+  e->cond_bytes = off;
+  e->pages_bytes = (size_t)L * e->lay.page_bytes;
+  int rc = 0;
+  rc |= dev_alloc((void **)&e->dev.pages, e->pages_bytes);
+  rc |= dev_alloc((void **)&e->dev.shadow, e->pages_bytes);
+  rc |= dev_alloc((void **)&e->dev.cond, e->cond_bytes);
+  rc |= dev_alloc((void **)&e->dev.cond_off, sizeof(uint64_t) * (L + 1));
+  rc |= dev_alloc((void **)&e->dev.seq, seq.size());
+  rc |= dev_alloc((void **)&e->dev.P, sizeof(int32_t) * L);
+  rc |= dev_alloc((void **)&e->dev.out, sizeof(double) * GPH_OUT_SLOTS * L);
+  rc |= dev_alloc((void **)&e->d_part, sizeof(double) * 3 * GPH_RED_BLOCKS * GPH_RED_COLS);
+  rc |= dev_alloc((void **)&e->d_red, sizeof(double) * 3 * GPH_RED_COLS);
+  if (mutRates) rc |= dev_alloc((void **)&e->d_mutRate, sizeof(double) * L);
+  if (rc) { fprintf(stderr, "gphocs_hip: device allocation failed\n"); return GPH_EHIP; }
+  rc |= h2d(e, (void *)e->dev.cond_off, e->h_cond_off.data(), sizeof(uint64_t) * (L + 1));
+  rc |= h2d(e, (void *)e->dev.seq, seq.data(), seq.size());
+  rc |= h2d(e, (void *)e->dev.P, e->h_P.data(), sizeof(int32_t) * L);
+  if (mutRates) rc |= h2d(e, e->d_mutRate, mutRates, sizeof(double) * L);
+  if (rc) return GPH_EHIP;
+  e->dev.L = (int32_t)L;
+  e->dev.Ltot = (int32_t)e->cfg.L_total;
+  e->dev.seq_bytes = seq_bytes;
+  e->loaded = true;
+#ifndef GPH_HOSTEMU
+  // every per-locus kernel uses the same dynamic LDS size; allow > 64 KiB
+  const void *ks[] = {(const void *)k_init, (const void *)k_sweep, (const void *)k_tau_eval, (const void *)k_tau_commit,
+                      (const void *)k_tau_revert, (const void *)k_mix_eval, (const void *)k_mix_commit,
+                      (const void *)k_sync, (const void *)k_check};
+  for (auto k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, e->lay.lds_bytes));
+#endif
+  return 0;
+}
+
+int gph_engine_set_model(gph_engine *e, const double *theta, const double *popAge, const double *sampleAge,
+                         const double *migRate, const double *bandStart, const double *bandEnd)
+{
+  if (!e || !theta || !popAge || !sampleAge) return GPH_EARG;
+  for (int p = 0; p < e->cfg.K; p++) { e->model.theta[p] = theta[p]; e->model.popAge[p] = popAge[p]; e->model.sampleAge[p] = sampleAge[p]; }
+  for (int b = 0; b < e->cfg.B; b++) { e->model.migRate[b] = migRate[b]; e->model.bandStart[b] = bandStart[b]; e->model.bandEnd[b] = bandEnd[b]; }
+  e->model_set = true;
+  return 0;
+}
+
+int gph_engine_seed(gph_engine *e, uint32_t seed)
+{
+  if (!e) return GPH_EARG;
+  e->seedz = 170u * (seed % 178u) + 137u;   // utils.c:421
+  e->seeded = true;
+  return 0;
+}
+
+int gph_engine_init_genealogies(gph_engine *e, double *sumGen, double *sumData)
+{
+  if (!e || !e->loaded || !e->seeded || !e->model_set) return GPH_ESTATE;
+  LAUNCH(e, 3, k_init, e->dev, e->seedz, (const double *)e->d_mutRate);
+  int rc = finish_kernel(e);
+  if (rc) return rc;
+  double s[2] = {RSUM(e, 0), RSUM(e, 1)};
+  rc = xreduce(e, s, 2, nullptr, 0);
+  if (sumGen) *sumGen = s[0];
+  if (sumData) *sumData = s[1];
+  e->initialized = true;
+  return rc;
+}
+
+int gph_engine_genealogy_sweep(gph_engine *e, int32_t flags, double ftCoal, double ftMig, gph_sweep_result *out)
+{
+  if (!e || !e->initialized || !out) return GPH_ESTATE;
+  LAUNCH(e, 0, k_sweep, e->dev, (int)flags, ftCoal, ftMig);
+  int rc = finish_kernel(e);
+  if (rc) return rc;
+  double s[9] = {RSUM(e, 0), RSUM(e, 1), RSUM(e, 2), RSUM(e, 3), RSUM(e, 4), RSUM(e, 5), RSUM(e, 6), RSUM(e, 7), RSUM(e, 12)};
+  rc = xreduce(e, s, 9, nullptr, 0);
+  out->accepted_internal = (int64_t)s[0];
+  out->accepted_mignode = (int64_t)s[1];
+  out->accepted_spr = (int64_t)s[2];
+  out->dData_internal = s[3];
+  out->dLog_internal = s[4];
+  out->dLog_mignode = s[5];
+  out->dData_spr = s[6];
+  out->dLog_spr = s[7];
+  out->total_mig_nodes = (int64_t)s[8];
+  return rc;
+}
+
+int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result *out)
+{
+  if (!e || !e->initialized || !a || !out) return GPH_ESTATE;
+  if (a->num_aff > 2 * GPH_MAXB) return GPH_EARG;
+  GphTauArgs &A = e->tau;
+  memset(&A, 0, sizeof A);
+  A.ap = a->ap; A.son0 = a->son0; A.son1 = a->son1; A.isRoot = a->isRoot; A.num_aff = a->num_aff;
+  A.tauold = a->tauold; A.taunew = a->taunew; A.taub0 = a->taub0; A.taub1 = a->taub1;
+  A.taufactor0 = a->taufactor0; A.taufactor1 = a->taufactor1;
+  for (int i = 0; i < a->num_aff; i++) {
+    A.aff_bands[i] = (int16_t)a->aff_bands[i];
+    A.start_or_end[i] = (int16_t)a->start_or_end[i];
+    A.new_band_ages[i] = a->new_band_ages[i];
+  }
+  LAUNCH(e, 1, k_tau_eval, e->dev, A);
+  int rc = finish_kernel(e);
+  if (rc) return rc;
+  // first conflicting locus in serial order: loci after it were never touched by the
+  // reference -- sums only count loci before it (they are unused then anyway)
+  int64_t first = -1;
+  if (RMAX(e, 2) > 0.0) {
+    std::vector<double> outv((size_t)e->L * GPH_OUT_SLOTS);
+    rc = d2h(e, outv.data(), e->dev.out, outv.size() * sizeof(double));
+    if (rc) return rc;
+    for (int64_t g = 0; g < e->L; g++) if (outv[(size_t)g * GPH_OUT_SLOTS + 2] > 0.0) { first = g; break; }
+  }
+  double s[4] = {RSUM(e, 0), RSUM(e, 1), RSUM(e, 3), RSUM(e, 4)};
+  double mn[1] = {first >= 0 ? (double)(first + e->cfg.locus_begin) : 1e300};
+  rc = xreduce(e, s, 4, mn, 1);
+  out->ntj0 = (int64_t)s[0];
+  out->ntj1 = (int64_t)s[1];
+  out->genDelta = s[2];
+  out->dataDelta = s[3];
+  out->first_conflict_locus = mn[0] < 1e299 ? (int64_t)mn[0] : -1;
+  return rc;
+}
+
+int gph_engine_tau_commit(gph_engine *e)
+{
+  if (!e || !e->initialized) return GPH_ESTATE;
+  LAUNCH(e, 5, k_tau_commit, e->dev, e->tau);
+  return finish_kernel(e);
+}
+
+int gph_engine_tau_revert(gph_engine *e, int64_t first_conflict)
+{
+  if (!e || !e->initialized) return GPH_ESTATE;
+  int64_t limit = e->L;
+  if (first_conflict >= 0) {
+    limit = first_conflict - e->cfg.locus_begin;
+    if (limit < 0) limit = 0;
+    if (limit > e->L) limit = e->L;
+  }
+#ifdef GPH_HOSTEMU
+  for (int64_t g = 0; g < e->L; g++) for (int k = 0; k < GPH_OUT_SLOTS; k++) e->dev.out[g * GPH_OUT_SLOTS + k] = 0;
+#else
+  HIPCHK(hipMemsetAsync(e->dev.out, 0, sizeof(double) * GPH_OUT_SLOTS * e->L, e->stream));
+#endif
+  LAUNCH(e, 6, k_tau_revert, e->dev, (int)limit);
+  return finish_kernel(e);
+}
+
+int gph_engine_mixing_evaluate(gph_engine *e, double c, double *dataDelta)
+{
+  if (!e || !e->initialized || !dataDelta) return GPH_ESTATE;
+  LAUNCH(e, 2, k_mix_eval, e->dev, c);
+  int rc = finish_kernel(e);
+  if (rc) return rc;
+  double s[1] = {RSUM(e, 0)};
+  rc = xreduce(e, s, 1, nullptr, 0);
+  *dataDelta = s[0];
+  return rc;
+}
+
+int gph_engine_mixing_commit(gph_engine *e, double c, double lnc)
+{
+  if (!e || !e->initialized) return GPH_ESTATE;
+  LAUNCH(e, 7, k_mix_commit, e->dev, c, lnc);
+  return finish_kernel(e);
+}
+
+// mixing reject (GPhoCS.c:4881-4887): revertToSaved restores every locus exactly, and
+// the evaluated state only ever lived in the shadow pages -- nothing to do.
+int gph_engine_mixing_revert(gph_engine *e) { return e ? 0 : GPH_EARG; }
+
+int gph_engine_apply_theta(gph_engine *e, int32_t pop, double lnc, double thetaold, double thetanew)
+{
+  if (!e || !e->initialized || pop < 0 || pop >= e->cfg.K) return GPH_EARG;
+  double inv_diff = (1 / thetanew - 1 / thetaold);
+#ifdef GPH_HOSTEMU
+  for (int64_t g = 0; g < e->L; g++) {
+    char *pg = e->dev.pages + (size_t)g * e->lay.page_bytes;
+    double *fs = (double *)(pg + e->lay.o_fscal);
+    fs[FS_GENLNL] -= (lnc * ((int16_t *)(pg + e->lay.o_ncoal))[pop] + inv_diff * ((double *)(pg + e->lay.o_coal))[pop]);
+  }
+#else
+  int rc = upload_tables(e);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_apply_theta, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, e->dev, (int)pop, lnc, inv_diff);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int gph_engine_apply_migrate(gph_engine *e, int32_t band, double lnc, double old_rate, double new_rate)
+{
+  if (!e || !e->initialized || band < 0 || band >= e->cfg.B) return GPH_EARG;
+  double diff = (new_rate - old_rate);
+#ifdef GPH_HOSTEMU
+  for (int64_t g = 0; g < e->L; g++) {
+    char *pg = e->dev.pages + (size_t)g * e->lay.page_bytes;
+    double *fs = (double *)(pg + e->lay.o_fscal);
+    fs[FS_GENLNL] += (lnc * ((int16_t *)(pg + e->lay.o_nmig))[band] - diff * ((double *)(pg + e->lay.o_migst))[band]);
+  }
+#else
+  int rc = upload_tables(e);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_apply_migrate, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, e->dev, (int)band, lnc, diff);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int gph_engine_get_totals(gph_engine *e, double *cs, double *nc, double *ms, double *nm)
+{
+  if (!e || !e->initialized) return GPH_ESTATE;
+  const int K = e->cfg.K, B = e->cfg.B;
+#ifndef GPH_HOSTEMU
+  int rc0 = upload_tables(e);
+  if (rc0) return rc0;
+#endif
+  int rc = reduce_local(e, 1, 2 * K + 2 * B);
+  if (rc) return rc;
+  std::vector<double> s(2 * K + 2 * B);
+  for (int c = 0; c < 2 * K + 2 * B; c++) s[c] = RSUM(e, c);
+  rc = xreduce(e, s.data(), 2 * K + 2 * B, nullptr, 0);
+  for (int p = 0; p < K; p++) { cs[p] = s[p]; nc[p] = s[K + p]; }
+  for (int b = 0; b < B; b++) { ms[b] = s[2 * K + b]; nm[b] = s[2 * K + B + b]; }
+  return rc;
+}
+
+int gph_engine_synchronize(gph_engine *e, int32_t refresh, double *oldGen, double *newGen)
+{
+  if (!e || !e->initialized) return GPH_ESTATE;
+  LAUNCH(e, 5, k_sync, e->dev, (int)refresh);
+  int rc = finish_kernel(e);
+  if (rc) return rc;
+  if (RMIN(e, 0) < 1.0) { fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n"); return GPH_EKERNEL; }
+  double s[2] = {RSUM(e, 1), RSUM(e, 2)};
+  rc = xreduce(e, s, 2, nullptr, 0);
+  if (oldGen) *oldGen = s[0];
+  if (newGen) *newGen = s[1];
+  return rc;
+}
+
+int gph_engine_check_all(gph_engine *e, int32_t *ok, double *sumData, double *sumGen)
+{
+  if (!e || !e->initialized) return GPH_ESTATE;
+  LAUNCH(e, 4, k_check, e->dev);
+  int rc = finish_kernel(e);
+  if (rc) return rc;
+  double s[2] = {RSUM(e, 1), RSUM(e, 2)};
+  double mn[1] = {RMIN(e, 0)};
+  rc = xreduce(e, s, 2, mn, 1);
+  if (ok) *ok = mn[0] >= 1.0;
+  if (sumData) *sumData = s[0];
+  if (sumGen) *sumGen = s[1];
+  return rc;
+}
+
+int gph_engine_get_counters(gph_engine *e, gph_counters *out, int32_t reset)
+{
+  if (!e || !out) return GPH_EARG;
+  *out = e->counters;
+  if (reset) e->counters = gph_counters{0, 0, 0.0, 0};
+  return 0;
+}
+
+int gph_engine_last_kernel_ms(gph_engine *e, int32_t which, double *ms)
+{
+  if (!e || !ms || which < 0 || which >= 8) return GPH_EARG;
+  *ms = e->last_ms[which];
+  return 0;
+}
+
+int64_t gph_engine_num_loci(gph_engine *e) { return e ? e->L : 0; }
+
+int gph_engine_hbm_bytes(gph_engine *e, double *bytes)
+{
+  if (!e || !bytes) return GPH_EARG;
+  *bytes = 2.0 * e->pages_bytes + (double)e->cond_bytes + (double)e->L * e->dev.seq_bytes + 8.0 * GPH_OUT_SLOTS * e->L;
+  return 0;
+}
+
+// canonical text dump (same format as oracle/gphocs_oracle_io.c go_dump_state's per-locus part)
+int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int32_t append)
+{
+  if (!e || !e->initialized || !path) return GPH_ESTATE;
+  const GphLayout &y = e->lay;
+  std::vector<char> pages(e->pages_bytes), cond(withCond ? e->cond_bytes : 0);
+  int rc = d2h(e, pages.data(), e->dev.pages, e->pages_bytes);
+  if (!rc && withCond) rc = d2h(e, cond.data(), e->dev.cond, e->cond_bytes);
+  if (rc) return rc;
+  FILE *f = fopen(path, append ? "a" : "w");
+  if (!f) return GPH_EARG;
+  for (int64_t g = 0; g < e->L; g++) {
+    const char *pg = pages.data() + (size_t)g * y.page_bytes;
+    const double *fs = (const double *)(pg + y.o_fscal);
+    const int32_t *is = (const int32_t *)(pg + y.o_iscal);
+    const double *age = (const double *)(pg + y.o_age);
+    const int16_t *fa = (const int16_t *)(pg + y.o_father), *le = (const int16_t *)(pg + y.o_left),
+                  *ri = (const int16_t *)(pg + y.o_right), *np = (const int16_t *)(pg + y.o_npop),
+                  *ne = (const int16_t *)(pg + y.o_nev);
+    const int16_t *enext = (const int16_t *)(pg + y.o_ev_next), *enode = (const int16_t *)(pg + y.o_ev_node),
+                  *enlin = (const int16_t *)(pg + y.o_ev_nlin), *first = (const int16_t *)(pg + y.o_first);
+    const uint8_t *etype = (const uint8_t *)(pg + y.o_ev_type), *cbit = (const uint8_t *)(pg + y.o_condbit);
+    const double *evt = (const double *)(pg + y.o_ev_time);
+    fprintf(f, "LOCUS %lld root %d dataLnL %a genLnL %a rng %u %u %u\n", (long long)(g + e->cfg.locus_begin), is[IS_ROOT],
+            fs[FS_DATALNL], fs[FS_GENLNL], (unsigned)is[IS_RX], (unsigned)is[IS_RY], (unsigned)is[IS_RZ]);
+    for (int i = 0; i < y.N; i++)
+      fprintf(f, "N %d %d %d %d %a %d %d\n", i, fa[i], le[i], ri[i], age[i], np[i], i < y.n ? -1 : ne[i]);
+    for (int pop = 0; pop < y.K; pop++) {
+      fprintf(f, "C %d", pop);
+      int guard = 0;
+      for (int ev = first[pop]; ev >= 0 && guard++ < y.E; ev = enext[ev])
+        fprintf(f, " %d:%d:%d:%d:%a", ev, etype[ev], enode[ev], enlin[ev], evt[ev]);
+      fprintf(f, "\n");
+    }
+    fprintf(f, "S");
+    for (int pop = 0; pop < y.K; pop++)
+      fprintf(f, " %a %d", ((const double *)(pg + y.o_coal))[pop], ((const int16_t *)(pg + y.o_ncoal))[pop]);
+    for (int b = 0; b < y.B; b++)
+      fprintf(f, " %a %d", ((const double *)(pg + y.o_migst))[b], ((const int16_t *)(pg + y.o_nmig))[b]);
+    fprintf(f, "\n");
+    fprintf(f, "M %d", is[IS_NUM_MIGS]);
+    for (int i = 0; i < is[IS_NUM_MIGS]; i++) {
+      int mg = ((const int16_t *)(pg + y.o_living))[i];
+      const int16_t *mi = (const int16_t *)(pg + y.o_mig_i) + mg * MG_COUNT;
+      fprintf(f, " %d:%d:%d:%d:%d:%d:%d:%a", mg, mi[MG_BRANCH], mi[MG_BAND], mi[MG_SPOP], mi[MG_TPOP], mi[MG_SEV],
+              mi[MG_TEV], ((const double *)(pg + y.o_mig_age))[mg]);
+    }
+    fprintf(f, "\n");
+    if (withCond) {
+      int P = e->h_P[g];
+      const char *cb = cond.data() + e->h_cond_off[g];
+      for (int i = y.n; i < y.N; i++) {
+        const double *c = (const double *)(cb + ((size_t)(cbit[i] * (y.n - 1) + (i - y.n)) * P) * 32);
+        fprintf(f, "K %d", i);
+        for (int k = 0; k < 4 * P; k++) fprintf(f, " %a", c[k]);
+        fprintf(f, "\n");
+      }
+    }
+  }
+  fclose(f);
+  return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,626 @@
+// gph_kernels.h -- per-locus kernel bodies: stage the locus into LDS, run the
+// proposal(s), stage it back.  One 64-lane wavefront (= one workgroup) per locus.
+//
+// Each kb_* function is the body of the per-locus loop of one reference
+// proposal function (GPhoCS.c); the `#pragma omp parallel for` over loci there
+// (MultiCoreUtils.h:8-21) is the grid here.  Cross-locus `omp atomic`
+// accumulations become per-locus output slots reduced by a fixed-shape tree.
+#pragma once
+#include "gph_locus.h"
+
+struct GphDev {            // device pointers (passed by value to every kernel)
+  char *pages;             // L * page_bytes
+  char *shadow;            // L * page_bytes
+  char *cond;              // conditionals, per-locus byte offset cond_off[g]
+  const uint64_t *cond_off;
+  const char *seq;         // L * seq_bytes (leaf codes, phases, counts; fixed-size blocks)
+  const int32_t *P;        // phased patterns per locus
+  double *out;             // L * GPH_OUT_SLOTS
+  int32_t L;               // loci on this device
+  int32_t Ltot;            // loci over all devices (dataSetup.numLoci)
+  int32_t seq_bytes;
+};
+
+// ---------------------------------------------------------------- staging
+GPH_DEV void copy16_g2l(int lds_off, const char *src, int bytes)
+{
+  int i, n16 = bytes >> 4;
+#ifdef GPH_HOSTEMU
+  memcpy(gph_sm + lds_off, src, bytes);
+  (void)i; (void)n16;
+#else
+  const uint4 *s = (const uint4 *)src;
+  typedef GPH_LDS uint4 luint4;
+  luint4 *d = (luint4 *)(GPH_SMB + lds_off);
+  for (i = GPH_LANE; i < n16; i += GPH_NLANES) d[i] = s[i];
+#endif
+}
+GPH_DEV void copy16_l2g(char *dst, int lds_off, int bytes)
+{
+  int i, n16 = bytes >> 4;
+#ifdef GPH_HOSTEMU
+  memcpy(dst, gph_sm + lds_off, bytes);
+  (void)i; (void)n16;
+#else
+  uint4 *d = (uint4 *)dst;
+  typedef GPH_LDS uint4 luint4;
+  const luint4 *s = (const luint4 *)(GPH_SMB + lds_off);
+  for (i = GPH_LANE; i < n16; i += GPH_NLANES) d[i] = s[i];
+#endif
+}
+
+// conditionals: per internal node only the CURRENT half (page condbit) travels.
+// mode 1: every internal node; mode 2: only nodes whose dirty flag is set.
+GPH_DEV void cond_transfer(const GphDev &D, int g, int store, int mode)
+{
+  const int P = D.P[g], nint = g_lay.n - 1;
+  const int pairs = 2 * P;               /* 16-byte units per node half */
+  char *base = D.cond + D.cond_off[g];
+  int e;
+  for (e = GPH_LANE; e < nint * pairs; e += GPH_NLANES) {
+    int k = e / pairs, j = e - k * pairs, node = g_lay.n + k;
+    int bit = gu8v(g_lay.o_condbit, node);
+    if (mode == 2 && !gu8v(g_lay.o_dirty, node)) continue;
+    int off = ((bit * nint + k) * P) * 32 + j * 16;
+#ifdef GPH_HOSTEMU
+    if (store) memcpy(base + off, gph_sm + g_lay.o_cond + off, 16);
+    else memcpy(gph_sm + g_lay.o_cond + off, base + off, 16);
+#else
+    typedef GPH_LDS double2 ld2;
+    if (store) *(double2 *)(base + off) = *(ld2 *)(GPH_SMB + g_lay.o_cond + off);
+    else *(ld2 *)(GPH_SMB + g_lay.o_cond + off) = *(const double2 *)(base + off);
+#endif
+  }
+}
+
+GPH_DEV void scratch_init(const GphDev &D, int g)
+{
+  int k;
+  for (k = 0; k < CN_COUNT; k++) setCNT(k, 0);
+  setCNT(CN_P, D.P[g]);
+  sf64(g_lay.s_cntf, 0, 0.0);
+  delta_clear(0);
+  delta_clear(1);
+}
+
+// load page (+ optionally sequence data and current conditionals)
+GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withCond)
+{
+  copy16_g2l(0, pages + (size_t)g * g_lay.page_bytes, g_lay.page_bytes);
+  if (withCond) copy16_g2l(g_lay.o_seq, D.seq + (size_t)g * D.seq_bytes, D.seq_bytes);
+  GPH_SYNC();
+  scratch_init(D, g);
+  if (withCond) { cond_transfer(D, g, 0, 1); GPH_SYNC(); }
+}
+GPH_DEV void stage_out(const GphDev &D, int g, char *pages, int condMode)
+{
+  GPH_SYNC();
+  copy16_l2g(pages + (size_t)g * g_lay.page_bytes, 0, g_lay.page_bytes);
+  if (condMode) cond_transfer(D, g, 1, condMode);
+}
+GPH_DEV void out_common(const GphDev &D, int g)
+{
+  if (GPH_LANE == 0) {
+    double *o = D.out + (size_t)g * GPH_OUT_SLOTS;
+    o[8] = CNT(CN_EVALS);
+    o[9] = CNT(CN_NODES);
+    o[10] = gf64(g_lay.s_cntf, 0);
+    o[11] = CNT(CN_ERROR);
+    o[13] = CNT(CN_NOTENOUGH);
+  }
+}
+#define OUT(g, k, v) do { if (GPH_LANE == 0) D.out[(size_t)(g) * GPH_OUT_SLOTS + (k)] = (v); } while (0)
+
+// ---------------------------------------------------------------- init
+// Coalescence1Pop, patch.c:279-358, iterative over the population post-order (the
+// reference recursion visits sons[0], sons[1], then the population itself).  The
+// living-lineage array is packed exactly as the recursion packs it: a cursor
+// advances past each finished population's SURVIVING lineages, so an ancestral
+// population's list is the contiguous run [base(son0), cursor).
+GPH_DEV void random_gtree()
+{
+  const int n = g_lay.n;
+  int pi, pop, nextId = n, num, node1, node2, choice, a, b, base, cur = 0;
+  double t, T;
+  for (pi = 0; pi < g_lay.K; pi++) {
+    pop = g_model.postOrder[pi];
+    if (pop < g_lay.Kc) {
+      node1 = pop > 0 ? g_model.cumSamples[pop - 1] : 0;
+      num = g_model.cumSamples[pop] - node1;
+      base = cur;
+      for (node2 = 0; node2 < num; ++node2) {
+        si16(g_lay.s_targets, base + node2, node1 + node2);
+        setNPOP(node1 + node2, pop);
+        setNEV(node1 + node2, -1);
+        setLEFT(node1 + node2, -1);
+        setRGHT(node1 + node2, -1);
+        setFATH(node1 + node2, -1);
+        setAGE(node1 + node2, g_model.sampleAge[pop]);
+      }
+    } else {
+      base = gi16(g_lay.s_ord, g_model.popSon0[pop]);
+      num = cur - base;
+    }
+    si16(g_lay.s_ord, pop, base);
+    T = g_model.popAge[pop];
+    if (pop < g_lay.Kc) T = g_model.sampleAge[pop];
+    for (; num > 1; num--, nextId++) {
+      t = -(g_model.theta[pop] / (num * (num - 1.))) * log(l_rndu());
+      T += t;
+      if (pop != g_lay.rootPop && T > g_model.popAge[g_model.popFather[pop]]) break;
+      choice = (int)(num * l_rndu());
+      a = gi16(g_lay.s_targets, base + choice);
+      si16(g_lay.s_targets, base + choice, gi16(g_lay.s_targets, base + num - 1));
+      choice = (int)((num - 1) * l_rndu());
+      b = gi16(g_lay.s_targets, base + choice);
+      si16(g_lay.s_targets, base + choice, nextId);
+      setRGHT(nextId, a);
+      setLEFT(nextId, b);
+      setFATH(nextId, -1);
+      setAGE(nextId, T);
+      setFATH(a, nextId);
+      setFATH(b, nextId);
+      setNPOP(nextId, pop);
+    }
+    cur = base + num;
+  }
+  setISC(IS_ROOT, nextId - 1);
+}
+
+// initializeMCMC per-locus body, GPhoCS.c:1197-1214
+GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate)
+{
+  int i;
+  /* blank page */
+  for (i = GPH_LANE; i < g_lay.page_bytes / 4; i += GPH_NLANES) ((li32 *)GPH_SMB)[i] = 0;
+  copy16_g2l(g_lay.o_seq, D.seq + (size_t)g * D.seq_bytes, D.seq_bytes);
+  GPH_SYNC();
+  scratch_init(D, g);
+  setISC(IS_RX, 11);
+  setISC(IS_RY, 23);
+  setISC(IS_RZ, (int)seedz);
+  setISC(IS_SV_ROOT, -1);
+  setFS(FS_MUTRATE, mutRate);
+  for (i = 0; i < GPH_MAX_MIGS; i++) {
+    setMG(i, MG_BRANCH, -1); setMG(i, MG_BAND, -1); setMG(i, MG_SPOP, -1);
+    setMG(i, MG_TPOP, -1); setMG(i, MG_SEV, -1); setMG(i, MG_TEV, -1);
+  }
+  random_gtree();
+  construct_event_chain();
+  compute_genetree_stats();
+  setFS(FS_GENLNL, gtree_lnl());
+  lik_compute(0);
+  lik_reset_saved();
+  OUT(g, 0, FS(FS_GENLNL));
+  OUT(g, 1, FS(FS_DATALNL));
+  out_common(D, g);
+  stage_out(D, g, D.pages, 1);
+}
+
+// ---------------------------------------------------------------- genealogy sweeps
+// UpdateGB_InternalNode per-locus body, GPhoCS.c:2299-2425
+GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune)
+{
+  int pop, inode, i, son, mig, acc = 0;
+  double t, tnew, lnacc, lnLd, dgen, tb0, tb1, dData = 0, dLog = 0;
+  for (inode = g_lay.n; inode < g_lay.N; inode++) {
+    t = AGE(inode);
+    pop = NPOP(inode);
+    tb0 = g_model.popAge[pop];
+    if (pop != g_lay.rootPop) tb1 = g_model.popAge[g_model.popFather[pop]];
+    else tb1 = GPH_OLDAGE;
+    mig = find_first_mig(inode, -1);
+    if (mig >= 0) tb1 = gmin2(tb1, MAGE(mig));
+    else if (inode != ISC(IS_ROOT)) tb1 = gmin2(tb1, AGE(FATH(inode)));
+    for (i = 0; i < 2; i++) {
+      son = i == 0 ? LEFT(inode) : RGHT(inode);
+      mig = find_last_mig(son, -1);
+      if (mig >= 0) tb0 = gmax2(tb0, MAGE(mig));
+      else tb0 = gmax2(tb0, AGE(son));
+    }
+    tnew = t + finetune * l_rnd2normal8();
+    tnew = l_reflect(tnew, tb0, tb1);
+    if (fabs(tnew - t) < 1e-15) { acc++; continue; }
+    lik_adjust_age(inode, tnew);
+    lnLd = -FS(FS_DATALNL);
+    lnLd += lik_compute(1);
+    dgen = consider_event_move(0, NEV(inode), pop, t, pop, tnew);
+    lnacc = dgen + lnLd;
+    if (gph_failed()) break;
+    if (lnacc >= 0 || l_rndu() < exp(lnacc)) {
+      acc++;
+      setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
+      dData += lnLd;
+      dLog += (dgen + lnLd) / D.Ltot;
+      accept_event_chain_changes(0);
+      lik_reset_saved();
+    } else {
+      reject_event_chain_changes(0);
+      lik_revert();
+    }
+  }
+  OUT(g, 0, acc);
+  OUT(g, 3, dData);
+  OUT(g, 4, dLog);
+}
+
+// UpdateGB_MigrationNode per-locus body, GPhoCS.c:2453-2587
+GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune)
+{
+  int mi, mignode, pop_s, pop_t, ev_s, ev_t, below, mig_below, mig_above, father, acc = 0, totmigs = 0;
+  double t, tnew, tb0, tb1, dgen, lnacc, dLog = 0;
+  for (mi = 0; mi < ISC(IS_NUM_MIGS); mi++) {
+    mignode = LIVING(mi);
+    t = MAGE(mignode);
+    pop_s = MG(mignode, MG_SPOP);
+    pop_t = MG(mignode, MG_TPOP);
+    ev_s = MG(mignode, MG_SEV);
+    ev_t = MG(mignode, MG_TEV);
+    below = MG(mignode, MG_BRANCH);
+    tb0 = g_model.bandStart[MG(mignode, MG_BAND)];
+    tb1 = g_model.bandEnd[MG(mignode, MG_BAND)];
+    mig_below = find_last_mig(below, t);
+    mig_above = find_first_mig(below, t);
+    if (mig_below >= 0) tb0 = gmax2(tb0, MAGE(mig_below));
+    else tb0 = gmax2(tb0, AGE(below));
+    if (mig_above >= 0) tb1 = gmin2(tb1, MAGE(mig_above));
+    else {
+      father = FATH(below);
+      if (father < 0) tb1 = gmin2(tb1, GPH_OLDAGE);
+      else tb1 = gmin2(tb1, AGE(father));
+    }
+    tnew = t + finetune * l_rnd2normal8();
+    tnew = l_reflect(tnew, tb0, tb1);
+    if (fabs(tnew - t) < 1e-15) { acc++; continue; }
+    dgen = consider_event_move(0, ev_s, pop_s, t, pop_s, tnew);
+    dgen += consider_event_move(1, ev_t, pop_t, t, pop_t, tnew);
+    lnacc = dgen;
+    if (gph_failed()) break;
+    if (lnacc >= 0 || l_rndu() < exp(lnacc)) {
+      acc++;
+      setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
+      dLog += dgen / D.Ltot;
+      accept_event_chain_changes(0);
+      accept_event_chain_changes(1);
+      setMAGE(mignode, tnew);
+    } else {
+      reject_event_chain_changes(0);
+      reject_event_chain_changes(1);
+    }
+  }
+  for (mi = 0; mi < g_lay.B; mi++) totmigs += NMIGB(mi);
+  OUT(g, 1, acc);
+  OUT(g, 5, dLog);
+  OUT(g, 12, totmigs);
+}
+
+// UpdateGB_MigSPR per-locus body, GPhoCS.c:2610-2944 (no admixture)
+GPH_DEV void sweep_spr(const GphDev &D, int g)
+{
+  int node, res, father, father_pop_old, sibling, b, i, mig, ev, target, pop, acc = 0, fpn, fen;
+  double lnLd, lnacc, t_new, dData = 0, dLog = 0;
+  for (node = 0; node < g_lay.N; node++) {
+    if (node == ISC(IS_ROOT)) continue;
+    father = FATH(node);
+    father_pop_old = NPOP(father);
+    sibling = LEFT(father) + RGHT(father) - node;
+    trace_lineage<0>(node);
+    res = trace_lineage<1>(node);
+    lnLd = -FS(FS_DATALNL);
+    lnLd += lik_compute(1);
+    lnacc = lnLd;
+    if (gph_failed()) break;
+    if (res >= 0 && (lnacc >= 0 || l_rndu() < exp(lnacc))) {
+      acc++;
+      setFS(FS_GENLNL, FS(FS_GENLNL) + (SPRLN(1) - SPRLN(0)));
+      dData += lnLd;
+      dLog += (lnLd - SPRLN(0) + SPRLN(1)) / D.Ltot;
+      target = SPRI(SI_TARGET);
+      t_new = AGE(father);
+      for (i = 0; i < ISC(IS_NUM_MIGS); i++) {
+        mig = LIVING(i);
+        if (MG(mig, MG_BRANCH) == father) setMG(mig, MG_BRANCH, sibling);
+        if (target == father) target = sibling;
+        if (MG(mig, MG_BRANCH) == target && MAGE(mig) >= t_new) setMG(mig, MG_BRANCH, father);
+      }
+      remove_event(SPRI(SI_FEV_OLD));
+      fen = SPRI(SI_FEV_NEW);
+      setETYPE(fen, GPH_COAL);
+      setENODE(fen, father);
+      setNEV(father, fen);
+      fpn = SPRI(SI_FPOP_NEW);
+      if (fpn != father_pop_old) {
+        setNPOP(father, fpn);
+        setNCOAL(father_pop_old, NCOAL(father_pop_old) - 1);
+        setNCOAL(fpn, NCOAL(fpn) + 1);
+      }
+      replace_mig_nodes(node);
+      for (i = 0; i < DI(1, DI_NEV); ++i) {
+        ev = DEV(1, i);
+        setENLIN(ev, ENLIN(ev) + 1);
+      }
+      for (b = 0; b < g_lay.B; ++b) setMIGST(b, MIGST(b) + (DMIG(1, b) - DMIG(0, b)));
+      for (pop = 0; pop < g_lay.K; pop++) setCOALS(pop, COALS(pop) + (DCOAL(1, pop) - DCOAL(0, pop)));
+      lik_reset_saved();
+    } else {
+      if (res >= 0) remove_event(SPRI(SI_FEV_NEW));
+      for (i = 0; i < SPRI(SI_NNEW); i++) {
+        remove_event(SPRA(SA_NEWIN, i));
+        remove_event(SPRA(SA_NEWOUT, i));
+      }
+      for (i = 0; i < DI(0, DI_NEV); ++i) {
+        ev = DEV(0, i);
+        setENLIN(ev, ENLIN(ev) + 1);
+      }
+      lik_revert();
+    }
+  }
+  OUT(g, 2, acc);
+  OUT(g, 6, dData);
+  OUT(g, 7, dLog);
+}
+
+// fused genealogy sweep: UpdateGB_InternalNode, UpdateGB_MigrationNode, UpdateGB_MigSPR
+// run back to back on the LDS-resident locus (GPhoCS.c:1495-1538 calls them in this
+// order with nothing in between) -- one load and one store of the locus instead of three
+GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double ftMig)
+{
+  stage_in(D, g, D.pages, 1);
+  OUT(g, 0, 0.0); OUT(g, 1, 0.0); OUT(g, 2, 0.0); OUT(g, 3, 0.0); OUT(g, 4, 0.0);
+  OUT(g, 5, 0.0); OUT(g, 6, 0.0); OUT(g, 7, 0.0); OUT(g, 12, 0.0);
+  if ((flags & 1) && ftCoal > 0.0) sweep_internal(D, g, ftCoal);
+  if ((flags & 2) && ftMig > 0.0 && !gph_failed()) sweep_mignodes(D, g, ftMig);
+  if ((flags & 4) && !gph_failed()) sweep_spr(D, g);
+  out_common(D, g);
+  stage_out(D, g, D.pages, 1);
+}
+
+// ---------------------------------------------------------------- UpdateTau
+// loop 1 body of UpdateTau, GPhoCS.c:3491-3833.  Reads the main page, writes the
+// evaluated state to the SHADOW page (see gph_types.h); new conditionals go to the
+// non-current halves.  out: 0 ntj0, 1 ntj1, 2 conflict, 3 genDelta, 4 dataDelta
+GPH_DEV void kb_tau_eval(const GphDev &D, int g, const GphTauArgs &A)
+{
+  const int ap = A.ap, s0 = A.son0, s1 = A.son1;
+  double age_mt, new_age = 0.0, dGen = 0, dData = 0, gd;
+  int srcP, tgtP, fatherNode, inode, inORout = -1, ev = -1, n1_0 = 0, n1_1 = 0, i, mig, mig1, band, pop;
+  int conflict = 0, k;
+  stage_in(D, g, D.pages, 1);
+  setISC(IS_CONFLICT_LOG, 1);
+  setISC(IS_RB_NUM, 0);
+  for (i = 0; i < ISC(IS_NUM_MIGS); i++) {
+    if (conflict == 0) {
+      pop = -1;
+      mig = LIVING(i);
+      band = MG(mig, MG_BAND);
+      srcP = MG(mig, MG_SPOP);
+      tgtP = MG(mig, MG_TPOP);
+      age_mt = MAGE(mig);
+      if (age_mt < A.taub0 || age_mt > A.taub1) continue;
+      if ((srcP == s0 && tgtP == s1) || (srcP == s1 && tgtP == s0)) {
+        n1_0++;
+      } else if (srcP == ap) {
+        inORout = 1;
+        ev = MG(mig, MG_TEV);
+        pop = tgtP;
+        new_age = A.taub1 + A.taufactor1 * (age_mt - A.taub1);
+        n1_1++;
+      } else if (tgtP == ap) {
+        inORout = 0;
+        ev = MG(mig, MG_SEV);
+        pop = srcP;
+        new_age = A.taub1 + A.taufactor1 * (age_mt - A.taub1);
+        n1_1++;
+      } else if ((srcP == s0 || srcP == s1) && MAGE(mig) > A.taub0) {
+        inORout = 1;
+        ev = MG(mig, MG_TEV);
+        pop = tgtP;
+        new_age = A.taub0 + A.taufactor0 * (age_mt - A.taub0);
+        n1_0++;
+      } else if ((tgtP == s0 || tgtP == s1) && MAGE(mig) > A.taub0) {
+        inORout = 0;
+        ev = MG(mig, MG_SEV);
+        pop = srcP;
+        new_age = A.taub0 + A.taufactor0 * (age_mt - A.taub0);
+        n1_0++;
+      }
+      if (ev >= 0) {
+        inode = MG(mig, MG_BRANCH);
+        if (new_age >= g_model.bandEnd[band]) conflict = 1;
+        else if (new_age <= g_model.bandStart[band]) conflict = 1;
+        else if (inORout == 0 && new_age > age_mt) {
+          fatherNode = FATH(inode);
+          mig1 = find_first_mig(inode, MAGE(mig));
+          if (mig1 >= 0 && MG(mig1, MG_SPOP) != ap && MG(mig1, MG_SPOP) != s0 && MG(mig1, MG_SPOP) != s1 &&
+              new_age >= MAGE(mig1))
+            conflict = 1;
+          else if (fatherNode >= 0 && new_age >= AGE(fatherNode))
+            conflict = 1;
+        } else if (inORout == 1 && new_age < age_mt) {
+          mig1 = find_last_mig(inode, MAGE(mig));
+          if (mig1 >= 0 && MG(mig1, MG_TPOP) != ap && MG(mig1, MG_TPOP) != s0 && MG(mig1, MG_TPOP) != s1 &&
+              new_age <= MAGE(mig1))
+            conflict = 1;
+          else if (new_age <= AGE(inode))
+            conflict = 1;
+        }
+        if (conflict != 1) {
+          k = ISC(IS_RB_NUM);
+          setRBI(0, k, ev);
+          setRBI(2, k, pop);
+          setRBAGE(k, new_age);
+          setISC(IS_RB_NUM, k + 1);
+          ev = -1;
+        }
+      }
+    }
+  }
+  if (conflict) {
+    setISC(IS_RB_NUM, 0);
+  } else {
+    for (i = 0; i < A.num_aff; i++) {
+      int guard = 0;
+      band = A.aff_bands[i];
+      tgtP = g_model.bandTgt[band];
+      for (ev = FIRSTEV(tgtP); ev >= 0; ev = ENEXT(ev)) {
+        if (ENODE(ev) == band &&
+            ((ETYPE(ev) == GPH_MIG_BAND_START && A.start_or_end[i]) || ETYPE(ev) == GPH_MIG_BAND_END))
+          break;
+        if (++guard > g_lay.E) { ev = -1; break; }
+      }
+      if (ev < 0) { gph_fail(74); break; }
+      k = ISC(IS_RB_NUM);
+      setRBI(0, k, ev);
+      setRBI(2, k, tgtP);
+      setRBAGE(k, A.new_band_ages[i]);
+      setISC(IS_RB_NUM, k + 1);
+    }
+    if (!gph_failed()) {
+      gd = rubber_band_ripple(1);
+      if (A.isRoot) gd += rubber_band(ap, A.taub0, A.tauold, A.taufactor1, 0, &n1_1);
+      else gd += rubber_band(ap, A.taub1, A.tauold, A.taufactor1, 0, &n1_1);
+      gd += rubber_band(s0, A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
+      gd += rubber_band(s1, A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
+      setFS(FS_GENDELTA, gd);
+      dGen += gd;
+      if (n1_0 + n1_1) {
+        dData -= FS(FS_DATALNL);
+        dData += lik_compute(1);
+      }
+    }
+  }
+  OUT(g, 0, conflict ? 0 : n1_0);
+  OUT(g, 1, conflict ? 0 : n1_1);
+  OUT(g, 2, conflict);
+  OUT(g, 3, dGen);
+  OUT(g, 4, dData);
+  out_common(D, g);
+  stage_out(D, g, D.shadow, 2);
+}
+
+// loop 2 body (commit), GPhoCS.c:3885-3936 (+ adjustRootEvents patch.c:1808 for the root)
+GPH_DEV void kb_tau_commit(const GphDev &D, int g, const GphTauArgs &A)
+{
+  int dummy = 0, i, mig, nw, ev;
+  double age;
+  stage_in(D, g, D.shadow, 0);
+  setFS(FS_GENLNL, FS(FS_GENLNL) + FS(FS_GENDELTA));
+  if (A.isRoot) rubber_band(A.ap, A.taub0, A.tauold, A.taufactor1, 1, &dummy);
+  else rubber_band(A.ap, A.taub1, A.tauold, A.taufactor1, 1, &dummy);
+  rubber_band(A.son0, A.taub0, A.tauold, A.taufactor0, 1, &dummy);
+  rubber_band(A.son1, A.taub0, A.tauold, A.taufactor0, 1, &dummy);
+  lik_reset_saved();
+  for (i = 0; i < ISC(IS_RB_NUM); i++) {
+    nw = RBI(1, i);
+    mig = ENODE(nw);
+    if (ETYPE(nw) == GPH_IN_MIG) {
+      setMG(mig, MG_TEV, nw);
+      setMAGE(mig, RBAGE(i));
+    } else if (ETYPE(nw) == GPH_OUT_MIG) {
+      setMG(mig, MG_SEV, nw);
+    }
+    remove_event(RBI(0, i));
+  }
+  setISC(IS_RB_NUM, 0);
+  if (A.isRoot) {
+    int guard = 0;
+    ev = FIRSTEV(g_lay.rootPop);
+    age = A.taunew;
+    while (ENEXT(ev) >= 0) { age += EVT(ev); ev = ENEXT(ev); if (++guard > g_lay.E) { gph_fail(97); break; } }
+    setEVT(ev, GPH_OLDAGE - age);
+  }
+  out_common(D, g);
+  stage_out(D, g, D.pages, 0);
+}
+
+// loops 3/4 body (reject), GPhoCS.c:3965-3989: only loci whose ripple moved events
+// differ from their main page; everything else is bit-identical already
+GPH_DEV void kb_tau_revert(const GphDev &D, int g, int limit)
+{
+  if (g >= limit) return;
+  const int32_t *is = (const int32_t *)(D.shadow + (size_t)g * g_lay.page_bytes + g_lay.o_iscal);
+  if (is[IS_RB_NUM] == 0) return;
+  stage_in(D, g, D.shadow, 0);
+  lik_revert();
+  rubber_band_ripple(0);
+  out_common(D, g);
+  stage_out(D, g, D.pages, 0);
+}
+
+// ---------------------------------------------------------------- mixing
+// evaluate loop of mixing(), GPhoCS.c:4790-4801.  out: 0 dataDelta
+GPH_DEV void kb_mix_eval(const GphDev &D, int g, double c)
+{
+  double d;
+  stage_in(D, g, D.pages, 1);
+  d = lik_scale_ages(c);
+  OUT(g, 0, d);
+  out_common(D, g);
+  stage_out(D, g, D.shadow, 2);
+}
+// commit loop of mixing(), GPhoCS.c:4815-4848 + adjustRootEvents (patch.c:1808)
+GPH_DEV void kb_mix_commit(const GphDev &D, int g, double c, double lnc)
+{
+  int i, pop, b, ev;
+  double age;
+  stage_in(D, g, D.shadow, 0);
+  lik_reset_saved();
+  for (i = 0; i < ISC(IS_NUM_MIGS); i++) setMAGE(LIVING(i), MAGE(LIVING(i)) * c);
+  setFS(FS_GENLNL, FS(FS_GENLNL) - lnc * (g_lay.n - 1 + ISC(IS_NUM_MIGS)));
+  for (pop = 0; pop < g_lay.K; pop++) setCOALS(pop, COALS(pop) * c);
+  for (b = 0; b < g_lay.B; b++) setMIGST(b, MIGST(b) * c);
+  for (i = GPH_LANE; i < g_lay.E; i += GPH_NLANES) {
+    double t = gf64(g_lay.o_ev_time, i);
+    if (t > 0) sf64(g_lay.o_ev_time, i, t * c);
+  }
+  GPH_SYNC();
+  {
+    int guard = 0;
+    ev = FIRSTEV(g_lay.rootPop);
+    age = g_model.popAge[g_lay.rootPop];
+    while (ENEXT(ev) >= 0) { age += EVT(ev); ev = ENEXT(ev); if (++guard > g_lay.E) { gph_fail(97); break; } }
+    setEVT(ev, GPH_OLDAGE - age);
+  }
+  out_common(D, g);
+  stage_out(D, g, D.pages, 0);
+}
+
+// ---------------------------------------------------------------- end-of-iteration
+// synchronizeEvents(gen), GPhoCS.c:1705-1714; refresh = start-mig recomputation of
+// genLogLikelihood (GPhoCS.c:1749-1756).  out: 0 ok, 1 old genLnL, 2 new genLnL
+GPH_DEV void kb_sync(const GphDev &D, int g, int refresh)
+{
+  int ok;
+  stage_in(D, g, D.pages, 0);
+  ok = synchronize_events();
+  OUT(g, 0, ok);
+  OUT(g, 1, FS(FS_GENLNL));
+  if (refresh) setFS(FS_GENLNL, gtree_lnl());
+  OUT(g, 2, FS(FS_GENLNL));
+  out_common(D, g);
+  stage_out(D, g, D.pages, 0);
+}
+
+// checkAll per-locus body, patch.c:2766-2790: structure check + statistics resync,
+// full likelihood recomputation (checkLocusDataLikelihood, LocusDataLikelihood.c:717),
+// genLogLikelihood resync.  out: 0 ok, 1 dataLnL, 2 genLnL
+GPH_DEV void kb_check(const GphDev &D, int g)
+{
+  int ok;
+  double lnLd_gen, PREC = 0.0000001, a, b;
+  stage_in(D, g, D.pages, 1);
+  ok = check_gtree_structure();
+  lik_compute(0);
+  a = FS(FS_DATALNL);
+  b = FS(FS_SV_DATALNL);
+  if (!(a == b || fabs(1 - a / b) < 0.000000001)) ok = 0;
+  lik_reset_saved();
+  lnLd_gen = gtree_lnl();
+  if (fabs(FS(FS_GENLNL) - lnLd_gen) > PREC && fabs(1 - FS(FS_GENLNL) / lnLd_gen) > PREC) ok = 0;
+  setFS(FS_GENLNL, lnLd_gen);
+  OUT(g, 0, ok);
+  OUT(g, 1, FS(FS_DATALNL));
+  OUT(g, 2, lnLd_gen);
+  out_common(D, g);
+  stage_out(D, g, D.pages, 1);
+}

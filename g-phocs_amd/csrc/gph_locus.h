@@ -1,0 +1,1258 @@
+// gph_locus.h -- per-locus device functions (one wavefront per locus, state in LDS).
+//
+// Everything here operates on the LDS copy of ONE locus (gph_rt.h accessors)
+// and on the __constant__ model/layout tables.  Control flow is wave-uniform;
+// only prune_node()/root_terms() spread (pattern, base) pairs over the 64 lanes.
+//
+// Arithmetic contract (bit-faithful state evolution): every floating-point
+// expression keeps the reference's operand order and association and the file
+// is compiled with -ffp-contract=off.  Reference citations are file:line under
+// the upstream src/ directory.
+#pragma once
+#include "gph_rt.h"
+
+// ---------------------------------------------------------------- accessors
+#define AGE(i) gf64(g_lay.o_age, (i))
+#define setAGE(i, v) sf64(g_lay.o_age, (i), (v))
+#define SVAGE(i) gf64(g_lay.o_sv_age, (i))
+#define setSVAGE(i, v) sf64(g_lay.o_sv_age, (i), (v))
+#define EVT(e) gf64(g_lay.o_ev_time, (e))
+#define setEVT(e, v) sf64(g_lay.o_ev_time, (e), (v))
+#define MAGE(m) gf64(g_lay.o_mig_age, (m))
+#define setMAGE(m, v) sf64(g_lay.o_mig_age, (m), (v))
+#define COALS(p) gf64(g_lay.o_coal, (p))
+#define setCOALS(p, v) sf64(g_lay.o_coal, (p), (v))
+#define MIGST(b) gf64(g_lay.o_migst, (b))
+#define setMIGST(b, v) sf64(g_lay.o_migst, (b), (v))
+#define RBAGE(i) gf64(g_lay.o_rb_age, (i))
+#define setRBAGE(i, v) sf64(g_lay.o_rb_age, (i), (v))
+#define FS(k) gf64(g_lay.o_fscal, (k))
+#define setFS(k, v) sf64(g_lay.o_fscal, (k), (v))
+#define FATH(i) gi16(g_lay.o_father, (i))
+#define setFATH(i, v) si16(g_lay.o_father, (i), (v))
+#define LEFT(i) gi16(g_lay.o_left, (i))
+#define setLEFT(i, v) si16(g_lay.o_left, (i), (v))
+#define RGHT(i) gi16(g_lay.o_right, (i))
+#define setRGHT(i, v) si16(g_lay.o_right, (i), (v))
+#define NPOP(i) gi16(g_lay.o_npop, (i))
+#define setNPOP(i, v) si16(g_lay.o_npop, (i), (v))
+#define NEV(i) gi16(g_lay.o_nev, (i))
+#define setNEV(i, v) si16(g_lay.o_nev, (i), (v))
+#define SVF(i) gi16(g_lay.o_sv_father, (i))
+#define SVL(i) gi16(g_lay.o_sv_left, (i))
+#define SVR(i) gi16(g_lay.o_sv_right, (i))
+#define CHG(i) gi16(g_lay.o_changed, (i))
+#define CHGC(i) gi16(g_lay.o_changedc, (i))
+#define ENEXT(e) gi16(g_lay.o_ev_next, (e))
+#define setENEXT(e, v) si16(g_lay.o_ev_next, (e), (v))
+#define EPREV(e) gi16(g_lay.o_ev_prev, (e))
+#define setEPREV(e, v) si16(g_lay.o_ev_prev, (e), (v))
+#define ENODE(e) gi16(g_lay.o_ev_node, (e))
+#define setENODE(e, v) si16(g_lay.o_ev_node, (e), (v))
+#define ENLIN(e) gi16(g_lay.o_ev_nlin, (e))
+#define setENLIN(e, v) si16(g_lay.o_ev_nlin, (e), (v))
+#define ETYPE(e) gu8(g_lay.o_ev_type, (e))
+#define setETYPE(e, v) su8(g_lay.o_ev_type, (e), (v))
+#define FIRSTEV(p) gi16(g_lay.o_first, (p))
+#define setFIRSTEV(p, v) si16(g_lay.o_first, (p), (v))
+#define MG(m, f) gi16(g_lay.o_mig_i, (m) * MG_COUNT + (f))
+#define setMG(m, f, v) si16(g_lay.o_mig_i, (m) * MG_COUNT + (f), (v))
+#define LIVING(i) gi16(g_lay.o_living, (i))
+#define setLIVING(i, v) si16(g_lay.o_living, (i), (v))
+#define NCOAL(p) gi16(g_lay.o_ncoal, (p))
+#define setNCOAL(p, v) si16(g_lay.o_ncoal, (p), (v))
+#define NMIGB(b) gi16(g_lay.o_nmig, (b))
+#define setNMIGB(b, v) si16(g_lay.o_nmig, (b), (v))
+#define RBI(k, i) gi16(g_lay.o_rb_i, (k) * g_lay.RB + (i))
+#define setRBI(k, i, v) si16(g_lay.o_rb_i, (k) * g_lay.RB + (i), (v))
+#define ISC(k) gi32(g_lay.o_iscal, (k))
+#define setISC(k, v) si32(g_lay.o_iscal, (k), (v))
+#define CBIT(i) gu8(g_lay.o_condbit, (i))
+#define setCBIT(i, v) su8(g_lay.o_condbit, (i), (v))
+#define DIRTY(i) gu8(g_lay.o_dirty, (i))
+#define setDIRTY(i, v) su8(g_lay.o_dirty, (i), (v))
+// scratch
+#define DEV(inst, i) gi16(g_lay.s_dev[inst], (i))
+#define setDEV(inst, i, v) si16(g_lay.s_dev[inst], (i), (v))
+#define DCOAL(inst, i) gf64(g_lay.s_dcoal[inst], (i))
+#define setDCOAL(inst, i, v) sf64(g_lay.s_dcoal[inst], (i), (v))
+#define DMIG(inst, i) gf64(g_lay.s_dmig[inst], (i))
+#define setDMIG(inst, i, v) sf64(g_lay.s_dmig[inst], (i), (v))
+#define DPOPS(inst, i) gi16(g_lay.s_dpops[inst], (i))
+#define setDPOPS(inst, i, v) si16(g_lay.s_dpops[inst], (i), (v))
+#define DBANDS(inst, i) gi16(g_lay.s_dbands[inst], (i))
+#define setDBANDS(inst, i, v) si16(g_lay.s_dbands[inst], (i), (v))
+#define DI(inst, k) gi32(g_lay.s_di[inst], (k))
+#define setDI(inst, k, v) si32(g_lay.s_di[inst], (k), (v))
+#define SPRI(k) gi32(g_lay.s_spri, (k))
+#define setSPRI(k, v) si32(g_lay.s_spri, (k), (v))
+#define SPRA(k, i) gi16(g_lay.s_spri16, (k) * GPH_MAX_MIGS + (i))
+#define setSPRA(k, i, v) si16(g_lay.s_spri16, (k) * GPH_MAX_MIGS + (i), (v))
+#define SPRAGE(i) gf64(g_lay.s_sprf, (i))
+#define setSPRAGE(i, v) sf64(g_lay.s_sprf, (i), (v))
+#define SPRLN(r) gf64(g_lay.s_sprf, GPH_MAX_MIGS + (r))
+#define setSPRLN(r, v) sf64(g_lay.s_sprf, GPH_MAX_MIGS + (r), (v))
+#define CNT(k) gi32(g_lay.s_cnt, (k))
+#define setCNT(k, v) si32(g_lay.s_cnt, (k), (v))
+
+// ordered list of live migration bands (<= 16 entries of 4 bits): the reference keeps
+// int live_mig_bands[MAX_MIG_BANDS] with swap-removal; the order decides which band a
+// sampled migration picks (patch.c:1167-1169), so it is reproduced exactly -- in one
+// 64-bit scalar instead of a private-memory array.
+struct LiveList {
+  uint64_t bits;
+  int n;
+};
+GPH_DEV int ll_get(const LiveList &l, int i) { return (int)((l.bits >> (4 * i)) & 15); }
+GPH_DEV void ll_set(LiveList &l, int i, int v) { l.bits = (l.bits & ~((uint64_t)15 << (4 * i))) | ((uint64_t)v << (4 * i)); }
+GPH_DEV void ll_push(LiveList &l, int v) { ll_set(l, l.n, v); l.n++; }
+GPH_DEV int ll_find(const LiveList &l, int v) { int i; for (i = 0; i < l.n; i++) if (ll_get(l, i) == v) break; return i; }
+GPH_DEV void ll_swap_remove(LiveList &l, int i) { l.n--; ll_set(l, i, ll_get(l, l.n)); }
+
+#define gmin2(a, b) ((a) < (b) ? (a) : (b))
+#define gmax2(a, b) ((a) > (b) ? (a) : (b))
+
+GPH_DEV void gph_fail(int code) { if (CNT(CN_ERROR) == 0) setCNT(CN_ERROR, code); }
+GPH_DEV int gph_failed() { return CNT(CN_ERROR) != 0; }
+
+// ---------------------------------------------------------------- RNG
+// rndu, utils.c:498-513: unsigned 32-bit Wichmann-Hill without the sign fix-up
+GPH_DEV double l_rndu()
+{
+  uint32_t x = (uint32_t)ISC(IS_RX), y = (uint32_t)ISC(IS_RY), z = (uint32_t)ISC(IS_RZ);
+  double r;
+  x = 171u * (x % 177u) - 2u * (x / 177u);
+  y = 172u * (y % 176u) - 35u * (y / 176u);
+  z = 170u * (z % 178u) - 63u * (z / 178u);
+  setISC(IS_RX, (int)x);
+  setISC(IS_RY, (int)y);
+  setISC(IS_RZ, (int)z);
+  r = x / 30269.0 + y / 30307.0 + z / 30323.0;
+  r = (r - (int)r);
+  return r;
+}
+// rndnormal, utils.c:459-472
+GPH_DEV double l_rndnormal()
+{
+  double u, v, s;
+  int guard = 0;
+  for (;;) {
+    if (++guard > 100000) { gph_fail(89); return 0.0; }
+    u = 2 * l_rndu() - 1;
+    v = 2 * l_rndu() - 1;
+    s = u * u + v * v;
+    if (s > 0 && s < 1) break;
+  }
+  s = sqrt(-2. * log(s) / s);
+  return u * s;
+}
+// rnd2normal8, utils.c:482-488 (kernel constants utils.c:427-431)
+GPH_DEV double l_rnd2normal8()
+{
+  const double m2s2 = 8.;
+  double m2N = sqrt(m2s2 / (m2s2 + 1.));
+  double s2N = sqrt(1. / (m2s2 + 1.));
+  double z = m2N + l_rndnormal() * s2N;
+  z = l_rndu() < 0.5 ? z : -z;
+  return z;
+}
+// reflect, utils.c:333-398
+GPH_DEV double l_reflect(double x, double a, double b)
+{
+  const double slack = 0.000000001;
+  double xnew, di;
+  a += slack;
+  b -= slack;
+  if (b <= a) return (a + b) / 2.;
+  if (x < b && x > a) return x;
+  xnew = x;
+  if (xnew <= a) xnew = 2. * a - xnew;
+  di = 2. * (b - a);
+  xnew = xnew - di * floor((xnew - a) / di);
+  if (xnew >= b) xnew = 2. * b - xnew;
+  /* the reference loops here until the value is inside; landing exactly on a bound
+   * ping-pongs forever there.  A wavefront must not hang: bail out after 64 folds. */
+  int guard = 0;
+  while (xnew <= a || xnew >= b) {
+    if (xnew >= b) xnew = 2. * b - xnew;
+    else xnew = 2 * a - xnew;
+    if (++guard > 64) { gph_fail(90); return (a + b) / 2.; }
+  }
+  return xnew;
+}
+
+// ---------------------------------------------------------------- data likelihood
+// copyNodeConditionals, LocusDataLikelihood.c:1889-1906
+GPH_DEV int lik_mark_cond(int node)
+{
+  int k;
+  if (CNT(CN_P) <= 0 || DIRTY(node)) return 1;
+  k = ISC(IS_NCHANGEDC);
+  si16(g_lay.o_changedc, k, node);
+  setISC(IS_NCHANGEDC, k + 1);
+  setDIRTY(node, 1);
+  setCBIT(node, CBIT(node) ^ 1);
+  return 0;
+}
+// copyNodeToSaved, LocusDataLikelihood.c:1864-1876
+GPH_DEV void lik_save_node(int node, int recalc)
+{
+  int k;
+  if (recalc) lik_mark_cond(node);
+  k = ISC(IS_NCHANGED);
+  si16(g_lay.o_changed, k, node);
+  setISC(IS_NCHANGED, k + 1);
+  setSVAGE(node, AGE(node));
+  si16(g_lay.o_sv_father, node, FATH(node));
+  si16(g_lay.o_sv_left, node, LEFT(node));
+  si16(g_lay.o_sv_right, node, RGHT(node));
+}
+// adjustGenNodeAge, LocusDataLikelihood.c:875-882
+GPH_DEV void lik_adjust_age(int node, double age)
+{
+  lik_save_node(node, 1);
+  setAGE(node, age);
+}
+// resetSaved, LocusDataLikelihood.c:852-864
+GPH_DEV void lik_reset_saved()
+{
+  int i;
+  setISC(IS_COPYALL, 0);
+  setISC(IS_NCHANGED, 0);
+  setISC(IS_NCHANGEDC, 0);
+  setISC(IS_SV_ROOT, -1);
+  setFS(FS_SV_DATALNL, FS(FS_DATALNL));
+  for (i = 0; i < g_lay.N; i++) setDIRTY(i, 0);
+}
+// revertToSaved, LocusDataLikelihood.c:768-841 (value semantics: a node's saved
+// record and its previous conditional array are restored)
+GPH_DEV void lik_revert()
+{
+  int i, node, nc, ncc;
+  setFS(FS_DATALNL, FS(FS_SV_DATALNL));
+  if (ISC(IS_SV_ROOT) >= 0) { setISC(IS_ROOT, ISC(IS_SV_ROOT)); setISC(IS_SV_ROOT, -1); }
+  if (ISC(IS_COPYALL)) {
+    for (node = 0; node < g_lay.N; node++) {
+      setAGE(node, SVAGE(node));
+      setFATH(node, SVF(node));
+      setLEFT(node, SVL(node));
+      setRGHT(node, SVR(node));
+      if (DIRTY(node)) setCBIT(node, CBIT(node) ^ 1);
+    }
+    lik_reset_saved();
+    return;
+  }
+  nc = ISC(IS_NCHANGED);
+  ncc = ISC(IS_NCHANGEDC);
+  if (nc == 0 && ncc == 0) return;
+  for (i = 0; i < nc; i++) {
+    node = CHG(i);
+    setAGE(node, SVAGE(node));
+    setFATH(node, SVF(node));
+    setLEFT(node, SVL(node));
+    setRGHT(node, SVR(node));
+    if (DIRTY(node)) { setCBIT(node, CBIT(node) ^ 1); setDIRTY(node, 0); }
+  }
+  for (i = 0; i < ncc; i++) {
+    node = CHGC(i);
+    if (DIRTY(node)) { setCBIT(node, CBIT(node) ^ 1); setDIRTY(node, 0); }
+  }
+  setISC(IS_NCHANGED, 0);
+  setISC(IS_NCHANGEDC, 0);
+}
+
+// computeEdgeConditionalJC, LocusDataLikelihood.c:1831-1848
+GPH_DEV double edge_prob(double len)
+{
+  if (len < 1e-100) return 0.0;
+  return ((1 - exp(-4 * len / 3.0)) / 4.0);
+}
+
+// LDS byte offset of the conditional array (buffer `bit`) of internal node `node`
+GPH_DEV int cond_off(int node, int bit)
+{
+  int P = CNT(CN_P);
+  return g_lay.o_cond + ((bit * (g_lay.n - 1) + (node - g_lay.n)) * P) * 32;
+}
+
+// one child's factor for (pattern p, base a): computeSubtreeConditionals_new,
+// LocusDataLikelihood.c:1650-1673.  A leaf child is a base code (one-hot / N).
+GPH_DEV double child_factor(int child, int coff, int p, int a, double pe, double qe)
+{
+  double s0, s1, s2, s3, sa, S, Sp;
+  if (child < g_lay.n) {
+    int code = gu8v(g_lay.q_leaf, p * g_lay.n + child);
+    s0 = (code == 4 || code == 0) ? 1.0 : 0.0;
+    s1 = (code == 4 || code == 1) ? 1.0 : 0.0;
+    s2 = (code == 4 || code == 2) ? 1.0 : 0.0;
+    s3 = (code == 4 || code == 3) ? 1.0 : 0.0;
+  } else {
+    s0 = gf64(coff, 4 * p + 0);
+    s1 = gf64(coff, 4 * p + 1);
+    s2 = gf64(coff, 4 * p + 2);
+    s3 = gf64(coff, 4 * p + 3);
+  }
+  sa = a == 0 ? s0 : a == 1 ? s1 : a == 2 ? s2 : s3;
+  S = 0.0;
+  S += s0;
+  S += s1;
+  S += s2;
+  S += s3;
+  if (S >= 4) return 1.0; /* missing data below this edge: factor not applied (x*1.0 == x) */
+  Sp = S * pe;
+  return (Sp + sa * qe);
+}
+
+// recompute the conditionals of one internal node: lanes = (pattern, base) pairs
+// inner loops of computeConditionalJC_new, LocusDataLikelihood.c:1596-1633
+GPH_DEV void prune_node(int node)
+{
+  int l = LEFT(node), r = RGHT(node), P = CNT(CN_P);
+  double mut = FS(FS_MUTRATE); /* locus mutation rate (1 under CONST, GPhoCS.c:1141) */
+  double pl = edge_prob(mut * (AGE(node) - AGE(l)));
+  double ql = 1 - 4.0 * pl;
+  double pr = edge_prob(mut * (AGE(node) - AGE(r)));
+  double qr = 1 - 4.0 * pr;
+  int po = cond_off(node, CBIT(node));
+  int lo = l >= g_lay.n ? cond_off(l, CBIT(l)) : 0;
+  int ro = r >= g_lay.n ? cond_off(r, CBIT(r)) : 0;
+  int idx;
+  for (idx = GPH_LANE; idx < 4 * P; idx += GPH_NLANES) {
+    int p = idx >> 2, a = idx & 3;
+    double v = 1.0, f;
+    f = child_factor(l, lo, p, a, pl, ql);
+    v *= f;
+    f = child_factor(r, ro, p, a, pr, qr);
+    v *= f;
+    sf64(po, idx, v);
+  }
+  GPH_SYNC();
+}
+
+// computeLocusDataLikelihood, LocusDataLikelihood.c:426-483, with the recursion of
+// computeConditionalJC_new (:1559-1636) replaced by: mark the ancestors of every
+// dirty node, list the marked internal nodes parent-before-child, process the
+// list backwards.  Same set of recomputed nodes, children always before parents.
+GPH_DEVNI double lik_compute(int useOld)
+{
+  const int n = g_lay.n, N = g_lay.N;
+  int P = CNT(CN_P), i, node, k, sp, nord, ncc, U;
+  uint64_t need = 0;
+  double lnl;
+  if (P == 0) return 0.0;
+  if (!useOld)
+    for (node = n; node < N; node++) lik_mark_cond(node);
+  setFS(FS_SV_DATALNL, FS(FS_DATALNL));
+  if (!useOld) {
+    for (node = n; node < N; node++) need |= (uint64_t)1 << node;
+  } else {
+    ncc = ISC(IS_NCHANGEDC);
+    for (i = 0; i < ncc; i++) {
+      node = CHGC(i);
+      int guard = 0;
+      while (node >= 0 && !((need >> node) & 1)) {
+        need |= (uint64_t)1 << node;
+        node = FATH(node);
+        if (++guard > N) { gph_fail(99); return FS(FS_DATALNL); }
+      }
+    }
+  }
+  if (useOld) setCNT(CN_EVALS, CNT(CN_EVALS) + 1);
+  node = ISC(IS_ROOT);
+  if (!((need >> node) & 1)) return FS(FS_DATALNL);
+  /* pre-order list of needed internal nodes */
+  nord = 0;
+  sp = 0;
+  si16(g_lay.s_stack, sp++, node);
+  while (sp > 0) {
+    node = gi16(g_lay.s_stack, --sp);
+    if (nord >= N) { gph_fail(100); return FS(FS_DATALNL); }
+    si16(g_lay.s_ord, nord++, node);
+    k = LEFT(node);
+    if (k >= n && ((need >> k) & 1)) si16(g_lay.s_stack, sp++, k);
+    k = RGHT(node);
+    if (k >= n && ((need >> k) & 1)) si16(g_lay.s_stack, sp++, k);
+  }
+  for (i = nord - 1; i >= 0; i--) {
+    node = gi16(g_lay.s_ord, i);
+    if (useOld) lik_mark_cond(node);
+    prune_node(node);
+  }
+  setCNT(CN_NODES, CNT(CN_NODES) + nord);
+  /* root reduction, LocusDataLikelihood.c:466-479: per unphased pattern
+   * log(sum over phases and bases / (4*phases)) * count, summed in pattern order */
+  {
+    int ro = cond_off(ISC(IS_ROOT), CBIT(ISC(IS_ROOT)));
+    int p;
+    for (p = GPH_LANE; p < P; p += GPH_NLANES) {
+      int ph = gu8v(g_lay.q_phases, p);
+      if (ph > 0) {
+        int nc = 4 * ph, c;
+        double prob = 0.0;
+        for (c = 0; c < nc; c++) prob += gf64(ro, p * 4 + c);
+        sf64(g_lay.s_terms, p, log(prob / nc) * gi32v(g_lay.q_count, p));
+      }
+    }
+    GPH_SYNC();
+    lnl = 0.0;
+    U = 0;
+    for (p = 0; p < P; p++) {
+      if (gu8(g_lay.q_phases, p) > 0) { lnl += gf64(g_lay.s_terms, p); U++; }
+    }
+  }
+  setFS(FS_DATALNL, lnl);
+  if (useOld) sf64(g_lay.s_cntf, 0, gf64(g_lay.s_cntf, 0) + (96.0 * nord * P + 20.0 * N + 8.0 * U + 8.0));
+  return lnl;
+}
+
+// scaleAllNodeAges, LocusDataLikelihood.c:895-917
+GPH_DEV double lik_scale_ages(double factor)
+{
+  int node;
+  double old = FS(FS_DATALNL);
+  setISC(IS_COPYALL, 1);
+  for (node = 0; node < g_lay.N; node++) lik_adjust_age(node, factor * AGE(node));
+  lik_compute(1);
+  return FS(FS_DATALNL) - old;
+}
+
+// executeGenSPR, LocusDataLikelihood.c:931-1012
+GPH_DEV int lik_spr(int subtreeRoot, int target, double age)
+{
+  int targetFather = FATH(target);
+  int father = FATH(subtreeRoot);
+  int grandpa = FATH(father);
+  int sibling = LEFT(father) + RGHT(father) - subtreeRoot;
+  lik_adjust_age(father, age);
+  if (target == sibling || target == father) return 0;
+  lik_save_node(sibling, 0);
+  setFATH(sibling, grandpa);
+  if (grandpa >= 0) {
+    lik_save_node(grandpa, 1);
+    if (LEFT(grandpa) == father) setLEFT(grandpa, sibling);
+    else setRGHT(grandpa, sibling);
+  }
+  setFATH(father, targetFather);
+  setLEFT(father, subtreeRoot);
+  setRGHT(father, target);
+  if (target != grandpa) lik_save_node(target, 0);
+  setFATH(target, father);
+  if (targetFather < 0) {
+    setISC(IS_SV_ROOT, target);
+    setISC(IS_ROOT, father);
+    return 1;
+  }
+  if (targetFather == sibling) lik_mark_cond(targetFather);
+  else if (targetFather != grandpa) lik_save_node(targetFather, 1);
+  if (LEFT(targetFather) == target) setLEFT(targetFather, father);
+  else setRGHT(targetFather, father);
+  if (grandpa < 0) {
+    setISC(IS_SV_ROOT, father);
+    setISC(IS_ROOT, sibling);
+    return 2;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- migration-node lookups
+// findLastMig / findFirstMig, patch.c:374-414
+GPH_DEV int find_last_mig(int node, double age)
+{
+  int i, mig, last = -1, nm = ISC(IS_NUM_MIGS);
+  for (i = 0; i < nm; i++) {
+    mig = LIVING(i);
+    if (MG(mig, MG_BRANCH) != node) continue;
+    if ((age < 0 || MAGE(mig) < age) && (last < 0 || MAGE(mig) > MAGE(last))) last = mig;
+  }
+  return last;
+}
+GPH_DEV int find_first_mig(int node, double age)
+{
+  int i, mig, first = -1, nm = ISC(IS_NUM_MIGS);
+  for (i = 0; i < nm; i++) {
+    mig = LIVING(i);
+    if (MG(mig, MG_BRANCH) != node) continue;
+    if (MAGE(mig) > age && (first < 0 || MAGE(mig) < MAGE(first))) first = mig;
+  }
+  return first;
+}
+// getEdgesForTimePop, patch.c:526-571 (targets written to s_targets)
+GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
+{
+  int node, mig, pop1, num = 0, f;
+  if (g_model.popAge[pop] > time + 0.0000001) return 0;
+  for (node = 0; node < g_lay.N; node++) {
+    f = FATH(node);
+    if (node == exc || AGE(node) > time || (f >= 0 && AGE(f) <= time)) continue;
+    if (pop == g_lay.rootPop) { si16(g_lay.s_targets, num++, node); continue; }
+    mig = find_last_mig(node, time);
+    pop1 = (mig >= 0) ? MG(mig, MG_SPOP) : NPOP(node);
+    if ((g_model.isAnc[pop] >> pop1) & 1) si16(g_lay.s_targets, num++, node);
+  }
+  return num;
+}
+
+// ---------------------------------------------------------------- event chain
+// removeEvent, patch.c:1666-1700
+GPH_DEV void remove_event(int ev)
+{
+  int nx = ENEXT(ev), pv = EPREV(ev);
+  setEVT(nx, EVT(nx) + EVT(ev));
+  setEPREV(nx, pv);
+  if (pv < 0) {
+    int guard = 0;
+    for (pv = nx; ETYPE(pv) != GPH_END_CHAIN; pv = ENEXT(pv)) { if (++guard > g_lay.E || ENEXT(pv) < 0) { gph_fail(91); return; } }
+    setFIRSTEV(ENODE(pv), nx);
+  } else {
+    setENEXT(pv, nx);
+  }
+  nx = ISC(IS_FREE);
+  setENEXT(ev, nx);
+  setEPREV(nx, ev);
+  setISC(IS_FREE, ev);
+  setEVT(ev, 0);
+  setENLIN(ev, 0);
+  setENODE(ev, -1);
+}
+// createEventBefore, patch.c:1707-1742
+GPH_DEV int create_event_before(int pop, int ev, double elapsed)
+{
+  int pv = EPREV(ev), nw = ISC(IS_FREE);
+  setISC(IS_FREE, ENEXT(nw));
+  if (ENEXT(nw) < 0) { gph_fail(15); }
+  setENEXT(nw, ev);
+  setEPREV(nw, pv);
+  setENLIN(nw, ENLIN(ev));
+  setEVT(nw, elapsed);
+  setETYPE(nw, GPH_DUMMY);
+  setEPREV(ev, nw);
+  setEVT(ev, EVT(ev) - elapsed);
+  if (pv < 0) setFIRSTEV(pop, nw);
+  else setENEXT(pv, nw);
+  return nw;
+}
+// createEvent, patch.c:1753-1802
+GPH_DEVNI int create_event(int pop, double age)
+{
+  int ev;
+  double dt = age - g_model.popAge[pop];
+  if (dt < 0) return -1;
+  if (pop != g_lay.rootPop && age > g_model.popAge[g_model.popFather[pop]] + 0.000001) return -1;
+  int guard = 0;
+  for (ev = FIRSTEV(pop); ETYPE(ev) != GPH_END_CHAIN && EVT(ev) < dt; ev = ENEXT(ev)) {
+    dt -= EVT(ev);
+    if (++guard > g_lay.E || ENEXT(ev) < 0) { gph_fail(92); return -1; }
+  }
+  if (EVT(ev) < dt) {
+    if (EVT(ev) < dt - 0.000001) { gph_fail(18); return -1; }
+    dt = EVT(ev);
+  }
+  return create_event_before(pop, ev, dt);
+}
+
+// recalcStats, patch.c:2387-2513.  The reference also patches the global totals
+// here; the engine instead re-reduces the per-locus statistics after the kernel.
+GPH_DEVNI double recalc_stats(int pop)
+{
+  int n, id, b, ev, nc = 0;
+  LiveList live = {0, 0};
+  double t, delta = 0.0, cs = 0.0;
+  int guard = 0;
+  ev = FIRSTEV(pop);
+  n = ENLIN(ev);
+  for (; ev >= 0; ev = ENEXT(ev)) {
+    if (++guard > g_lay.E) { gph_fail(93); return 0.0; }
+    setENLIN(ev, n);
+    id = ENODE(ev);
+    t = EVT(ev);
+    cs += n * (n - 1) * t;
+    for (b = 0; b < live.n; b++) sf64(g_lay.s_chkmig, ll_get(live, b), gf64(g_lay.s_chkmig, ll_get(live, b)) + n * t);
+    switch (ETYPE(ev)) {
+    case GPH_SAMPLES_START: n += g_model.samplesPerPop[pop]; break;
+    case GPH_COAL: nc++; n--; break;
+    case GPH_IN_MIG: {
+      int bb = MG(id, MG_BAND);
+      si16(g_lay.s_chknm, bb, gi16(g_lay.s_chknm, bb) + 1);
+      n--;
+      break;
+    }
+    case GPH_OUT_MIG: n++; break;
+    case GPH_MIG_BAND_START:
+      ll_push(live, id);
+      si16(g_lay.s_chknm, id, 0);
+      sf64(g_lay.s_chkmig, id, 0.0);
+      break;
+    case GPH_MIG_BAND_END:
+      delta -= (gf64(g_lay.s_chkmig, id) - MIGST(id)) * g_model.migRate[id];
+      setMIGST(id, gf64(g_lay.s_chkmig, id));
+      setNMIGB(id, gi16(g_lay.s_chknm, id));
+      b = ll_find(live, id);
+      if (b == live.n) { gph_fail(25); return 0.0; }
+      ll_swap_remove(live, b);
+      break;
+    case GPH_DUMMY:
+    case GPH_END_CHAIN: break;
+    default: gph_fail(26); return 0.0;
+    }
+  }
+  if (live.n != 0) { gph_fail(27); return 0.0; }
+  delta -= (cs - COALS(pop)) / (g_model.theta[pop]);
+  setCOALS(pop, cs);
+  setNCOAL(pop, nc);
+  return delta;
+}
+
+// computeGenetreeStats, patch.c:2330-2354
+GPH_DEV void compute_genetree_stats()
+{
+  int i, pop;
+  for (i = 0; i < g_lay.K; i++) {
+    pop = g_model.postOrder[i];
+    if (pop >= g_lay.Kc)
+      setENLIN(FIRSTEV(pop), ENLIN(g_model.popSon0[pop]) + ENLIN(g_model.popSon1[pop]));
+    else
+      setENLIN(FIRSTEV(pop), 0);
+    recalc_stats(pop);
+  }
+}
+
+// gtreeLnLikelihood, patch.c:2702-2738 (no admixture)
+GPH_DEV double gtree_lnl()
+{
+  int pop, b;
+  double lnLd = 0, theta, rate;
+  for (pop = 0; pop < g_lay.K; pop++) {
+    theta = g_model.theta[pop];
+    lnLd += NCOAL(pop) * log(2 / theta) - COALS(pop) / (theta);
+  }
+  for (b = 0; b < g_lay.B; b++) {
+    rate = g_model.migRate[b];
+    if (rate > 0.0) lnLd += NMIGB(b) * log(rate) - MIGST(b) * rate;
+  }
+  return lnLd;
+}
+
+// constructEventChain, patch.c:1961-2125
+GPH_DEV void construct_event_chain()
+{
+  const int K = g_lay.K, E = g_lay.E;
+  int i, pop, mig, node, ev, b;
+  double age;
+  for (pop = 0; pop < K; pop++) {
+    setETYPE(pop, GPH_END_CHAIN);
+    setENEXT(pop, -1);
+    setEPREV(pop, -1);
+    setENODE(pop, pop);
+    setENLIN(pop, 0);
+    if (pop == g_lay.rootPop) setEVT(pop, GPH_OLDAGE - g_model.popAge[g_lay.rootPop]);
+    else setEVT(pop, g_model.popAge[g_model.popFather[pop]] - g_model.popAge[pop]);
+    setFIRSTEV(pop, pop);
+  }
+  setISC(IS_FREE, K);
+  setEPREV(K, -1);
+  setENEXT(E - 1, -1);
+  for (ev = K; ev < E - 1; ev++) { setENEXT(ev, ev + 1); setEPREV(ev + 1, ev); }
+  for (b = 0; b < g_lay.B; b++) {
+    pop = g_model.bandTgt[b];
+    ev = create_event(pop, g_model.bandStart[b]);
+    if (ev < 0) { gph_fail(20); return; }
+    setETYPE(ev, GPH_MIG_BAND_START);
+    setENODE(ev, b);
+    ev = create_event(pop, g_model.bandEnd[b]);
+    if (ev < 0) { gph_fail(21); return; }
+    setETYPE(ev, GPH_MIG_BAND_END);
+    setENODE(ev, b);
+  }
+  for (pop = 0; pop < g_lay.Kc; pop++) {
+    ev = create_event(pop, g_model.sampleAge[pop]);
+    if (ev < 0) { gph_fail(21); return; }
+    setETYPE(ev, GPH_SAMPLES_START);
+  }
+  for (i = 0; i < ISC(IS_NUM_MIGS); i++) {
+    mig = LIVING(i);
+    age = MAGE(mig);
+    ev = create_event(MG(mig, MG_TPOP), age);
+    if (ev < 0) { gph_fail(22); return; }
+    setETYPE(ev, GPH_IN_MIG);
+    setENODE(ev, mig);
+    setMG(mig, MG_TEV, ev);
+    ev = create_event(MG(mig, MG_SPOP), age);
+    if (ev < 0) { gph_fail(23); return; }
+    setETYPE(ev, GPH_OUT_MIG);
+    setENODE(ev, mig);
+    setMG(mig, MG_SEV, ev);
+  }
+  for (node = g_lay.n; node < g_lay.N; node++) {
+    ev = create_event(NPOP(node), AGE(node));
+    if (ev < 0) { gph_fail(24); return; }
+    setETYPE(ev, GPH_COAL);
+    setENODE(ev, node);
+    setNEV(node, ev);
+  }
+}
+
+// ---------------------------------------------------------------- considerEventMove
+// computeMigStatsDelta, patch.c:1838-1864
+GPH_DEV void mig_stats_delta(int inst, double bottom_age, int bottom_pop, double top_age, int dlin)
+{
+  int b, nb = 0;
+  double dt, lo, hi;
+  for (b = 0; b < g_lay.B; b++) {
+    if (!((g_model.isAnc[g_model.bandTgt[b]] >> bottom_pop) & 1)) continue;
+    hi = gmin2(g_model.bandEnd[b], top_age);
+    lo = gmax2(g_model.bandStart[b], bottom_age);
+    dt = hi - lo;
+    if (dt <= 0) continue;
+    setDBANDS(inst, nb, b);
+    setDMIG(inst, nb, dlin * dt);
+    nb++;
+  }
+  setDI(inst, DI_NBANDS, nb);
+}
+// computeCoalStatsDelta, patch.c:1878-1927
+GPH_DEV void coal_stats_delta(int inst, int bottom_event, int bottom_pop, int top_event, int dlin)
+{
+  int pop = bottom_pop, ev = bottom_event, np = 1, ne = 0;
+  double acc = 0;
+  int guard = 0;
+  setDPOPS(inst, 0, pop);
+  while (ev >= 0) {
+    if (++guard > 2 * g_lay.E) { gph_fail(94); break; }
+    acc += dlin * (dlin - 1 + 2 * ENLIN(ev)) * EVT(ev);
+    setDEV(inst, ne, ev);
+    ne++;
+    if (ev == top_event) break;
+    ev = ENEXT(ev);
+    if (ev < 0) {
+      if (g_model.popFather[pop] < 0) { gph_fail(19); break; }
+      setDCOAL(inst, np - 1, acc);
+      acc = 0;
+      pop = g_model.popFather[pop];
+      ev = FIRSTEV(pop);
+      setDPOPS(inst, np, pop);
+      np++;
+    }
+  }
+  setDCOAL(inst, np - 1, acc);
+  setDI(inst, DI_NPOPS, np);
+  setDI(inst, DI_NEV, ne);
+}
+// computeDeltaLnLd, patch.c:1516-1532
+GPH_DEV double delta_lnld(int inst)
+{
+  int i, np = DI(inst, DI_NPOPS), nb = DI(inst, DI_NBANDS);
+  double r = 0;
+  for (i = 0; i < np; i++) r -= DCOAL(inst, i) / g_model.theta[DPOPS(inst, i)];
+  for (i = 0; i < nb; i++) r -= DMIG(inst, i) * g_model.migRate[DBANDS(inst, i)];
+  return r;
+}
+// considerEventMove, patch.c:1434-1507
+GPH_DEVNI double consider_event_move(int inst, int event_id, int source_pop, double original_age,
+                                     int target_pop, double new_age)
+{
+  int new_event, bottom_event, top_event, bottom_pop, dlin;
+  double top_age, bottom_age, r;
+  new_event = create_event(target_pop, new_age);
+  if (new_event < 0) { gph_fail(13); return 0.0; }
+  setDI(inst, DI_ORIG, event_id);
+  setDI(inst, DI_UPD, new_event);
+  if (new_age > original_age) {
+    dlin = (ETYPE(event_id) == GPH_OUT_MIG) ? (-1) : (1);
+    bottom_event = ENEXT(event_id);
+    top_event = new_event;
+    bottom_pop = source_pop;
+    top_age = new_age;
+    bottom_age = original_age;
+  } else {
+    dlin = (ETYPE(event_id) == GPH_OUT_MIG) ? (1) : (-1);
+    bottom_event = ENEXT(new_event);
+    top_event = event_id;
+    bottom_pop = target_pop;
+    top_age = original_age;
+    bottom_age = new_age;
+  }
+  setDI(inst, DI_DLIN, dlin);
+  coal_stats_delta(inst, bottom_event, bottom_pop, top_event, dlin);
+  mig_stats_delta(inst, bottom_age, bottom_pop, top_age, dlin);
+  r = delta_lnld(inst);
+  if (ETYPE(event_id) == GPH_COAL && source_pop != target_pop)
+    r += log(g_model.theta[source_pop] / g_model.theta[target_pop]);
+  return r;
+}
+GPH_DEV void delta_clear(int inst)
+{
+  setDI(inst, DI_NPOPS, 0);
+  setDI(inst, DI_NBANDS, 0);
+  setDI(inst, DI_NEV, 0);
+  setDI(inst, DI_DLIN, 0);
+  setDI(inst, DI_ORIG, -1);
+  setDI(inst, DI_UPD, -1);
+}
+// acceptEventChainChanges, patch.c:1540-1633
+GPH_DEV void accept_event_chain_changes(int inst)
+{
+  int i, pop, b, ue, oe, dlin = DI(inst, DI_DLIN);
+  for (i = 0; i < DI(inst, DI_NPOPS); i++) {
+    pop = DPOPS(inst, i);
+    setCOALS(pop, COALS(pop) + DCOAL(inst, i));
+  }
+  for (i = 0; i < DI(inst, DI_NBANDS); i++) {
+    b = DBANDS(inst, i);
+    setMIGST(b, MIGST(b) + DMIG(inst, i));
+  }
+  oe = DI(inst, DI_ORIG);
+  i = DI(inst, DI_NEV) - 1;
+  if (i >= 0 && DEV(inst, i) == oe) i--;
+  for (; i >= 0; i--) setENLIN(DEV(inst, i), ENLIN(DEV(inst, i)) + dlin);
+  ue = DI(inst, DI_UPD);
+  if (ue >= 0) {
+    setENODE(ue, ENODE(oe));
+    setETYPE(ue, ETYPE(oe));
+    switch (ETYPE(ue)) {
+    case GPH_COAL: setNEV(ENODE(ue), ue); break;
+    case GPH_OUT_MIG: setMG(ENODE(ue), MG_SEV, ue); break;
+    case GPH_IN_MIG: setMG(ENODE(ue), MG_TEV, ue); break;
+    default: gph_fail(14); break;
+    }
+    remove_event(oe);
+  }
+  delta_clear(inst);
+}
+// rejectEventChainChanges, patch.c:1639-1661
+GPH_DEV void reject_event_chain_changes(int inst)
+{
+  if (DI(inst, DI_UPD) >= 0) remove_event(DI(inst, DI_UPD));
+  delta_clear(inst);
+}
+
+// ---------------------------------------------------------------- rubber band
+// rubberBand, patch.c:596-801
+GPH_DEVNI double rubber_band(int pop, double static_point, double moving_point, double factor, int post,
+                             int *out_num_events)
+{
+  int i, ev, b, node_id, num_lins, count_events = 0, flag, ty;
+  LiveList live = {0, 0};
+  double age, dt, mig_rate = 0.0, mig_delta, coal_delta = 0.0, lnLd = 0.0, age1;
+  double fm1 = factor - 1.0;
+  double start_time = gmin2(static_point, moving_point);
+  double end_time = gmax2(static_point, moving_point);
+  if (pop == g_lay.rootPop) { start_time = moving_point; end_time = GPH_OLDAGE; }
+  ev = FIRSTEV(pop);
+  age = g_model.popAge[pop];
+  flag = (age >= start_time);
+  int guard = 0;
+  while (age < end_time) {
+    if (ev == -1) { gph_fail(11); break; }
+    if (++guard > g_lay.E) { gph_fail(95); break; }
+    dt = gmin2(EVT(ev), end_time - age);
+    age += dt;
+    if (!flag && age > start_time) { flag = 1; dt = age - start_time; }
+    if (flag) {
+      dt *= fm1;
+      num_lins = ENLIN(ev);
+      mig_delta = dt * num_lins;
+      coal_delta += mig_delta * (num_lins - 1);
+      lnLd -= mig_delta * mig_rate;
+      if (post) {
+        setEVT(ev, EVT(ev) + dt);
+        for (b = 0; b < live.n; b++) setMIGST(ll_get(live, b), MIGST(ll_get(live, b)) + mig_delta);
+      }
+    }
+    ty = ETYPE(ev);
+    if (age >= end_time && ty != GPH_SAMPLES_START) break;
+    node_id = ENODE(ev);
+    switch (ty) {
+    case GPH_COAL:
+      if (flag) {
+        count_events++;
+        if (!post) {
+          age1 = AGE(node_id);
+          age1 += (age1 - static_point) * fm1;
+          lik_adjust_age(node_id, age1);
+        }
+      }
+      break;
+    case GPH_SAMPLES_START:
+      if (flag && g_model.sampleAge[pop] > 0) {
+        if (static_point < moving_point && !post) {
+          age1 = g_model.sampleAge[pop];
+          age1 += (age1 - static_point) * fm1;
+          for (i = 0; i < g_lay.n; i++)
+            if (NPOP(i) == pop) lik_adjust_age(i, age1);
+        }
+      }
+      break;
+    case GPH_IN_MIG:
+      if (flag && post) setMAGE(node_id, MAGE(node_id) + (MAGE(node_id) - static_point) * fm1);
+      break;
+    case GPH_MIG_BAND_START:
+      mig_rate += g_model.migRate[node_id];
+      ll_push(live, node_id);
+      break;
+    case GPH_MIG_BAND_END:
+      mig_rate -= g_model.migRate[node_id];
+      i = ll_find(live, node_id);
+      if (i == live.n) { gph_fail(4); return 0.0; }
+      ll_swap_remove(live, i);
+      break;
+    case GPH_END_CHAIN: age = end_time; break;
+    default: break;
+    }
+    ev = ENEXT(ev);
+  }
+  if (post) setCOALS(pop, COALS(pop) + coal_delta);
+  lnLd -= coal_delta / (g_model.theta[pop]);
+  *out_num_events += count_events;
+  return lnLd;
+}
+
+// rubberBandRipple, patch.c:815-869
+GPH_DEV double rubber_band_ripple(int do_or_redo)
+{
+  int i, pop, nw, orig, nmoved = ISC(IS_RB_NUM);
+  uint32_t affected = 0;
+  double delta = 0.0;
+  if (nmoved == 0) return 0.0;
+  for (i = 0; i < nmoved; i++) {
+    pop = RBI(2, i);
+    orig = RBI(0, i);
+    affected |= 1u << pop;
+    if (do_or_redo) {
+      nw = create_event(pop, RBAGE(i));
+      setRBI(1, i, nw);
+      if (nw < 0) { gph_fail(5); return 0.0; }
+      setETYPE(nw, ETYPE(orig));
+      setENODE(nw, ENODE(orig));
+      setETYPE(orig, GPH_DUMMY);
+    } else {
+      nw = RBI(1, i);
+      setETYPE(orig, ETYPE(nw));
+      if (FIRSTEV(pop) == nw) setENLIN(ENEXT(nw), ENLIN(nw));
+      remove_event(nw);
+    }
+  }
+  for (pop = 0; pop < g_lay.K; pop++)
+    if ((affected >> pop) & 1) delta += recalc_stats(pop);
+  if (!do_or_redo) setISC(IS_RB_NUM, 0);
+  return delta;
+}
+
+// ---------------------------------------------------------------- traceLineage
+// traceLineage, patch.c:886-1331.  RECONNECT == 0: walk the existing edge above
+// `node`, removing one lineage; RECONNECT == 1: re-sample its path from the prior
+template <int RECONNECT>
+GPH_DEVNI int trace_lineage(int node)
+{
+  const int inst = RECONNECT;
+  int i, pop, ev, node_id, b = -1, mig_source, proceed;
+  LiveList live = {0, 0};
+  int target, num_targets, nev = 0;
+  double age, t = 0, event_sample, rate, mig_rate, theta, lnld = 0.0;
+
+  pop = NPOP(node);
+  if (node < g_lay.n) {
+    ev = FIRSTEV(pop);
+    while (ETYPE(ev) != GPH_SAMPLES_START && ETYPE(ev) != GPH_END_CHAIN) ev = ENEXT(ev);
+    if (ETYPE(ev) == GPH_END_CHAIN) { gph_fail(101); setDI(inst, DI_NEV, 0); setSPRLN(RECONNECT, 0.0); return RECONNECT ? -1 : 0; }
+    ev = ENEXT(ev);
+  } else {
+    ev = ENEXT(NEV(node));
+  }
+  theta = g_model.theta[pop];
+  age = AGE(node);
+  if (!RECONNECT) {
+    setSPRI(SI_NOLD, 0);
+    if (node != ISC(IS_ROOT)) setSPRI(SI_FEV_OLD, NEV(FATH(node)));
+  } else {
+    setSPRI(SI_NNEW, 0);
+  }
+  setDI(inst, DI_NPOPS, g_lay.K);
+  for (i = 0; i < g_lay.K; i++) { setDPOPS(inst, i, i); setDCOAL(inst, i, 0.0); }
+  setDI(inst, DI_NBANDS, g_lay.B);
+  for (i = 0; i < g_lay.B; i++) { setDBANDS(inst, i, i); setDMIG(inst, i, 0.0); }
+  mig_rate = 0.0;
+  for (b = 0; b < g_lay.B; b++) {
+    if (g_model.bandTgt[b] == pop && g_model.bandStart[b] < age && g_model.bandEnd[b] > age) {
+      mig_rate += g_model.migRate[b];
+      ll_push(live, b);
+    }
+  }
+  mig_source = -1;
+  proceed = 1;
+  int guard = 0;
+  while (proceed) {
+    if (++guard > 4 * g_lay.E) { gph_fail(96); break; }
+    if (ev < 0) {
+      if (g_model.popFather[pop] < 0) {
+        if (RECONNECT) { setDI(inst, DI_NEV, nev); setSPRLN(RECONNECT, lnld); return -1; }
+        gph_fail(6);
+        break;
+      }
+      pop = g_model.popFather[pop];
+      theta = g_model.theta[pop];
+      ev = FIRSTEV(pop);
+      mig_rate = 0.0;
+      if (fabs(age / g_model.popAge[pop] - 1) > 0.01) { gph_fail(8); break; }
+      age = g_model.popAge[pop];
+    }
+    node_id = ENODE(ev);
+    if (!RECONNECT) {
+      setENLIN(ev, ENLIN(ev) - 1);
+      t = EVT(ev);
+      age += t;
+      proceed = (ev != SPRI(SI_FEV_OLD));
+      if (ETYPE(ev) == GPH_IN_MIG) {
+        if (MG(node_id, MG_BRANCH) == node) {
+          int k = SPRI(SI_NOLD);
+          b = MG(node_id, MG_BAND);
+          mig_source = MG(node_id, MG_SEV);
+          setSPRA(SA_OLD, k, node_id);
+          setSPRI(SI_NOLD, k + 1);
+        }
+      }
+    } else {
+      rate = mig_rate + 2 * ENLIN(ev) / theta;
+      if (rate <= 0) t = EVT(ev);
+      else t = -(1 / rate) * log(l_rndu());
+      if (t >= EVT(ev)) {
+        t = EVT(ev);
+        age += t;
+      } else {
+        age += t;
+        event_sample = rate * l_rndu();
+        if (event_sample < mig_rate) {
+          int k = SPRI(SI_NNEW);
+          if (GPH_MAX_MIGS <= ISC(IS_NUM_MIGS) + k - SPRI(SI_NOLD)) {
+            setCNT(CN_NOTENOUGH, CNT(CN_NOTENOUGH) + 1);
+            setDI(inst, DI_NEV, nev);
+            setSPRLN(RECONNECT, lnld);
+            return -1;
+          }
+          for (i = 0; event_sample >= 0 && i < live.n; i++) event_sample -= g_model.migRate[ll_get(live, i)];
+          if (i <= 0) { gph_fail(9); break; }
+          b = ll_get(live, i - 1);
+          setSPRA(SA_NEWBAND, k, b);
+          if (g_model.bandTgt[b] != pop) { gph_fail(9); break; }
+          setSPRAGE(k, age);
+          ev = create_event_before(pop, ev, t);
+          setSPRA(SA_NEWIN, k, ev);
+          mig_source = create_event(g_model.bandSrc[b], age);
+          setSPRA(SA_NEWOUT, k, mig_source);
+          if (mig_source < 0) { gph_fail(10); break; }
+          setSPRI(SI_NNEW, k + 1);
+        } else {
+          num_targets = edges_for_time_pop((age - t) + EVT(ev) / 2, pop, node);
+          if (num_targets != ENLIN(ev)) { gph_fail(11); break; }
+          i = (int)((event_sample - mig_rate) * theta / 2);
+          target = gi16(g_lay.s_targets, i);
+          lik_spr(node, target, age);
+          setSPRI(SI_FPOP_NEW, pop);
+          setSPRI(SI_TARGET, target);
+          ev = create_event_before(pop, ev, t);
+          setSPRI(SI_FEV_NEW, ev);
+          proceed = 0;
+        }
+      }
+    }
+    setDCOAL(inst, pop, DCOAL(inst, pop) + 2 * ENLIN(ev) * t);
+    for (i = 0; i < live.n; i++) setDMIG(inst, ll_get(live, i), DMIG(inst, ll_get(live, i)) + t);
+    setDEV(inst, nev, ev);
+    nev++;
+    lnld -= (mig_rate + 2 * ENLIN(ev) / theta) * t;
+    if (mig_source >= 0) {
+      lnld += log(g_model.migRate[b]);
+      ev = mig_source;
+      pop = g_model.bandSrc[b];
+      theta = g_model.theta[pop];
+      mig_source = -1;
+      mig_rate = 0.0;
+      live.n = 0;
+      for (b = 0; b < g_lay.B; b++) {
+        if (g_model.bandTgt[b] == pop && g_model.bandStart[b] <= age && g_model.bandEnd[b] > age) {
+          mig_rate += g_model.migRate[b];
+          ll_push(live, b);
+        }
+      }
+    } else if (ETYPE(ev) == GPH_MIG_BAND_START) {
+      mig_rate += g_model.migRate[node_id];
+      ll_push(live, node_id);
+    } else if (ETYPE(ev) == GPH_MIG_BAND_END) {
+      mig_rate -= g_model.migRate[node_id];
+      if (live.n == 1) mig_rate = 0.0;
+      i = ll_find(live, node_id);
+      if (i < live.n) ll_swap_remove(live, i);
+    }
+    ev = ENEXT(ev);
+  }
+  lnld += log(2 / theta);
+  setDI(inst, DI_NEV, nev);
+  setSPRLN(RECONNECT, lnld);
+  return 0;
+}
+
+// replaceMigNodes, patch.c:1343-1420
+GPH_DEV void replace_mig_nodes(int node)
+{
+  int i, j, mig = 0, b, nold = SPRI(SI_NOLD), nnew = SPRI(SI_NNEW), nm;
+  int mx = nold > nnew ? nold : nnew;
+  for (i = 0; i < mx; i++) {
+    if (i < nold) {
+      mig = SPRA(SA_OLD, i);
+      remove_event(MG(mig, MG_SEV));
+      remove_event(MG(mig, MG_TEV));
+      b = MG(mig, MG_BAND);
+      setNMIGB(b, NMIGB(b) - 1);
+    } else {
+      for (mig = 0; mig < GPH_MAX_MIGS; mig++) if (MG(mig, MG_BAND) < 0) break;
+      if (mig == GPH_MAX_MIGS) { gph_fail(12); return; }
+      nm = ISC(IS_NUM_MIGS);
+      setLIVING(nm, mig);
+      setISC(IS_NUM_MIGS, nm + 1);
+      setMG(mig, MG_BRANCH, node);
+    }
+    if (i < nnew) {
+      setMG(mig, MG_SEV, SPRA(SA_NEWOUT, i));
+      setMG(mig, MG_TEV, SPRA(SA_NEWIN, i));
+      setMAGE(mig, SPRAGE(i));
+      b = SPRA(SA_NEWBAND, i);
+      setMG(mig, MG_BAND, b);
+      setMG(mig, MG_SPOP, g_model.bandSrc[b]);
+      setMG(mig, MG_TPOP, g_model.bandTgt[b]);
+      setETYPE(SPRA(SA_NEWOUT, i), GPH_OUT_MIG);
+      setENODE(SPRA(SA_NEWOUT, i), mig);
+      setETYPE(SPRA(SA_NEWIN, i), GPH_IN_MIG);
+      setENODE(SPRA(SA_NEWIN, i), mig);
+      setNMIGB(b, NMIGB(b) + 1);
+    } else {
+      setMG(mig, MG_BAND, -1);
+      nm = ISC(IS_NUM_MIGS);
+      for (j = 0; j < nm; j++) {
+        if (LIVING(j) == mig) { setLIVING(j, LIVING(nm - 1)); setISC(IS_NUM_MIGS, nm - 1); break; }
+      }
+    }
+  }
+}
+
+// synchronizeEvents, patch.c:3548-3633
+GPH_DEV int synchronize_events()
+{
+  int i, pop, ev, id, res = 1;
+  double realAge = 0.0, age, PREC = 0.0000001, et;
+  for (i = 0; i < g_lay.K; i++) {
+    pop = g_model.postOrder[i];
+    int guard = 0;
+    ev = FIRSTEV(pop);
+    age = g_model.popAge[pop];
+    for (; ev >= 0; ev = ENEXT(ev)) {
+      if (++guard > g_lay.E) { gph_fail(97); return 0; }
+      id = ENODE(ev);
+      age += EVT(ev);
+      switch (ETYPE(ev)) {
+      case GPH_SAMPLES_START: realAge = g_model.sampleAge[pop]; break;
+      case GPH_COAL: realAge = AGE(id); break;
+      case GPH_IN_MIG:
+      case GPH_OUT_MIG: realAge = MAGE(id); break;
+      case GPH_MIG_BAND_START: realAge = g_model.bandStart[id]; break;
+      case GPH_MIG_BAND_END: realAge = g_model.bandEnd[id]; break;
+      case GPH_END_CHAIN:
+        if (pop != g_lay.rootPop) realAge = g_model.popAge[g_model.popFather[pop]];
+        else realAge = age;
+        break;
+      default: realAge = age; break;
+      }
+      if (fabs(realAge - age) > PREC) res = 0;
+      et = EVT(ev) + (realAge - age);
+      if (et < -PREC) res = 0;
+      else if (et < 0.0) et = 0.0;
+      setEVT(ev, et);
+      age = realAge;
+    }
+  }
+  return res;
+}
+
+// the state-mutating part of checkGtreeStructure (patch.c:2978-3380): statistics are
+// recomputed from the chain and overwrite the stored ones; returns 0 on inconsistency
+GPH_DEV int check_gtree_structure()
+{
+  int i, n, pop, b, ev, id, res = 1, nc;
+  LiveList live = {0, 0};
+  double age, dt, PREC = 0.0000000001, cs;
+  /* lineages entering each population: LDS work list (s_stack is free here) */
+  for (pop = 0; pop < g_lay.K; pop++) si16(g_lay.s_stack, pop, 0);
+  for (i = 0; i < g_lay.K; i++) {
+    pop = g_model.postOrder[i];
+    cs = 0.0;
+    nc = 0;
+    n = gi16(g_lay.s_stack, pop);
+    age = g_model.popAge[pop];
+    live.n = 0;
+    int guard = 0;
+    for (ev = FIRSTEV(pop); ev >= 0; ev = ENEXT(ev)) {
+      if (++guard > g_lay.E) { gph_fail(98); return 0; }
+      if (ENLIN(ev) != n) res = 0;
+      if (ENEXT(ev) >= 0 && ev != EPREV(ENEXT(ev))) res = 0;
+      id = ENODE(ev);
+      dt = EVT(ev);
+      age += dt;
+      cs += n * (n - 1) * dt;
+      for (b = 0; b < live.n; b++) sf64(g_lay.s_chkmig, ll_get(live, b), gf64(g_lay.s_chkmig, ll_get(live, b)) + n * dt);
+      switch (ETYPE(ev)) {
+      case GPH_SAMPLES_START:
+        n += g_model.samplesPerPop[pop];
+        if (fabs(g_model.sampleAge[pop] - age) > PREC) res = 0;
+        break;
+      case GPH_COAL:
+        nc++;
+        n--;
+        if (fabs(AGE(id) - age) > PREC) res = 0;
+        if (NPOP(id) != pop || NEV(id) != ev) res = 0;
+        break;
+      case GPH_IN_MIG: {
+        int bb = MG(id, MG_BAND);
+        si16(g_lay.s_chknm, bb, gi16(g_lay.s_chknm, bb) + 1);
+        n--;
+        if (fabs(MAGE(id) - age) > PREC || MG(id, MG_TEV) != ev) res = 0;
+        break;
+      }
+      case GPH_OUT_MIG:
+        n++;
+        if (fabs(MAGE(id) - age) > PREC || MG(id, MG_SEV) != ev) res = 0;
+        break;
+      case GPH_MIG_BAND_START:
+        ll_push(live, id);
+        si16(g_lay.s_chknm, id, 0);
+        sf64(g_lay.s_chkmig, id, 0.0);
+        if (fabs(g_model.bandStart[id] - age) > PREC) res = 0;
+        break;
+      case GPH_MIG_BAND_END:
+        b = ll_find(live, id);
+        if (b == live.n) res = 0;
+        else ll_swap_remove(live, b);
+        if (fabs(g_model.bandEnd[id] - age) > PREC) res = 0;
+        break;
+      case GPH_END_CHAIN:
+        if (id != pop || live.n != 0 || ENEXT(ev) >= 0) res = 0;
+        if (pop != g_lay.rootPop) {
+          si16(g_lay.s_stack, g_model.popFather[pop], gi16(g_lay.s_stack, g_model.popFather[pop]) + n);
+          if (fabs(g_model.popAge[g_model.popFather[pop]] - age) > PREC) res = 0;
+        }
+        break;
+      default: res = 0; break;
+      }
+    }
+    sf64(g_lay.s_chkcoal, pop, cs);
+    si16(g_lay.s_chknc, pop, nc);
+  }
+  for (pop = 0; pop < g_lay.K; pop++) {
+    if (fabs(gf64(g_lay.s_chkcoal, pop) - COALS(pop)) > PREC) res = 0;
+    setCOALS(pop, gf64(g_lay.s_chkcoal, pop));
+    if (gi16(g_lay.s_chknc, pop) != NCOAL(pop)) res = 0;
+  }
+  for (b = 0; b < g_lay.B; b++) {
+    if (fabs(gf64(g_lay.s_chkmig, b) - MIGST(b)) > PREC) res = 0;
+    setMIGST(b, gf64(g_lay.s_chkmig, b));
+    if (gi16(g_lay.s_chknm, b) != NMIGB(b)) res = 0;
+  }
+  return res;
+}

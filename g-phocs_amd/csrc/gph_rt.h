@@ -1,0 +1,64 @@
+// gph_rt.h -- execution-model shim.
+//
+// Product build (hipcc, gfx950): one 64-lane wavefront per locus, the locus
+// staged in LDS (`gph_sm`, dynamic shared memory of a single-wave workgroup),
+// layout/model tables in __constant__ memory so every table access is a scalar
+// load.  All chain/tree logic is wave-uniform (every lane executes it on the
+// same LDS words); integer loads that steer control flow go through
+// v_readfirstlane so branches are scalar.  Only the pruning inner loops and the
+// stage-in/out copies are lane-parallel.
+//
+// GPH_HOSTEMU build (g++, tests/hostemu only): the same per-locus code compiled
+// for the host with a 1-lane "wave" so it can be run under sanitizers/gdb in the
+// GPU-less build container.  It is a debugging aid for tests; it is NOT linked
+// into libgphocs_hip.so and there is no CPU fallback in the product.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include "gph_types.h"
+
+#ifdef GPH_HOSTEMU
+#include <string.h>
+#define GPH_DEV static inline
+#define GPH_DEVNI static
+#define GPH_LDS
+#define GPH_LANE 0
+#define GPH_NLANES 1
+#define GPH_SYNC() ((void)0)
+#define RFL(x) (x)
+extern thread_local char *gph_sm;
+extern GphLayout g_lay;
+extern GphModel g_model;
+#else
+#include <hip/hip_runtime.h>
+#define GPH_DEV __device__ inline
+#define GPH_DEVNI __device__ __noinline__
+#define GPH_LDS __attribute__((address_space(3)))
+#define GPH_LANE ((int)threadIdx.x)
+#define GPH_NLANES GPH_WAVE
+#define GPH_SYNC() __syncthreads()
+#define RFL(x) __builtin_amdgcn_readfirstlane((int)(x))
+extern __shared__ __attribute__((aligned(16))) char gph_sm[];
+extern __constant__ GphLayout g_lay;
+extern __constant__ GphModel g_model;
+#endif
+
+typedef GPH_LDS double lf64;
+typedef GPH_LDS int16_t li16;
+typedef GPH_LDS int32_t li32;
+typedef GPH_LDS uint32_t lu32;
+typedef GPH_LDS uint8_t lu8;
+typedef GPH_LDS char lchar;
+
+#define GPH_SMB ((lchar *)gph_sm)
+GPH_DEV double gf64(int off, int i) { return ((lf64 *)(GPH_SMB + off))[i]; }
+GPH_DEV void sf64(int off, int i, double v) { ((lf64 *)(GPH_SMB + off))[i] = v; }
+GPH_DEV int gi16(int off, int i) { return RFL(((li16 *)(GPH_SMB + off))[i]); }
+GPH_DEV void si16(int off, int i, int v) { ((li16 *)(GPH_SMB + off))[i] = (int16_t)v; }
+GPH_DEV int gi32(int off, int i) { return RFL(((li32 *)(GPH_SMB + off))[i]); }
+GPH_DEV void si32(int off, int i, int v) { ((li32 *)(GPH_SMB + off))[i] = v; }
+GPH_DEV int gu8(int off, int i) { return RFL(((lu8 *)(GPH_SMB + off))[i]); }
+GPH_DEV void su8(int off, int i, int v) { ((lu8 *)(GPH_SMB + off))[i] = (uint8_t)v; }
+// lane-varying byte/int loads (no readfirstlane): pruning only
+GPH_DEV int gu8v(int off, int i) { return ((lu8 *)(GPH_SMB + off))[i]; }
+GPH_DEV int gi32v(int off, int i) { return ((li32 *)(GPH_SMB + off))[i]; }

@@ -1,0 +1,104 @@
+// gph_types.h -- MI355X-native per-locus likelihood engine: data layout.
+//
+// HBM layout (one process per GPU, loci sharded across ranks):
+//   pages  : L fixed-size "locus pages" (genealogy, event chain, migration
+//            nodes, sufficient statistics, RNG slot, pending-move storage),
+//            16-byte aligned, contiguous => a wavefront stages its locus into
+//            LDS with perfectly coalesced 16-B/lane loads.
+//   shadow : a second array of L pages written by the *evaluate* kernels of the
+//            global proposals (tau rubber band, mixing); commit/revert kernels
+//            read it.  Loci the serial reference would never have touched after
+//            a migration conflict keep their main page.
+//   cond   : per locus [2][n-1][P][4] fp64 conditional likelihoods of the internal
+//            nodes (double buffer, the page's condbit[node] selects the current
+//            half) -- leaves are not stored as doubles: a leaf is a base code.
+//   seq    : per locus leaf codes u8[P][n], phases u8[P], counts i32[P] (read-only).
+//
+// Replaces the reference's per-locus heap structures: struct LOCUS_LIKELIHOOD
+// (LocusDataLikelihood.c:40-104), Event / EVENT_CHAIN (patch.h:159-172),
+// GENETREE_MIGS (patch.h:138-148), GENETREE_STATS (patch.h:48-51),
+// Locus_SuperStruct (patch.h:108-117), RndCtx slots (utils.c:401).
+#pragma once
+#include <stdint.h>
+
+#define GPH_MAXK 32        // populations   (reference cap 39, patch.h:19)
+#define GPH_MAXB 16        // migration bands (reference cap 100, patch.h:17)
+#define GPH_MAX_MIGS 10    // migration events per genealogy (patch.h:18)
+#define GPH_MAXN 63        // genealogy nodes per locus (n <= 32 leaves)
+#define GPH_OLDAGE 999.0   // patch.h:21
+#define GPH_WAVE 64
+
+enum { GPH_COAL = 0, GPH_IN_MIG, GPH_OUT_MIG, GPH_MIG_BAND_START, GPH_MIG_BAND_END,
+       GPH_SAMPLES_START, GPH_END_CHAIN, GPH_DUMMY };
+
+// model parameters read by the kernels: passed BY VALUE as a kernel argument so
+// that every access is a scalar (SGPR) load from the kernarg segment.
+struct GphModel {
+  double theta[GPH_MAXK], popAge[GPH_MAXK], sampleAge[GPH_MAXK];
+  double migRate[GPH_MAXB], bandStart[GPH_MAXB], bandEnd[GPH_MAXB];
+  uint32_t isAnc[GPH_MAXK];            // bit d of isAnc[a]: a is ancestral to (or is) d
+  int16_t popFather[GPH_MAXK], popSon0[GPH_MAXK], popSon1[GPH_MAXK], samplesPerPop[GPH_MAXK];
+  int16_t bandSrc[GPH_MAXB], bandTgt[GPH_MAXB];
+  int16_t postOrder[GPH_MAXK];         // populationPostOrder(rootPop), patch.c:1936
+  int32_t cumSamples[GPH_MAXK];
+};
+
+// byte offsets of every array inside a locus page (uniform over loci)
+struct GphLayout {
+  int32_t n, N, K, Kc, B, E, RB, rootPop;
+  // f64
+  int32_t o_age, o_sv_age, o_ev_time, o_mig_age, o_coal, o_migst, o_rb_age, o_fscal;
+  // i16
+  int32_t o_father, o_left, o_right, o_npop, o_nev, o_sv_father, o_sv_left, o_sv_right;
+  int32_t o_changed, o_changedc;
+  int32_t o_ev_next, o_ev_prev, o_ev_node, o_ev_nlin, o_first;
+  int32_t o_mig_i, o_living, o_ncoal, o_nmig, o_rb_i;
+  // i32
+  int32_t o_iscal;
+  // u8
+  int32_t o_ev_type, o_condbit, o_dirty;
+  int32_t page_bytes;      // multiple of 16
+  int32_t scratch_bytes;   // LDS-only per-wave scratch (pending-proposal storage)
+  int32_t Pmax;            // max phased patterns of any locus on this device
+  int32_t lds_bytes;       // page + scratch + cond + seq, multiple of 16
+  int32_t o_scratch, o_cond, o_seq;  // LDS offsets
+  // LDS-only scratch (absolute LDS byte offsets): pending-proposal storage of
+  // GENETREE_STATS_DELTA x2 (patch.h:60-72), MIG_SPR_STATS (patch.h:97-105),
+  // genetree_stats_check (patch.h:109), pruning work lists
+  int32_t s_dev[2], s_dcoal[2], s_dmig[2], s_dpops[2], s_dbands[2], s_di[2];
+  int32_t s_sprf, s_spri16, s_spri;
+  int32_t s_ord, s_stack, s_terms, s_targets;
+  int32_t s_chkcoal, s_chkmig, s_chknc, s_chknm;
+  int32_t s_cnt, s_cntf;
+  // seq region (absolute LDS byte offsets): leaf codes u8[P][n], phases u8[P], counts i32[P]
+  int32_t q_leaf, q_phases, q_count;
+};
+// delta scalars (s_di[inst])
+enum { DI_ORIG = 0, DI_UPD, DI_DLIN, DI_NEV, DI_NPOPS, DI_NBANDS, DI_COUNT };
+// spr scalars (s_spri), i16 arrays (s_spri16 + 10*k), f64 (s_sprf: new_ages[0..9], dlnLd[10..11])
+enum { SI_FEV_OLD = 0, SI_FEV_NEW, SI_FPOP_NEW, SI_TARGET, SI_NOLD, SI_NNEW, SI_COUNT };
+enum { SA_OLD = 0, SA_NEWIN, SA_NEWOUT, SA_NEWBAND };
+// counters (s_cnt i32): evals, evalNodes, error, P, U ; (s_cntf f64): evalBytes
+enum { CN_EVALS = 0, CN_NODES, CN_ERROR, CN_P, CN_NOTENOUGH, CN_COUNT };
+
+// f64 scalars in the page (index into o_fscal)
+enum { FS_DATALNL = 0, FS_SV_DATALNL, FS_GENLNL, FS_GENDELTA, FS_MUTRATE, FS_COUNT };
+// i32 scalars in the page (index into o_iscal)
+enum { IS_ROOT = 0, IS_SV_ROOT, IS_COPYALL, IS_NCHANGED, IS_NCHANGEDC, IS_FREE, IS_NUM_MIGS,
+       IS_RB_NUM, IS_CONFLICT_LOG, IS_RX, IS_RY, IS_RZ, IS_COUNT };
+// i16 fields per migration node (o_mig_i + 6*mig)
+enum { MG_BRANCH = 0, MG_BAND, MG_SPOP, MG_TPOP, MG_SEV, MG_TEV, MG_COUNT };
+
+// per-locus outputs of a kernel launch (reduced over loci afterwards)
+#define GPH_OUT_SLOTS 16
+enum { OUT_ACCEPT = 0, OUT_DDATA, OUT_DLOG, OUT_EVALS, OUT_EVALNODES, OUT_EVALBYTES,
+       OUT_NTJ0, OUT_NTJ1, OUT_CONFLICT, OUT_ERROR, OUT_GENLNL, OUT_DATALNL, OUT_NMIGS };
+
+// arguments of the tau-evaluate kernel (host part of UpdateTau, GPhoCS.c:3224-3461)
+struct GphTauArgs {
+  int32_t ap, son0, son1, isRoot, num_aff;
+  double tauold, taunew, taub0, taub1, taufactor0, taufactor1;
+  int16_t aff_bands[GPH_MAXB * 2];
+  int16_t start_or_end[GPH_MAXB * 2];
+  double new_band_ages[GPH_MAXB * 2];
+};

@@ -1,0 +1,164 @@
+/*
+ * gphocs_hip.h -- C ABI of libgphocs_hip.so, the MI355X-native per-locus likelihood
+ * engine for G-PhoCS-style MCMC (drop-in for the reference's per-locus hot path).
+ *
+ * The reference has no plugin/FFI layer: the seam is the set of plain C entry points
+ * performMCMC() calls (upstream src/GPhoCS.h:84-100) operating on process-wide
+ * globals.  This ABI exports the same granularity -- batched over loci, an opaque
+ * handle instead of globals, an int status instead of exit(-1):
+ *
+ *   reference (file:line)                              this library
+ *   ------------------------------------------------   --------------------------------
+ *   processAlignments/createLocusData/initializeLocusData
+ *     GPhoCS.c:260-438, LocusDataLikelihood.c:142,239   gph_engine_load_loci
+ *   GetMem  patch.c:28                                  gph_engine_create
+ *   initRandomGenerator  utils.c:411                    gph_engine_seed
+ *   initializeMCMC per-locus loop  GPhoCS.c:1197-1214   gph_engine_init_genealogies
+ *   UpdateGB_InternalNode  GPhoCS.c:2287   \
+ *   UpdateGB_MigrationNode GPhoCS.c:2439    }           gph_engine_genealogy_sweep
+ *   UpdateGB_MigSPR        GPhoCS.c:2598   /
+ *   UpdateTau loop 1       GPhoCS.c:3491-3833           gph_engine_tau_evaluate
+ *   UpdateTau loop 2       GPhoCS.c:3885-3936           gph_engine_tau_commit
+ *   UpdateTau loops 3/4    GPhoCS.c:3965-3989           gph_engine_tau_revert
+ *   mixing loops           GPhoCS.c:4793-4801,4818-4848 gph_engine_mixing_evaluate/_commit
+ *   UpdateTheta/UpdateMigRates per-locus touch-ups
+ *     GPhoCS.c:3084-3093, 3192-3200                     gph_engine_apply_theta/_migrate
+ *   computeTotalStats  patch.c:2134                     gph_engine_get_totals
+ *   synchronizeEvents  patch.c:3548                     gph_engine_synchronize
+ *   checkAll           patch.c:2745                     gph_engine_check_all
+ *   performMCMC iteration body GPhoCS.c:1476-1821       gph_mcmc_iteration (host driver)
+ *
+ * All pointers are plain host pointers unless named *_dev.  Every function returns 0
+ * on success or a negative GPH_E* code; the HIP path is the only path -- there is no
+ * CPU fallback, and creation fails loudly when no gfx950 device is usable.
+ * Not re-entrant per handle (as the reference: called serially from one thread).
+ */
+#ifndef GPHOCS_HIP_H
+#define GPHOCS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPH_OK 0
+#define GPH_EARG (-1)      /* bad argument / unsupported size */
+#define GPH_EHIP (-2)      /* HIP runtime failure (no device, OOM, launch error) */
+#define GPH_EKERNEL (-3)   /* a locus reported a fatal consistency error (reference: "Fatal Error NNNN") */
+#define GPH_ESTATE (-4)    /* call out of order */
+
+typedef struct gph_engine gph_engine;
+typedef struct gph_mcmc gph_mcmc;
+
+typedef struct {
+  int32_t n;              /* haploid leaves per locus (dataSetup.numSamples) */
+  int32_t Kc, K, B;       /* current pops, all pops, migration bands */
+  int32_t rootPop;
+  const int32_t *samplesPerPop;                 /* [Kc] haploid leaves per current pop */
+  const int32_t *popFather, *popSon0, *popSon1; /* [K], -1 = none */
+  const int32_t *bandSrc, *bandTgt;             /* [B] */
+  int32_t device;         /* HIP device ordinal */
+  int64_t L_total;        /* loci over all ranks (dataSetup.numLoci) */
+  int64_t locus_begin;    /* global index of this rank's first locus */
+} gph_config;
+
+/* cross-rank reduction hook (one process per GPU): sums[0..nsum) are summed, mins[0..nmin)
+ * minimised, in place, over all ranks.  NULL = single rank. */
+typedef int (*gph_allreduce_fn)(void *user, double *sums, int32_t nsum, double *mins, int32_t nmin);
+
+typedef struct {
+  int64_t accepted_internal, accepted_mignode, accepted_spr;
+  double dData_internal, dLog_internal, dLog_mignode, dData_spr, dLog_spr;
+  int64_t total_mig_nodes;    /* sum of num_migs after the migration-node sweep (GPhoCS.c:1517-1520) */
+} gph_sweep_result;
+
+typedef struct {
+  int32_t ap, son0, son1, isRoot, num_aff;
+  double tauold, taunew, taub0, taub1, taufactor0, taufactor1;
+  int32_t aff_bands[32];
+  int32_t start_or_end[32];
+  double new_band_ages[32];
+} gph_tau_args;
+
+typedef struct {
+  int64_t ntj0, ntj1;
+  int64_t first_conflict_locus;   /* global locus index, -1 = no migration conflict */
+  double genDelta, dataDelta;
+} gph_tau_result;
+
+typedef struct {
+  int64_t evals;          /* computeLocusDataLikelihood(useOld=1)-equivalents since last reset */
+  int64_t eval_nodes;     /* recomputed internal nodes (R) */
+  double eval_bytes;      /* algorithmic bytes 96*R*P + 20*N + 8*U + 8 per evaluation */
+  int64_t not_enough_migs;
+} gph_counters;
+
+int gph_engine_create(const gph_config *cfg, gph_engine **out);
+void gph_engine_destroy(gph_engine *e);
+int gph_engine_set_allreduce(gph_engine *e, gph_allreduce_fn fn, void *user);
+/* leafcodes: [Ptot][n] with 0..3 = T,C,A,G and 4 = N; numPhases non-zero on the first phase
+ * of each unphased pattern; counts on the same rows; pattern_offsets[L+1] */
+int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *pattern_offsets, const uint8_t *leafcodes,
+                         const uint8_t *numPhases, const int32_t *counts, const double *mutRates);
+int gph_engine_set_model(gph_engine *e, const double *theta, const double *popAge, const double *sampleAge,
+                         const double *migRate, const double *bandStart, const double *bandEnd);
+int gph_engine_seed(gph_engine *e, uint32_t seed);
+int gph_engine_init_genealogies(gph_engine *e, double *sumGenLnL, double *sumDataLnL);
+/* flags: 1 = internal-node ages, 2 = migration-node ages, 4 = SPR; fused in one launch */
+int gph_engine_genealogy_sweep(gph_engine *e, int32_t flags, double finetuneCoalTime, double finetuneMigTime,
+                               gph_sweep_result *out);
+int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result *out);
+int gph_engine_tau_commit(gph_engine *e);
+int gph_engine_tau_revert(gph_engine *e, int64_t first_conflict_locus);
+int gph_engine_mixing_evaluate(gph_engine *e, double c, double *dataDelta);
+int gph_engine_mixing_commit(gph_engine *e, double c, double lnc);
+int gph_engine_mixing_revert(gph_engine *e);
+int gph_engine_apply_theta(gph_engine *e, int32_t pop, double lnc, double thetaold, double thetanew);
+int gph_engine_apply_migrate(gph_engine *e, int32_t band, double lnc, double old_rate, double new_rate);
+/* sums over ALL ranks; num_* returned as doubles holding exact integers */
+int gph_engine_get_totals(gph_engine *e, double *coal_stats, double *num_coals, double *mig_stats,
+                          double *num_migs);
+int gph_engine_synchronize(gph_engine *e, int32_t refresh_genealogy_lnl, double *sumOldGenLnL,
+                           double *sumNewGenLnL);
+int gph_engine_check_all(gph_engine *e, int32_t *ok, double *sumDataLnL, double *sumGenLnL);
+int gph_engine_get_counters(gph_engine *e, gph_counters *out, int32_t reset);
+/* debug / parity: canonical text dump of every local locus (same format as the oracle's) */
+int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditionals, int32_t append);
+/* timing of the last launch of a named kernel class, measured with HIP events on the
+ * engine's own stream: which = 0 sweep, 1 tau_eval, 2 mix_eval, 3 init, 4 check */
+int gph_engine_last_kernel_ms(gph_engine *e, int32_t which, double *ms);
+int64_t gph_engine_num_loci(gph_engine *e);
+int gph_engine_hbm_bytes(gph_engine *e, double *bytes);
+
+/* ------------------------------------------------------------------------------------
+ * host MCMC driver: the iteration body of performMCMC (GPhoCS.c:1476-1821) above the
+ * engine: general-slot RNG, priors, accept decisions of the global proposals
+ * (UpdateTheta GPhoCS.c:3037, UpdateMigRates :3115, UpdateTau :3224 host part,
+ * mixing :4688 host part), accumulators dataState.{logLikelihood,dataLogLikelihood}. */
+typedef struct {
+  const double *thetaAlpha, *thetaBeta, *thetaStart;   /* [K] */
+  const double *ageAlpha, *ageBeta, *ageStart;         /* [K] (ancestral pops) */
+  const double *sampleAge;                             /* [K] */
+  const double *mrAlpha, *mrBeta;                      /* [B] */
+  double ftCoalTime, ftMigTime, ftTheta, ftMigRate, ftMixing;
+  const double *ftTaus;                                /* [K] */
+  int32_t seed, startMig, doMixing, samplesPerLog;
+  int32_t numParameters;
+  const double *printFactors;                          /* [numParameters] */
+} gph_mcmc_config;
+
+int gph_mcmc_create(gph_engine *e, const gph_config *cfg, const gph_mcmc_config *mc, gph_mcmc **out);
+void gph_mcmc_destroy(gph_mcmc *m);
+int gph_mcmc_initialize(gph_mcmc *m, int64_t *totalCoals);
+/* optional record file: one "IT <iter> <proposal> <accepted> <dataLnL %a> <logL %a>" line per
+ * proposal call and one TRACE line per iteration (the unchanged trace-file row format) */
+int gph_mcmc_set_record_file(gph_mcmc *m, const char *path);
+int gph_mcmc_iteration(gph_mcmc *m, int32_t iteration);
+int gph_mcmc_get_state(gph_mcmc *m, double *logLikelihood, double *dataLogLikelihood, double *theta,
+                       double *popAge, double *migRate);
+int gph_mcmc_dump_state(gph_mcmc *m, const char *path, int32_t withConditionals);
+int gph_mcmc_accept_counts(gph_mcmc *m, int64_t *counts9);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,48 @@
+"""Debugging aid (tests only): run the product's per-locus code compiled for the HOST
+(GPH_HOSTEMU, 1-lane wave) on a pack and write the proposal records / state dump, so the
+engine's logic can be checked against the oracle in the GPU-less build container.
+Not a product path: libgphocs_hip.so contains no CPU code."""
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+import gphocs_amd as G  # noqa: E402
+
+HOSTEMU = os.path.join(REPO, "tests", "hostemu", "libgphocs_hostemu.so")
+
+
+def build_hostemu(sanitize=False):
+    csrc = os.path.join(REPO, "g-phocs_amd", "csrc")
+    srcs = [os.path.join(csrc, "gph_engine.hip"), os.path.join(csrc, "gph_mcmc.cpp")]
+    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+    if os.path.exists(HOSTEMU) and all(os.path.getmtime(HOSTEMU) >= os.path.getmtime(d) for d in deps):
+        return HOSTEMU
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU", "-ffp-contract=off", "-fPIC", "-shared",
+           "-x", "c++"] + srcs + ["-o", HOSTEMU]
+    if sanitize:
+        cmd[1:1] = ["-fsanitize=address,undefined"]
+    subprocess.run(cmd, check=True)
+    return HOSTEMU
+
+
+def run(pack_path, iters, trace, state=None, state_iter=None, with_cond=True, lib=None):
+    lib = lib or G.load_library(build_hostemu())
+    pk = G.Pack.load(pack_path)
+    s = G.Sampler(pk, lib=lib)
+    s.set_record_file(trace)
+    s.initialize()
+    if state and state_iter is not None and state_iter < 0:
+        s.dump_state(state, with_cond)
+    for it in range(iters):
+        s.iteration(it)
+        if state and state_iter == it:
+            s.dump_state(state, with_cond)
+    s.set_record_file(None)
+    s.close()
+
+
+if __name__ == "__main__":
+    a = sys.argv
+    run(a[1], int(a[2]), a[3], a[4] if len(a) > 4 else None, int(a[5]) if len(a) > 5 else int(a[2]) - 1)
