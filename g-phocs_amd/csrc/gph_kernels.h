@@ -29,8 +29,9 @@ GPH_DEV void copy16_g2l(int lds_off, const char *src, int bytes)
   memcpy(gph_sm + lds_off, src, bytes);
   (void)i; (void)n16;
 #else
-  const uint4 *s = (const uint4 *)src;
-  typedef GPH_LDS uint4 luint4;
+  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
+  typedef GPH_LDS gu32x4 luint4;
+  const gu32x4 *s = (const gu32x4 *)src;
   luint4 *d = (luint4 *)(GPH_SMB + lds_off);
   for (i = GPH_LANE; i < n16; i += GPH_NLANES) d[i] = s[i];
 #endif
@@ -42,8 +43,9 @@ GPH_DEV void copy16_l2g(char *dst, int lds_off, int bytes)
   memcpy(dst, gph_sm + lds_off, bytes);
   (void)i; (void)n16;
 #else
-  uint4 *d = (uint4 *)dst;
-  typedef GPH_LDS uint4 luint4;
+  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
+  typedef GPH_LDS gu32x4 luint4;
+  gu32x4 *d = (gu32x4 *)dst;
   const luint4 *s = (const luint4 *)(GPH_SMB + lds_off);
   for (i = GPH_LANE; i < n16; i += GPH_NLANES) d[i] = s[i];
 #endif
@@ -66,9 +68,10 @@ GPH_DEV void cond_transfer(const GphDev &D, int g, int store, int mode)
     if (store) memcpy(base + off, gph_sm + g_lay.o_cond + off, 16);
     else memcpy(gph_sm + g_lay.o_cond + off, base + off, 16);
 #else
-    typedef GPH_LDS double2 ld2;
-    if (store) *(double2 *)(base + off) = *(ld2 *)(GPH_SMB + g_lay.o_cond + off);
-    else *(ld2 *)(GPH_SMB + g_lay.o_cond + off) = *(const double2 *)(base + off);
+    typedef double gf64x2 __attribute__((ext_vector_type(2)));
+    typedef GPH_LDS gf64x2 ld2;
+    if (store) *(gf64x2 *)(base + off) = *(ld2 *)(GPH_SMB + g_lay.o_cond + off);
+    else *(ld2 *)(GPH_SMB + g_lay.o_cond + off) = *(const gf64x2 *)(base + off);
 #endif
   }
 }

@@ -1,0 +1,71 @@
+"""Comparison helpers for the parity tests.
+
+Bar (BASELINE.json north_star): accept/reject counters bit-exact, fp64 log-likelihoods within
+1e-10 relative.  The HIP path uses the device's exp/log (<= 1 ulp from glibc's), and reduces
+per-locus partial sums with a fixed-shape tree, so doubles are compared with REL_TOL; every
+integer (counters, topology, event ids, lineage counts, RNG state) must be identical."""
+import math
+
+REL_TOL = 1e-10      # log-likelihoods / accumulators (north_star tolerance)
+STATE_TOL = 1e-9     # per-locus doubles (ages, elapsed times, statistics, conditionals)
+
+
+def _close(a, b, tol):
+    if a == b:
+        return True
+    return abs(a - b) <= tol * max(abs(a), abs(b), 1e-300) or abs(a - b) < 1e-300
+
+
+def compare_records(path_a, path_b, tol=REL_TOL):
+    """IT / CONFLICTS / TRACE lines: proposal name + accept count exact, accumulators within tol"""
+    A = open(path_a).read().splitlines()
+    B = open(path_b).read().splitlines()
+    assert len(A) == len(B), f"record count differs: {len(A)} vs {len(B)}"
+    worst = 0.0
+    for x, y in zip(A, B):
+        xs, ys = x.split(), y.split()
+        if xs[0] == "IT":
+            assert xs[:4] == ys[:4], f"accept counters differ:\n  {x}\n  {y}"
+            for u, v in zip(xs[4:], ys[4:]):
+                u, v = float.fromhex(u), float.fromhex(v)
+                assert _close(u, v, tol), f"accumulator differs beyond {tol}:\n  {x}\n  {y}"
+                worst = max(worst, abs(u - v) / max(abs(v), 1e-300))
+        elif xs[0] == "TRACE":
+            assert len(xs) == len(ys)
+            for u, v in zip(xs[1:], ys[1:]):
+                assert abs(float(u) - float(v)) <= 2e-5 * max(1.0, abs(float(v)) * 1e-3), f"trace row differs:\n  {x}\n  {y}"
+        else:
+            assert x == y, f"record differs:\n  {x}\n  {y}"
+    return worst
+
+
+def _tok_close(u, v, tol):
+    """compare one whitespace token that may be int, hexfloat or colon-joined mixture"""
+    if u == v:
+        return True
+    if ":" in u or ":" in v:
+        us, vs = u.split(":"), v.split(":")
+        return len(us) == len(vs) and all(_tok_close(a, b, tol) for a, b in zip(us, vs))
+    if "x" in u or "x" in v or "." in u or "." in v:
+        try:
+            return _close(float.fromhex(u), float.fromhex(v), tol)
+        except ValueError:
+            return False
+    return False  # integers must match exactly
+
+
+def compare_states(path_a, path_b, tol=STATE_TOL, skip_global=False):
+    """canonical state dumps: integers exact, doubles within tol"""
+    A = open(path_a).read().splitlines()
+    B = open(path_b).read().splitlines()
+    assert len(A) == len(B), f"state line count differs: {len(A)} vs {len(B)}"
+    for x, y in zip(A, B):
+        if x == y:
+            continue
+        xs, ys = x.split(), y.split()
+        assert len(xs) == len(ys), f"state line differs:\n  {x[:200]}\n  {y[:200]}"
+        if skip_global and xs[0] in ("GLOBAL", "TOTALS"):
+            continue
+        for u, v in zip(xs, ys):
+            assert _tok_close(u, v, tol), f"state differs ({u} vs {v}):\n  {x[:300]}\n  {y[:300]}"
+    return True
