@@ -84,7 +84,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_engine_mixing_revert", "gph_engine_apply_theta", "gph_engine_apply_migrate",
     "gph_engine_get_totals", "gph_engine_synchronize", "gph_engine_check_all",
     "gph_engine_get_counters", "gph_engine_dump_loci", "gph_engine_last_kernel_ms",
-    "gph_engine_num_loci", "gph_engine_hbm_bytes",
+    "gph_engine_num_loci", "gph_engine_hbm_bytes", "gph_debug_math",
     "gph_mcmc_create", "gph_mcmc_destroy", "gph_mcmc_initialize", "gph_mcmc_set_record_file",
     "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
 ]

@@ -113,6 +113,20 @@ __global__ void k_reduce_final(int ncols, const double *part, double *red)
 }
 #endif
 
+#ifndef GPH_HOSTEMU
+// parity probe: the device's exp/log (gph_math.h) and its native sqrt / divide / floor
+__global__ void k_debug_math(const double *x, const double *y, int n, double *o)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  o[i] = gph_exp(x[i]);
+  o[n + i] = gph_log(x[i]);
+  o[2 * n + i] = sqrt(fabs(x[i]));
+  o[3 * n + i] = x[i] / y[i];
+  o[4 * n + i] = floor(x[i]);
+}
+#endif
+
 // ---------------------------------------------------------------- engine object
 struct gph_engine {
   gph_config cfg;
@@ -686,6 +700,33 @@ int gph_engine_last_kernel_ms(gph_engine *e, int32_t which, double *ms)
 }
 
 int64_t gph_engine_num_loci(gph_engine *e) { return e ? e->L : 0; }
+
+// out[5n]: exp(x), log(x), sqrt(|x|), x/y, floor(x) evaluated ON THE DEVICE
+int gph_debug_math(const double *x, const double *y, int32_t n, double *out, int32_t device)
+{
+  if (!x || !y || !out || n <= 0) return GPH_EARG;
+#ifdef GPH_HOSTEMU
+  (void)device;
+  for (int i = 0; i < n; i++) {
+    out[i] = gph_exp(x[i]); out[n + i] = gph_log(x[i]); out[2 * n + i] = sqrt(fabs(x[i]));
+    out[3 * n + i] = x[i] / y[i]; out[4 * n + i] = floor(x[i]);
+  }
+  return 0;
+#else
+  double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipMalloc((void **)&dx, sizeof(double) * n));
+  HIPCHK(hipMalloc((void **)&dy, sizeof(double) * n));
+  HIPCHK(hipMalloc((void **)&dout, sizeof(double) * 5 * n));
+  HIPCHK(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dy, y, sizeof(double) * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dy, (int)n, dout);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, dout, sizeof(double) * 5 * n, hipMemcpyDeviceToHost));
+  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+  return 0;
+#endif
+}
 
 int gph_engine_hbm_bytes(gph_engine *e, double *bytes)
 {

@@ -148,7 +148,7 @@ GPH_DEV void random_gtree()
     T = g_model.popAge[pop];
     if (pop < g_lay.Kc) T = g_model.sampleAge[pop];
     for (; num > 1; num--, nextId++) {
-      t = -(g_model.theta[pop] / (num * (num - 1.))) * log(l_rndu());
+      t = -(g_model.theta[pop] / (num * (num - 1.))) * gph_log(l_rndu());
       T += t;
       if (pop != g_lay.rootPop && T > g_model.popAge[g_model.popFather[pop]]) break;
       choice = (int)(num * l_rndu());
@@ -230,7 +230,7 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune)
     dgen = consider_event_move(0, NEV(inode), pop, t, pop, tnew);
     lnacc = dgen + lnLd;
     if (gph_failed()) break;
-    if (lnacc >= 0 || l_rndu() < exp(lnacc)) {
+    if (lnacc >= 0 || l_rndu() < gph_exp(lnacc)) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
       dData += lnLd;
@@ -279,7 +279,7 @@ GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune)
     dgen += consider_event_move(1, ev_t, pop_t, t, pop_t, tnew);
     lnacc = dgen;
     if (gph_failed()) break;
-    if (lnacc >= 0 || l_rndu() < exp(lnacc)) {
+    if (lnacc >= 0 || l_rndu() < gph_exp(lnacc)) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
       dLog += dgen / D.Ltot;
@@ -313,7 +313,7 @@ GPH_DEV void sweep_spr(const GphDev &D, int g)
     lnLd += lik_compute(1);
     lnacc = lnLd;
     if (gph_failed()) break;
-    if (res >= 0 && (lnacc >= 0 || l_rndu() < exp(lnacc))) {
+    if (res >= 0 && (lnacc >= 0 || l_rndu() < gph_exp(lnacc))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + (SPRLN(1) - SPRLN(0)));
       dData += lnLd;

@@ -143,7 +143,7 @@ GPH_DEV double l_rndnormal()
     s = u * u + v * v;
     if (s > 0 && s < 1) break;
   }
-  s = sqrt(-2. * log(s) / s);
+  s = sqrt(-2. * gph_log(s) / s);
   return u * s;
 }
 // rnd2normal8, utils.c:482-488 (kernel constants utils.c:427-431)
@@ -265,7 +265,7 @@ GPH_DEV void lik_revert()
 GPH_DEV double edge_prob(double len)
 {
   if (len < 1e-100) return 0.0;
-  return ((1 - exp(-4 * len / 3.0)) / 4.0);
+  return ((1 - gph_exp(-4 * len / 3.0)) / 4.0);
 }
 
 // LDS byte offset of the conditional array (buffer `bit`) of internal node `node`
@@ -380,7 +380,7 @@ GPH_DEVNI double lik_compute(int useOld)
   }
   setCNT(CN_NODES, CNT(CN_NODES) + nord);
   /* root reduction, LocusDataLikelihood.c:466-479: per unphased pattern
-   * log(sum over phases and bases / (4*phases)) * count, summed in pattern order */
+   * gph_log(sum over phases and bases / (4*phases)) * count, summed in pattern order */
   {
     int ro = cond_off(ISC(IS_ROOT), CBIT(ISC(IS_ROOT)));
     int p;
@@ -390,7 +390,7 @@ GPH_DEVNI double lik_compute(int useOld)
         int nc = 4 * ph, c;
         double prob = 0.0;
         for (c = 0; c < nc; c++) prob += gf64(ro, p * 4 + c);
-        sf64(g_lay.s_terms, p, log(prob / nc) * gi32v(g_lay.q_count, p));
+        sf64(g_lay.s_terms, p, gph_log(prob / nc) * gi32v(g_lay.q_count, p));
       }
     }
     GPH_SYNC();
@@ -623,11 +623,11 @@ GPH_DEV double gtree_lnl()
   double lnLd = 0, theta, rate;
   for (pop = 0; pop < g_lay.K; pop++) {
     theta = g_model.theta[pop];
-    lnLd += NCOAL(pop) * log(2 / theta) - COALS(pop) / (theta);
+    lnLd += NCOAL(pop) * gph_log(2 / theta) - COALS(pop) / (theta);
   }
   for (b = 0; b < g_lay.B; b++) {
     rate = g_model.migRate[b];
-    if (rate > 0.0) lnLd += NMIGB(b) * log(rate) - MIGST(b) * rate;
+    if (rate > 0.0) lnLd += NMIGB(b) * gph_log(rate) - MIGST(b) * rate;
   }
   return lnLd;
 }
@@ -776,7 +776,7 @@ GPH_DEVNI double consider_event_move(int inst, int event_id, int source_pop, dou
   mig_stats_delta(inst, bottom_age, bottom_pop, top_age, dlin);
   r = delta_lnld(inst);
   if (ETYPE(event_id) == GPH_COAL && source_pop != target_pop)
-    r += log(g_model.theta[source_pop] / g_model.theta[target_pop]);
+    r += gph_log(g_model.theta[source_pop] / g_model.theta[target_pop]);
   return r;
 }
 GPH_DEV void delta_clear(int inst)
@@ -1013,7 +1013,7 @@ GPH_DEVNI int trace_lineage(int node)
     } else {
       rate = mig_rate + 2 * ENLIN(ev) / theta;
       if (rate <= 0) t = EVT(ev);
-      else t = -(1 / rate) * log(l_rndu());
+      else t = -(1 / rate) * gph_log(l_rndu());
       if (t >= EVT(ev)) {
         t = EVT(ev);
         age += t;
@@ -1060,7 +1060,7 @@ GPH_DEVNI int trace_lineage(int node)
     nev++;
     lnld -= (mig_rate + 2 * ENLIN(ev) / theta) * t;
     if (mig_source >= 0) {
-      lnld += log(g_model.migRate[b]);
+      lnld += gph_log(g_model.migRate[b]);
       ev = mig_source;
       pop = g_model.bandSrc[b];
       theta = g_model.theta[pop];
@@ -1084,7 +1084,7 @@ GPH_DEVNI int trace_lineage(int node)
     }
     ev = ENEXT(ev);
   }
-  lnld += log(2 / theta);
+  lnld += gph_log(2 / theta);
   setDI(inst, DI_NEV, nev);
   setSPRLN(RECONNECT, lnld);
   return 0;

@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "gph_types.h"
+#include "gph_math.h"
 
 #ifdef GPH_HOSTEMU
 #include <string.h>

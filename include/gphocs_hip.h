@@ -127,6 +127,8 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditiona
  * engine's own stream: which = 0 sweep, 1 tau_eval, 2 mix_eval, 3 init, 4 check */
 int gph_engine_last_kernel_ms(gph_engine *e, int32_t which, double *ms);
 int64_t gph_engine_num_loci(gph_engine *e);
+/* parity probe: out[5n] = exp(x), log(x), sqrt(|x|), x/y, floor(x) evaluated on the device */
+int gph_debug_math(const double *x, const double *y, int32_t n, double *out5n, int32_t device);
 int gph_engine_hbm_bytes(gph_engine *e, double *bytes);
 
 /* ------------------------------------------------------------------------------------
