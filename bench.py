@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: full MCMC iterations of the per-locus likelihood engine.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+step      = one MCMC iteration of performMCMC's proposal sequence (GPhoCS.c:1476-1821) over every
+            locus: fused genealogy sweep (node ages, migration ages, SPR), theta, migration rates,
+            tau rubber bands, mixing, event synchronisation -- nothing skipped.
+workload  = BASELINE.json configs[3], the one the metric is quoted on: 100k loci x 1 kb, 8 diploid
+            samples (16 leaves), 5 current populations + 4 migration bands; synthetic data
+            (g-phocs_amd/synth.py), resident in HBM before the timed region.
+scaling   = weak: every rank holds --loci loci (default 100k); whole-job value = all ranks' units
+            / max-over-ranks time.  Ranks share nothing but the <= 240-byte all-reduce (RCCL) of
+            each global proposal.
+value     = locus-likelihood evaluations per second (computeLocusDataLikelihood(useOld=1)
+            equivalents, counted by the kernels); MCMC iterations/s is reported next to it.
+roofline  = dominant kernel (fused genealogy sweep): algorithmic bytes (96*R*P + 20*N + 8*U + 8 per
+            evaluation, counted per evaluation by the kernel) / HIP-event duration, vs 8 TB/s HBM.
+cpu_baseline = the oracle restatement (bit-identical to the reference on the golden vectors) timed
+            single-threaded on a bounded sample (first --cpu-loci loci, a few iterations) on this
+            box's host cores -- rank 0, N = 1 only.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+
+def _gen_chunk(args):
+    import gphocs_amd as G
+    config, n, seed, mut_scale = args
+    return G.make_synthetic_pack(G.Pack, config, n, mut_scale=mut_scale, data_seed=seed)
+
+
+def build_workload(G, config, L, mut_scale, seed0, cache_dir):
+    """L loci of the config's shape, generated in parallel chunks and cached as .npz"""
+    os.makedirs(cache_dir, exist_ok=True)
+    key = os.path.join(cache_dir, f"synth_c{config}_L{L}_m{mut_scale}_s{seed0}.npz")
+    base = G.Pack()
+    from gphocs_amd_pkg import synth
+    synth.make_model(base, config)
+    if os.path.exists(key):
+        z = np.load(key)
+        base.pattern_offsets, base.leafcodes = z["offs"], z["leaf"]
+        base.numPhases, base.counts = z["phases"], z["counts"]
+    else:
+        chunk = 4000
+        jobs = [(config, min(chunk, L - i), seed0 + 1000 + i // chunk, mut_scale) for i in range(0, L, chunk)]
+        nproc = min(len(jobs), max(1, (os.cpu_count() or 2) - 1), 16)
+        if nproc > 1:
+            with mp.get_context("fork").Pool(nproc) as pool:
+                parts = pool.map(_gen_chunk, jobs)
+        else:
+            parts = [_gen_chunk(j) for j in jobs]
+        offs = [0]
+        for p in parts:
+            offs.extend((p.pattern_offsets[1:] + offs[-1]).tolist())
+        base.pattern_offsets = np.array(offs, np.int64)
+        base.leafcodes = np.concatenate([p.leafcodes for p in parts])
+        base.numPhases = np.concatenate([p.numPhases for p in parts])
+        base.counts = np.concatenate([p.counts for p in parts])
+        try:
+            np.savez(key, offs=base.pattern_offsets, leaf=base.leafcodes, phases=base.numPhases, counts=base.counts)
+        except OSError:
+            pass
+    base.L = base.numLoci = L
+    base.mutRates = np.ones(L)
+    return base
+
+
+def cpu_baseline(G, pack, nloci, iters):
+    """oracle restatement, single thread, bounded sample of the same workload"""
+    from gphocs_amd_pkg import synth
+    exe = os.path.join(REPO, "oracle", "gphocs_oracle")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "oracle"], check=True, capture_output=True)
+    sub = G.Pack()
+    sub.__dict__.update(pack.__dict__)
+    sub.L = sub.numLoci = nloci
+    o1 = int(pack.pattern_offsets[nloci])
+    sub.pattern_offsets = pack.pattern_offsets[:nloci + 1]
+    sub.leafcodes, sub.numPhases, sub.counts = pack.leafcodes[:o1], pack.numPhases[:o1], pack.counts[:o1]
+    sub.mutRates = np.ones(nloci)
+    with tempfile.TemporaryDirectory() as td:
+        pth = os.path.join(td, "sample.gpk")
+        synth.write_pack(sub, pth)
+        out = subprocess.run([exe, "time", pth, str(iters), "2"], check=True, capture_output=True, text=True,
+                             timeout=600).stdout
+    r = json.loads(out)
+    return {"value": r["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"first {nloci} loci of the workload, {iters} iterations after 2 warm-up "
+                      f"({r['seconds']:.1f} s); {r['iters_per_s'] * nloci:.0f} locus-iterations/s",
+            "iters_per_s_at_sample": r["iters_per_s"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--loci", type=int, default=100000, help="loci per GPU")
+    ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--mut-scale", type=float, default=6.5, help="mutation scale of the synthetic data (P ~ 18)")
+    ap.add_argument("--cpu-loci", type=int, default=5000)
+    ap.add_argument("--cpu-iters", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import gphocs_amd as G
+    G.build()
+    torch.cuda.set_device(local_rank)
+    dist = None
+    allreduce = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        dev = torch.device("cuda", local_rank)
+
+        def allreduce(sums, mins):
+            # <= 240-byte payloads: one RCCL all-reduce (sum) + one (min) per global proposal
+            if sums.size:
+                t = torch.from_numpy(sums.copy()).to(dev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                sums[:] = t.cpu().numpy()
+            if mins.size:
+                t = torch.from_numpy(mins.copy()).to(dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                mins[:] = t.cpu().numpy()
+
+    L_total = a.loci * world
+    pack = build_workload(G, a.config, L_total, a.mut_scale, 20261002 + a.config,
+                          os.path.join(REPO, "bench_cache"))
+    P = np.diff(pack.pattern_offsets)
+    s = G.Sampler(pack, device=local_rank, rank=rank, world=world, allreduce=allreduce)
+    s.initialize()
+    for it in range(a.warmup):
+        s.iteration(it)
+    s.counters(reset=True)
+    for k in range(16):
+        s.class_stats(k, reset=True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(a.warmup, a.warmup + a.steps):
+        s.iteration(it)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    cnt = s.counters()
+    sweep = s.class_stats(0)
+    evals, tmax = float(cnt["evals"]), dt
+    if dist:
+        t = torch.tensor([evals], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        evals = float(t.item())
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+    if rank == 0:
+        kern = {}
+        names = {0: "sweep", 1: "tau_eval", 2: "mix_eval", 4: "check", 5: "tau_commit", 6: "tau_revert",
+                 7: "mix_commit", 8: "sync"}
+        for k, nm in names.items():
+            st = s.class_stats(k)
+            if st["launches"]:
+                kern[nm] = {"launches": int(st["launches"]), "avg_ms": st["ms"] / st["launches"]}
+        ach = (sweep["bytes"] / max(sweep["launches"], 1)) / (sweep["ms"] / max(sweep["launches"], 1) * 1e-3) / 1e9 \
+            if sweep["ms"] > 0 else 0.0
+        line = {
+            "metric": "locus-likelihood evals/sec (+ MCMC iters/sec), 100k loci per MI355X",
+            "value": evals / tmax, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": tmax / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "mcmc_iters_per_sec": a.steps / tmax,
+            "config": {"workload": f"BASELINE configs[3]: {a.loci} loci/GPU x 1 kb, 8 diploid samples (16 leaves), "
+                                   f"5 current pops + 4 migration bands, full MCMC iteration",
+                       "loci_total": L_total, "leaves": int(pack.n), "pops": int(pack.K), "bands": int(pack.B),
+                       "mean_phased_patterns": float(P.mean()), "max_phased_patterns": int(P.max()),
+                       "evals_per_locus_iter": evals / (L_total * a.steps),
+                       "recomputed_nodes_per_eval": cnt["eval_nodes"] / max(cnt["evals"], 1),
+                       "algorithmic_bytes_per_eval": cnt["eval_bytes"] / max(cnt["evals"], 1),
+                       "parallelism": f"loci sharded over {world} rank(s), one process per GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_sweep (fused UpdateGB_InternalNode+MigrationNode+MigSPR)",
+                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "avg_launch_ms": sweep["ms"] / max(sweep["launches"], 1),
+                         "algorithmic_bytes_per_launch": sweep["bytes"] / max(sweep["launches"], 1),
+                         "evals_per_launch": sweep["evals"] / max(sweep["launches"], 1)},
+            "kernels": kern,
+            "hbm_resident_bytes": s.hbm_bytes(),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(G, pack, min(a.cpu_loci, L_total), a.cpu_iters)
+            except Exception as ex:  # pragma: no cover
+                line["cpu_baseline"] = {"error": str(ex)}
+        print(json.dumps(line), flush=True)
+    s.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,8 @@ import subprocess
 
 import numpy as np
 
+from .synth import make_synthetic_pack, replicate_pack, write_pack  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libgphocs_hip.so")
@@ -84,7 +86,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_engine_mixing_revert", "gph_engine_apply_theta", "gph_engine_apply_migrate",
     "gph_engine_get_totals", "gph_engine_synchronize", "gph_engine_check_all",
     "gph_engine_get_counters", "gph_engine_dump_loci", "gph_engine_last_kernel_ms",
-    "gph_engine_num_loci", "gph_engine_hbm_bytes", "gph_debug_math",
+    "gph_engine_num_loci", "gph_engine_hbm_bytes", "gph_debug_math", "gph_engine_class_stats",
     "gph_mcmc_create", "gph_mcmc_destroy", "gph_mcmc_initialize", "gph_mcmc_set_record_file",
     "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
 ]
@@ -313,6 +315,11 @@ class Sampler:
         ms = C.c_double()
         self._chk(self.lib.gph_engine_last_kernel_ms(self.engine, which, C.byref(ms)), "kernel_ms")
         return ms.value
+
+    def class_stats(self, which, reset=False):
+        o = (C.c_double * 5)()
+        self._chk(self.lib.gph_engine_class_stats(self.engine, which, o, int(reset)), "class_stats")
+        return dict(launches=o[0], ms=o[1], evals=o[2], bytes=o[3], nodes=o[4])
 
     def hbm_bytes(self):
         b = C.c_double()

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "gph_kernels.h"
 #include "../../include/gphocs_hip.h"
 
@@ -26,15 +27,16 @@ __constant__ GphModel g_model;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "gphocs_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return GPH_EHIP; } } while (0)
 #endif
 
-GPH_KERNEL(k_init, GphDev D, uint32_t seedz, const double *mutRate) { kb_init(D, GPH_BLK, seedz, mutRate ? mutRate[GPH_BLK] : 1.0); }
-GPH_KERNEL(k_sweep, GphDev D, int flags, double ftCoal, double ftMig) { kb_sweep(D, GPH_BLK, flags, ftCoal, ftMig); }
-GPH_KERNEL(k_tau_eval, GphDev D, GphTauArgs A) { kb_tau_eval(D, GPH_BLK, A); }
-GPH_KERNEL(k_tau_commit, GphDev D, GphTauArgs A) { kb_tau_commit(D, GPH_BLK, A); }
-GPH_KERNEL(k_tau_revert, GphDev D, int limit) { kb_tau_revert(D, GPH_BLK, limit); }
-GPH_KERNEL(k_mix_eval, GphDev D, double c) { kb_mix_eval(D, GPH_BLK, c); }
-GPH_KERNEL(k_mix_commit, GphDev D, double c, double lnc) { kb_mix_commit(D, GPH_BLK, c, lnc); }
-GPH_KERNEL(k_sync, GphDev D, int refresh) { kb_sync(D, GPH_BLK, refresh); }
-GPH_KERNEL(k_check, GphDev D) { kb_check(D, GPH_BLK); }
+// j0 = first slot of the bucket being launched (see GphDev)
+GPH_KERNEL(k_init, GphDev D, int j0, uint32_t seedz, const double *mutRate) { kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0); }
+GPH_KERNEL(k_sweep, GphDev D, int j0, int flags, double ftCoal, double ftMig) { kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
+GPH_KERNEL(k_tau_eval, GphDev D, int j0, GphTauArgs A) { kb_tau_eval(D, j0 + GPH_BLK, A); }
+GPH_KERNEL(k_tau_commit, GphDev D, int j0, GphTauArgs A) { kb_tau_commit(D, j0 + GPH_BLK, A); }
+GPH_KERNEL(k_tau_revert, GphDev D, int j0, long long limit) { kb_tau_revert(D, j0 + GPH_BLK, limit); }
+GPH_KERNEL(k_mix_eval, GphDev D, int j0, double c) { kb_mix_eval(D, j0 + GPH_BLK, c); }
+GPH_KERNEL(k_mix_commit, GphDev D, int j0, double c, double lnc) { kb_mix_commit(D, j0 + GPH_BLK, c, lnc); }
+GPH_KERNEL(k_sync, GphDev D, int j0, int refresh) { kb_sync(D, j0 + GPH_BLK, refresh); }
+GPH_KERNEL(k_check, GphDev D, int j0, int unused) { (void)unused; kb_check(D, j0 + GPH_BLK); }
 
 // ---------------------------------------------------------------- small elementwise / reduction kernels
 #define GPH_RED_BLOCKS 256
@@ -136,9 +138,12 @@ struct gph_engine {
   GphDev dev;
   GphTauArgs tau;          // args of the pending tau proposal
   int64_t L = 0;
-  size_t cond_bytes = 0, pages_bytes = 0;
+  size_t cond_bytes = 0, pages_bytes = 0, seq_bytes_total = 0;
   std::vector<uint64_t> h_cond_off;
-  std::vector<int32_t> h_P;
+  std::vector<int32_t> h_P;          // per slot (sorted order)
+  std::vector<int32_t> h_orig;       // slot -> original local index
+  struct Bucket { int j0, count; GphLayout lay; };
+  std::vector<Bucket> buckets;
   double *d_mutRate = nullptr;
   double *d_part = nullptr, *d_red = nullptr;
   double h_red[3 * GPH_RED_COLS];
@@ -147,7 +152,10 @@ struct gph_engine {
   uint32_t seedz = 0;
   bool loaded = false, seeded = false, model_set = false, initialized = false;
   gph_counters counters = {0, 0, 0.0, 0};
-  double last_ms[8] = {0};
+  double last_ms[16] = {0};
+  // per kernel class: launches, summed HIP-event ms, evaluations, algorithmic bytes
+  double cls_launches[16] = {0}, cls_ms[16] = {0}, cls_evals[16] = {0}, cls_bytes[16] = {0}, cls_nodes[16] = {0};
+  int last_which = 0;
 #ifndef GPH_HOSTEMU
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -247,8 +255,10 @@ static void dev_free(void *p) { free(p); }
 static int h2d(gph_engine *, void *d, const void *h, size_t n) { memcpy(d, h, n); return 0; }
 static int d2h(gph_engine *, void *h, const void *d, size_t n) { memcpy(h, d, n); return 0; }
 static int upload_tables(gph_engine *e) { g_lay = e->lay; g_model = e->model; return 0; }
-#define LAUNCH(e, which, name, ...) do { upload_tables(e); (e)->lds.assign((e)->lay.lds_bytes + 64, 0); \
-    gph_sm = (e)->lds.data(); for (int b_ = 0; b_ < (int)(e)->L; b_++) name(b_, __VA_ARGS__); } while (0)
+#define LAUNCH(e, which, name, ...) do { g_model = (e)->model; \
+    for (auto &bk_ : (e)->buckets) { g_lay = bk_.lay; (e)->lds.assign(bk_.lay.lds_bytes + 64, 0); gph_sm = (e)->lds.data(); \
+      for (int b_ = 0; b_ < bk_.count; b_++) name(b_, (e)->dev, bk_.j0, __VA_ARGS__); } g_lay = (e)->lay; \
+    (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
 #else
 static int dev_alloc(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess ? 0 : GPH_EHIP; }
 static void dev_free(void *p) { if (p) (void)hipFree(p); }
@@ -271,13 +281,18 @@ static int upload_tables(gph_engine *e)
   return 0;
 }
 // timed launch: HIP events on the engine's own stream bracket the kernel
-#define LAUNCH(e, which, name, ...) do { int rc_ = upload_tables(e); if (rc_) return rc_; \
+// one launch per P-bucket, each with its own LDS size and layout table
+#define LAUNCH(e, which, name, ...) do { \
+    HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_model), &(e)->model, sizeof(GphModel), 0, hipMemcpyHostToDevice, (e)->stream)); \
     HIPCHK(hipEventRecord((e)->ev0, (e)->stream)); \
-    hipLaunchKernelGGL(name, dim3((unsigned)(e)->L), dim3(GPH_WAVE), (e)->lay.lds_bytes, (e)->stream, __VA_ARGS__); \
-    HIPCHK(hipGetLastError()); \
+    for (auto &bk_ : (e)->buckets) { \
+      HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lay), &bk_.lay, sizeof(GphLayout), 0, hipMemcpyHostToDevice, (e)->stream)); \
+      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lay.lds_bytes, (e)->stream, (e)->dev, bk_.j0, __VA_ARGS__); \
+      HIPCHK(hipGetLastError()); } \
     HIPCHK(hipEventRecord((e)->ev1, (e)->stream)); \
     HIPCHK(hipEventSynchronize((e)->ev1)); \
-    float ms_ = 0; HIPCHK(hipEventElapsedTime(&ms_, (e)->ev0, (e)->ev1)); (e)->last_ms[which] = ms_; } while (0)
+    float ms_ = 0; HIPCHK(hipEventElapsedTime(&ms_, (e)->ev0, (e)->ev1)); (e)->last_ms[which] = ms_; \
+    (e)->last_which = (which); (e)->cls_launches[which] += 1; (e)->cls_ms[which] += ms_; } while (0)
 #endif
 
 // reduce the per-locus outputs (mode 0) or page statistics (mode 1) over local loci
@@ -321,6 +336,9 @@ static int finish_kernel(gph_engine *e)
   e->counters.eval_nodes += (int64_t)RSUM(e, 9);
   e->counters.eval_bytes += RSUM(e, 10);
   e->counters.not_enough_migs += (int64_t)RSUM(e, 13);
+  e->cls_evals[e->last_which] += RSUM(e, 8);
+  e->cls_nodes[e->last_which] += RSUM(e, 9);
+  e->cls_bytes[e->last_which] += RSUM(e, 10);
   if (RMAX(e, 11) != 0.0) {
     fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by a locus kernel\n", (int)RMAX(e, 11));
     return GPH_EKERNEL;
@@ -376,7 +394,7 @@ void gph_engine_destroy(gph_engine *e)
 {
   if (!e) return;
   dev_free(e->dev.pages); dev_free(e->dev.shadow); dev_free(e->dev.cond); dev_free((void *)e->dev.cond_off);
-  dev_free((void *)e->dev.seq); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->d_mutRate);
+  dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->d_mutRate);
   dev_free(e->d_part); dev_free(e->d_red);
 #ifndef GPH_HOSTEMU
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -407,29 +425,68 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
     return GPH_EARG;
   }
   e->L = L;
-  const int seq_bytes = e->lay.o_cond - e->lay.o_seq;
-  std::vector<char> seq((size_t)L * seq_bytes, 0);
+  // slots sorted by P (stable), then cut into buckets at fixed P caps
+  e->h_orig.resize(L);
+  for (int64_t g = 0; g < L; g++) e->h_orig[g] = (int32_t)g;
+  std::stable_sort(e->h_orig.begin(), e->h_orig.end(), [&](int32_t a, int32_t b) {
+    return (poff[a + 1] - poff[a]) < (poff[b + 1] - poff[b]); });
+  static const int caps[] = {4, 6, 8, 10, 12, 14, 16, 20, 24, 32, 48, 64, 96, 128, 1 << 30};
+  e->buckets.clear();
+  {
+    int64_t j = 0;
+    for (int ci = 0; j < L; ci++) {
+      int64_t j0 = j;
+      int pb = 0;
+      while (j < L && (poff[e->h_orig[j] + 1] - poff[e->h_orig[j]]) <= caps[ci]) { pb = (int)(poff[e->h_orig[j] + 1] - poff[e->h_orig[j]]); j++; }
+      if (j > j0) {
+        gph_engine::Bucket bk;
+        bk.j0 = (int)j0;
+        bk.count = (int)(j - j0);
+        build_layout(bk.lay, n, e->cfg.Kc, e->cfg.K, e->cfg.B, e->cfg.rootPop, pb);
+        e->buckets.push_back(bk);
+      }
+    }
+  }
   e->h_cond_off.resize(L + 1);
   e->h_P.resize(L);
-  uint64_t off = 0;
-  for (int64_t g = 0; g < L; g++) {
-    int P = (int)(poff[g + 1] - poff[g]);
-    e->h_P[g] = P;
-    e->h_cond_off[g] = off;
-    off += (uint64_t)2 * (n - 1) * P * 32;
-    char *blk = seq.data() + (size_t)g * seq_bytes;
-    for (int p = 0; p < P; p++) {
-      for (int i = 0; i < n; i++) {
-        uint8_t c = leafcodes[(size_t)(poff[g] + p) * n + i];
-        if (c > 4) return GPH_EARG;
-        blk[(e->lay.q_leaf - e->lay.o_seq) + p * n + i] = (char)c;
-      }
-      blk[(e->lay.q_phases - e->lay.o_seq) + p] = (char)numPhases[poff[g] + p];
-      ((int32_t *)(blk + (e->lay.q_count - e->lay.o_seq)))[p] = counts[poff[g] + p];
+  std::vector<uint64_t> seq_off(L + 1);
+  std::vector<double> rates(L, 1.0);
+  uint64_t off = 0, soff = 0;
+  for (auto &bk : e->buckets) {
+    const int sb = bk.lay.o_cond - bk.lay.o_seq;
+    for (int j = bk.j0; j < bk.j0 + bk.count; j++) {
+      int64_t g = e->h_orig[j];
+      int P = (int)(poff[g + 1] - poff[g]);
+      e->h_P[j] = P;
+      e->h_cond_off[j] = off;
+      off += (uint64_t)2 * (n - 1) * P * 32;
+      seq_off[j] = soff;
+      soff += sb;
+      if (mutRates) rates[j] = mutRates[g];
     }
   }
   e->h_cond_off[L] = off;
+  seq_off[L] = soff;
+  std::vector<char> seq(soff, 0);
+  for (auto &bk : e->buckets) {
+    const GphLayout &y = bk.lay;
+    for (int j = bk.j0; j < bk.j0 + bk.count; j++) {
+      int64_t g = e->h_orig[j];
+      int P = e->h_P[j];
+      char *blk = seq.data() + seq_off[j];
+      for (int p = 0; p < P; p++) {
+        for (int i = 0; i < n; i++) {
+          uint8_t c = leafcodes[(size_t)(poff[g] + p) * n + i];
+          if (c > 4) return GPH_EARG;
+          blk[(y.q_leaf - y.o_seq) + p * n + i] = (char)c;
+        }
+        blk[(y.q_phases - y.o_seq) + p] = (char)numPhases[poff[g] + p];
+        ((int32_t *)(blk + (y.q_count - y.o_seq)))[p] = counts[poff[g] + p];
+      }
+    }
+  }
   e->cond_bytes = off;
+  e->seq_bytes_total = soff;
   e->pages_bytes = (size_t)L * e->lay.page_bytes;
   int rc = 0;
   rc |= dev_alloc((void **)&e->dev.pages, e->pages_bytes);
@@ -437,7 +494,9 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   rc |= dev_alloc((void **)&e->dev.cond, e->cond_bytes);
   rc |= dev_alloc((void **)&e->dev.cond_off, sizeof(uint64_t) * (L + 1));
   rc |= dev_alloc((void **)&e->dev.seq, seq.size());
+  rc |= dev_alloc((void **)&e->dev.seq_off, sizeof(uint64_t) * (L + 1));
   rc |= dev_alloc((void **)&e->dev.P, sizeof(int32_t) * L);
+  rc |= dev_alloc((void **)&e->dev.orig, sizeof(int32_t) * L);
   rc |= dev_alloc((void **)&e->dev.out, sizeof(double) * GPH_OUT_SLOTS * L);
   rc |= dev_alloc((void **)&e->d_part, sizeof(double) * 3 * GPH_RED_BLOCKS * GPH_RED_COLS);
   rc |= dev_alloc((void **)&e->d_red, sizeof(double) * 3 * GPH_RED_COLS);
@@ -445,15 +504,17 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   if (rc) { fprintf(stderr, "gphocs_hip: device allocation failed\n"); return GPH_EHIP; }
   rc |= h2d(e, (void *)e->dev.cond_off, e->h_cond_off.data(), sizeof(uint64_t) * (L + 1));
   rc |= h2d(e, (void *)e->dev.seq, seq.data(), seq.size());
+  rc |= h2d(e, (void *)e->dev.seq_off, seq_off.data(), sizeof(uint64_t) * (L + 1));
   rc |= h2d(e, (void *)e->dev.P, e->h_P.data(), sizeof(int32_t) * L);
-  if (mutRates) rc |= h2d(e, e->d_mutRate, mutRates, sizeof(double) * L);
+  rc |= h2d(e, (void *)e->dev.orig, e->h_orig.data(), sizeof(int32_t) * L);
+  if (mutRates) rc |= h2d(e, e->d_mutRate, rates.data(), sizeof(double) * L);
   if (rc) return GPH_EHIP;
   e->dev.L = (int32_t)L;
   e->dev.Ltot = (int32_t)e->cfg.L_total;
-  e->dev.seq_bytes = seq_bytes;
+  e->dev.locus_begin = e->cfg.locus_begin;
   e->loaded = true;
 #ifndef GPH_HOSTEMU
-  // every per-locus kernel uses the same dynamic LDS size; allow > 64 KiB
+  // per-locus kernels use up to the largest bucket's dynamic LDS size; allow > 64 KiB
   const void *ks[] = {(const void *)k_init, (const void *)k_sweep, (const void *)k_tau_eval, (const void *)k_tau_commit,
                       (const void *)k_tau_revert, (const void *)k_mix_eval, (const void *)k_mix_commit,
                       (const void *)k_sync, (const void *)k_check};
@@ -483,7 +544,7 @@ int gph_engine_seed(gph_engine *e, uint32_t seed)
 int gph_engine_init_genealogies(gph_engine *e, double *sumGen, double *sumData)
 {
   if (!e || !e->loaded || !e->seeded || !e->model_set) return GPH_ESTATE;
-  LAUNCH(e, 3, k_init, e->dev, e->seedz, (const double *)e->d_mutRate);
+  LAUNCH(e, 3, k_init, e->seedz, (const double *)e->d_mutRate);
   int rc = finish_kernel(e);
   if (rc) return rc;
   double s[2] = {RSUM(e, 0), RSUM(e, 1)};
@@ -497,7 +558,7 @@ int gph_engine_init_genealogies(gph_engine *e, double *sumGen, double *sumData)
 int gph_engine_genealogy_sweep(gph_engine *e, int32_t flags, double ftCoal, double ftMig, gph_sweep_result *out)
 {
   if (!e || !e->initialized || !out) return GPH_ESTATE;
-  LAUNCH(e, 0, k_sweep, e->dev, (int)flags, ftCoal, ftMig);
+  LAUNCH(e, 0, k_sweep, (int)flags, ftCoal, ftMig);
   int rc = finish_kernel(e);
   if (rc) return rc;
   double s[9] = {RSUM(e, 0), RSUM(e, 1), RSUM(e, 2), RSUM(e, 3), RSUM(e, 4), RSUM(e, 5), RSUM(e, 6), RSUM(e, 7), RSUM(e, 12)};
@@ -528,20 +589,13 @@ int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result
     A.start_or_end[i] = (int16_t)a->start_or_end[i];
     A.new_band_ages[i] = a->new_band_ages[i];
   }
-  LAUNCH(e, 1, k_tau_eval, e->dev, A);
+  LAUNCH(e, 1, k_tau_eval, A);
   int rc = finish_kernel(e);
   if (rc) return rc;
-  // first conflicting locus in serial order: loci after it were never touched by the
-  // reference -- sums only count loci before it (they are unused then anyway)
-  int64_t first = -1;
-  if (RMAX(e, 2) > 0.0) {
-    std::vector<double> outv((size_t)e->L * GPH_OUT_SLOTS);
-    rc = d2h(e, outv.data(), e->dev.out, outv.size() * sizeof(double));
-    if (rc) return rc;
-    for (int64_t g = 0; g < e->L; g++) if (outv[(size_t)g * GPH_OUT_SLOTS + 2] > 0.0) { first = g; break; }
-  }
+  // first conflicting locus in serial (input) order: loci after it were never touched by
+  // the reference; slot 14 holds the global index of a conflicting locus
   double s[4] = {RSUM(e, 0), RSUM(e, 1), RSUM(e, 3), RSUM(e, 4)};
-  double mn[1] = {first >= 0 ? (double)(first + e->cfg.locus_begin) : 1e300};
+  double mn[1] = {RMAX(e, 2) > 0.0 ? RMIN(e, 14) : 1e300};
   rc = xreduce(e, s, 4, mn, 1);
   out->ntj0 = (int64_t)s[0];
   out->ntj1 = (int64_t)s[1];
@@ -554,32 +608,27 @@ int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result
 int gph_engine_tau_commit(gph_engine *e)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
-  LAUNCH(e, 5, k_tau_commit, e->dev, e->tau);
+  LAUNCH(e, 5, k_tau_commit, e->tau);
   return finish_kernel(e);
 }
 
 int gph_engine_tau_revert(gph_engine *e, int64_t first_conflict)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
-  int64_t limit = e->L;
-  if (first_conflict >= 0) {
-    limit = first_conflict - e->cfg.locus_begin;
-    if (limit < 0) limit = 0;
-    if (limit > e->L) limit = e->L;
-  }
+  long long limit = first_conflict >= 0 ? (long long)first_conflict : (long long)1 << 62;
 #ifdef GPH_HOSTEMU
   for (int64_t g = 0; g < e->L; g++) for (int k = 0; k < GPH_OUT_SLOTS; k++) e->dev.out[g * GPH_OUT_SLOTS + k] = 0;
 #else
   HIPCHK(hipMemsetAsync(e->dev.out, 0, sizeof(double) * GPH_OUT_SLOTS * e->L, e->stream));
 #endif
-  LAUNCH(e, 6, k_tau_revert, e->dev, (int)limit);
+  LAUNCH(e, 6, k_tau_revert, limit);
   return finish_kernel(e);
 }
 
 int gph_engine_mixing_evaluate(gph_engine *e, double c, double *dataDelta)
 {
   if (!e || !e->initialized || !dataDelta) return GPH_ESTATE;
-  LAUNCH(e, 2, k_mix_eval, e->dev, c);
+  LAUNCH(e, 2, k_mix_eval, c);
   int rc = finish_kernel(e);
   if (rc) return rc;
   double s[1] = {RSUM(e, 0)};
@@ -591,7 +640,7 @@ int gph_engine_mixing_evaluate(gph_engine *e, double c, double *dataDelta)
 int gph_engine_mixing_commit(gph_engine *e, double c, double lnc)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
-  LAUNCH(e, 7, k_mix_commit, e->dev, c, lnc);
+  LAUNCH(e, 7, k_mix_commit, c, lnc);
   return finish_kernel(e);
 }
 
@@ -658,7 +707,7 @@ int gph_engine_get_totals(gph_engine *e, double *cs, double *nc, double *ms, dou
 int gph_engine_synchronize(gph_engine *e, int32_t refresh, double *oldGen, double *newGen)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
-  LAUNCH(e, 5, k_sync, e->dev, (int)refresh);
+  LAUNCH(e, 8, k_sync, (int)refresh);
   int rc = finish_kernel(e);
   if (rc) return rc;
   if (RMIN(e, 0) < 1.0) { fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n"); return GPH_EKERNEL; }
@@ -672,7 +721,7 @@ int gph_engine_synchronize(gph_engine *e, int32_t refresh, double *oldGen, doubl
 int gph_engine_check_all(gph_engine *e, int32_t *ok, double *sumData, double *sumGen)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
-  LAUNCH(e, 4, k_check, e->dev);
+  LAUNCH(e, 4, k_check, 0);
   int rc = finish_kernel(e);
   if (rc) return rc;
   double s[2] = {RSUM(e, 1), RSUM(e, 2)};
@@ -694,12 +743,21 @@ int gph_engine_get_counters(gph_engine *e, gph_counters *out, int32_t reset)
 
 int gph_engine_last_kernel_ms(gph_engine *e, int32_t which, double *ms)
 {
-  if (!e || !ms || which < 0 || which >= 8) return GPH_EARG;
+  if (!e || !ms || which < 0 || which >= 16) return GPH_EARG;
   *ms = e->last_ms[which];
   return 0;
 }
 
 int64_t gph_engine_num_loci(gph_engine *e) { return e ? e->L : 0; }
+
+int gph_engine_class_stats(gph_engine *e, int32_t which, double *out5, int32_t reset)
+{
+  if (!e || !out5 || which < 0 || which >= 16) return GPH_EARG;
+  out5[0] = e->cls_launches[which]; out5[1] = e->cls_ms[which]; out5[2] = e->cls_evals[which];
+  out5[3] = e->cls_bytes[which]; out5[4] = e->cls_nodes[which];
+  if (reset) e->cls_launches[which] = e->cls_ms[which] = e->cls_evals[which] = e->cls_bytes[which] = e->cls_nodes[which] = 0;
+  return 0;
+}
 
 // out[5n]: exp(x), log(x), sqrt(|x|), x/y, floor(x) evaluated ON THE DEVICE
 int gph_debug_math(const double *x, const double *y, int32_t n, double *out, int32_t device)
@@ -731,7 +789,7 @@ int gph_debug_math(const double *x, const double *y, int32_t n, double *out, int
 int gph_engine_hbm_bytes(gph_engine *e, double *bytes)
 {
   if (!e || !bytes) return GPH_EARG;
-  *bytes = 2.0 * e->pages_bytes + (double)e->cond_bytes + (double)e->L * e->dev.seq_bytes + 8.0 * GPH_OUT_SLOTS * e->L;
+  *bytes = 2.0 * e->pages_bytes + (double)e->cond_bytes + (double)e->seq_bytes_total + 8.0 * GPH_OUT_SLOTS * e->L;
   return 0;
 }
 
@@ -746,7 +804,10 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
   if (rc) return rc;
   FILE *f = fopen(path, append ? "a" : "w");
   if (!f) return GPH_EARG;
-  for (int64_t g = 0; g < e->L; g++) {
+  std::vector<int32_t> slot_of(e->L);
+  for (int64_t j = 0; j < e->L; j++) slot_of[e->h_orig[j]] = (int32_t)j;
+  for (int64_t go = 0; go < e->L; go++) {
+    const int64_t g = slot_of[go];
     const char *pg = pages.data() + (size_t)g * y.page_bytes;
     const double *fs = (const double *)(pg + y.o_fscal);
     const int32_t *is = (const int32_t *)(pg + y.o_iscal);
@@ -758,7 +819,7 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
                   *enlin = (const int16_t *)(pg + y.o_ev_nlin), *first = (const int16_t *)(pg + y.o_first);
     const uint8_t *etype = (const uint8_t *)(pg + y.o_ev_type), *cbit = (const uint8_t *)(pg + y.o_condbit);
     const double *evt = (const double *)(pg + y.o_ev_time);
-    fprintf(f, "LOCUS %lld root %d dataLnL %a genLnL %a rng %u %u %u\n", (long long)(g + e->cfg.locus_begin), is[IS_ROOT],
+    fprintf(f, "LOCUS %lld root %d dataLnL %a genLnL %a rng %u %u %u\n", (long long)(go + e->cfg.locus_begin), is[IS_ROOT],
             fs[FS_DATALNL], fs[FS_GENLNL], (unsigned)is[IS_RX], (unsigned)is[IS_RY], (unsigned)is[IS_RZ]);
     for (int i = 0; i < y.N; i++)
       fprintf(f, "N %d %d %d %d %a %d %d\n", i, fa[i], le[i], ri[i], age[i], np[i], i < y.n ? -1 : ne[i]);

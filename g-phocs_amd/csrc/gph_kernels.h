@@ -13,13 +13,18 @@ struct GphDev {            // device pointers (passed by value to every kernel)
   char *shadow;            // L * page_bytes
   char *cond;              // conditionals, per-locus byte offset cond_off[g]
   const uint64_t *cond_off;
-  const char *seq;         // L * seq_bytes (leaf codes, phases, counts; fixed-size blocks)
+  const char *seq;         // leaf codes, phases, counts; per-locus byte offset seq_off[g]
+  const uint64_t *seq_off;
   const int32_t *P;        // phased patterns per locus
+  const int32_t *orig;     // original (input-order) local index of the locus stored at slot g
   double *out;             // L * GPH_OUT_SLOTS
   int32_t L;               // loci on this device
   int32_t Ltot;            // loci over all devices (dataSetup.numLoci)
-  int32_t seq_bytes;
+  int64_t locus_begin;     // global index of this device's first locus
 };
+// Loci are stored sorted by their number of phased patterns and launched in buckets of
+// similar P, each bucket with an LDS allocation sized for ITS largest locus: the few
+// pattern-rich loci no longer dictate the occupancy of all the others.
 
 // ---------------------------------------------------------------- staging
 GPH_DEV void copy16_g2l(int lds_off, const char *src, int bytes)
@@ -90,7 +95,7 @@ GPH_DEV void scratch_init(const GphDev &D, int g)
 GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withCond)
 {
   copy16_g2l(0, pages + (size_t)g * g_lay.page_bytes, g_lay.page_bytes);
-  if (withCond) copy16_g2l(g_lay.o_seq, D.seq + (size_t)g * D.seq_bytes, D.seq_bytes);
+  if (withCond) copy16_g2l(g_lay.o_seq, D.seq + D.seq_off[g], g_lay.o_cond - g_lay.o_seq);
   GPH_SYNC();
   scratch_init(D, g);
   if (withCond) { cond_transfer(D, g, 0, 1); GPH_SYNC(); }
@@ -176,7 +181,7 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate)
   int i;
   /* blank page */
   for (i = GPH_LANE; i < g_lay.page_bytes / 4; i += GPH_NLANES) ((li32 *)GPH_SMB)[i] = 0;
-  copy16_g2l(g_lay.o_seq, D.seq + (size_t)g * D.seq_bytes, D.seq_bytes);
+  copy16_g2l(g_lay.o_seq, D.seq + D.seq_off[g], g_lay.o_cond - g_lay.o_seq);
   GPH_SYNC();
   scratch_init(D, g);
   setISC(IS_RX, 11);
@@ -495,6 +500,7 @@ GPH_DEV void kb_tau_eval(const GphDev &D, int g, const GphTauArgs &A)
   OUT(g, 0, conflict ? 0 : n1_0);
   OUT(g, 1, conflict ? 0 : n1_1);
   OUT(g, 2, conflict);
+  OUT(g, 14, conflict ? (double)(D.orig[g] + D.locus_begin) : 1e300);
   OUT(g, 3, dGen);
   OUT(g, 4, dData);
   out_common(D, g);
@@ -538,9 +544,9 @@ GPH_DEV void kb_tau_commit(const GphDev &D, int g, const GphTauArgs &A)
 
 // loops 3/4 body (reject), GPhoCS.c:3965-3989: only loci whose ripple moved events
 // differ from their main page; everything else is bit-identical already
-GPH_DEV void kb_tau_revert(const GphDev &D, int g, int limit)
+GPH_DEV void kb_tau_revert(const GphDev &D, int g, long long limit)
 {
-  if (g >= limit) return;
+  if (D.orig[g] + D.locus_begin >= limit) return;   /* loci the serial reference never touched */
   const int32_t *is = (const int32_t *)(D.shadow + (size_t)g * g_lay.page_bytes + g_lay.o_iscal);
   if (is[IS_RB_NUM] == 0) return;
   stage_in(D, g, D.shadow, 0);

@@ -124,8 +124,11 @@ int gph_engine_get_counters(gph_engine *e, gph_counters *out, int32_t reset);
 /* debug / parity: canonical text dump of every local locus (same format as the oracle's) */
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditionals, int32_t append);
 /* timing of the last launch of a named kernel class, measured with HIP events on the
- * engine's own stream: which = 0 sweep, 1 tau_eval, 2 mix_eval, 3 init, 4 check */
+ * engine's own stream: which = 0 sweep, 1 tau_eval, 2 mix_eval, 3 init, 4 check,
+ * 5 tau_commit, 6 tau_revert, 7 mix_commit, 8 sync */
 int gph_engine_last_kernel_ms(gph_engine *e, int32_t which, double *ms);
+/* accumulated per class: out5 = {launches, summed ms, evaluations, algorithmic bytes, recomputed nodes} */
+int gph_engine_class_stats(gph_engine *e, int32_t which, double *out5, int32_t reset);
 int64_t gph_engine_num_loci(gph_engine *e);
 /* parity probe: out[5n] = exp(x), log(x), sqrt(|x|), x/y, floor(x) evaluated on the device */
 int gph_debug_math(const double *x, const double *y, int32_t n, double *out5n, int32_t device);
