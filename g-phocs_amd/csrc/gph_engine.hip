@@ -198,7 +198,7 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
     y.s_dcoal[k] = f64(K); y.s_dmig[k] = f64(B > 0 ? B : 1);
   }
   y.s_sprf = f64(GPH_MAX_MIGS + 2); y.s_terms = f64(Pmax); y.s_chkcoal = f64(K); y.s_chkmig = f64(B > 0 ? B : 1);
-  y.s_cntf = f64(2);
+  y.s_cntf = f64(3);
   for (int k = 0; k < 2; k++) y.s_di[k] = i32(DI_COUNT);
   y.s_spri = i32(SI_COUNT); y.s_cnt = i32(CN_COUNT);
   for (int k = 0; k < 2; k++) { y.s_dev[k] = i16(y.E); y.s_dpops[k] = i16(K); y.s_dbands[k] = i16(B > 0 ? B : 1); }
@@ -213,9 +213,8 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   o = align_up(o, 4);
   y.q_count = o; o += 4 * Pmax;
   o = align_up(o, 16);
-  // conditionals [2][n-1][P][4] fp64
+  // end of the LDS image; the conditionals [2][n-1][P][4] fp64 stay in global memory
   y.o_cond = o;
-  o += 2 * (n - 1) * Pmax * 32;
   y.Pmax = Pmax;
   y.lds_bytes = align_up(o, 16);
 }

@@ -56,55 +56,31 @@ GPH_DEV void copy16_l2g(char *dst, int lds_off, int bytes)
 #endif
 }
 
-// conditionals: per internal node only the CURRENT half (page condbit) travels.
-// mode 1: every internal node; mode 2: only nodes whose dirty flag is set.
-GPH_DEV void cond_transfer(const GphDev &D, int g, int store, int mode)
-{
-  const int P = D.P[g], nint = g_lay.n - 1;
-  const int pairs = 2 * P;               /* 16-byte units per node half */
-  char *base = D.cond + D.cond_off[g];
-  int e;
-  for (e = GPH_LANE; e < nint * pairs; e += GPH_NLANES) {
-    int k = e / pairs, j = e - k * pairs, node = g_lay.n + k;
-    int bit = gu8v(g_lay.o_condbit, node);
-    if (mode == 2 && !gu8v(g_lay.o_dirty, node)) continue;
-    int off = ((bit * nint + k) * P) * 32 + j * 16;
-#ifdef GPH_HOSTEMU
-    if (store) memcpy(base + off, gph_sm + g_lay.o_cond + off, 16);
-    else memcpy(gph_sm + g_lay.o_cond + off, base + off, 16);
-#else
-    typedef double gf64x2 __attribute__((ext_vector_type(2)));
-    typedef GPH_LDS gf64x2 ld2;
-    if (store) *(gf64x2 *)(base + off) = *(ld2 *)(GPH_SMB + g_lay.o_cond + off);
-    else *(ld2 *)(GPH_SMB + g_lay.o_cond + off) = *(const gf64x2 *)(base + off);
-#endif
-  }
-}
-
 GPH_DEV void scratch_init(const GphDev &D, int g)
 {
   int k;
   for (k = 0; k < CN_COUNT; k++) setCNT(k, 0);
   setCNT(CN_P, D.P[g]);
   sf64(g_lay.s_cntf, 0, 0.0);
+  set_cond_base(D.cond + D.cond_off[g]);
   delta_clear(0);
   delta_clear(1);
 }
 
-// load page (+ optionally sequence data and current conditionals)
-GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withCond)
+// load page (+ optionally the read-only sequence block: leaf codes, phases, counts).
+// Conditionals are never staged: kernels read/write them in place (see cond_base()).
+GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withSeq)
 {
   copy16_g2l(0, pages + (size_t)g * g_lay.page_bytes, g_lay.page_bytes);
-  if (withCond) copy16_g2l(g_lay.o_seq, D.seq + D.seq_off[g], g_lay.o_cond - g_lay.o_seq);
+  if (withSeq) copy16_g2l(g_lay.o_seq, D.seq + D.seq_off[g], g_lay.o_cond - g_lay.o_seq);
   GPH_SYNC();
   scratch_init(D, g);
-  if (withCond) { cond_transfer(D, g, 0, 1); GPH_SYNC(); }
 }
-GPH_DEV void stage_out(const GphDev &D, int g, char *pages, int condMode)
+GPH_DEV void stage_out(const GphDev &D, int g, char *pages, int unused)
 {
+  (void)unused;
   GPH_SYNC();
   copy16_l2g(pages + (size_t)g * g_lay.page_bytes, 0, g_lay.page_bytes);
-  if (condMode) cond_transfer(D, g, 1, condMode);
 }
 GPH_DEV void out_common(const GphDev &D, int g)
 {

@@ -268,16 +268,33 @@ GPH_DEV double edge_prob(double len)
   return ((1 - gph_exp(-4 * len / 3.0)) / 4.0);
 }
 
-// LDS byte offset of the conditional array (buffer `bit`) of internal node `node`
+// The fp64 conditional arrays [2][n-1][P][4] of the locus stay in global memory: they are
+// touched lane-parallel and fully coalesced (4P consecutive doubles per node), the working
+// set of all resident waves fits the L2 / Infinity Cache, and keeping them out of LDS is
+// what lets 16+ loci be resident per CU instead of ~6 (the chain logic is latency-bound,
+// so resident loci per CU is the throughput lever).  The wave's base pointer sits in two
+// LDS scratch words.
+GPH_DEV gdbl *cond_base()
+{
+  uint64_t lo = (uint32_t)gi32(g_lay.s_cntf + 8, 0), hi = (uint32_t)gi32(g_lay.s_cntf + 8, 1);
+  return (gdbl *)(uintptr_t)(lo | (hi << 32));
+}
+GPH_DEV void set_cond_base(const void *p)
+{
+  uint64_t v = (uint64_t)(uintptr_t)p;
+  si32(g_lay.s_cntf + 8, 0, (int)(uint32_t)v);
+  si32(g_lay.s_cntf + 8, 1, (int)(uint32_t)(v >> 32));
+}
+// index (in doubles) of the conditional array (buffer `bit`) of internal node `node`
 GPH_DEV int cond_off(int node, int bit)
 {
   int P = CNT(CN_P);
-  return g_lay.o_cond + ((bit * (g_lay.n - 1) + (node - g_lay.n)) * P) * 32;
+  return ((bit * (g_lay.n - 1) + (node - g_lay.n)) * P) * 4;
 }
 
 // one child's factor for (pattern p, base a): computeSubtreeConditionals_new,
 // LocusDataLikelihood.c:1650-1673.  A leaf child is a base code (one-hot / N).
-GPH_DEV double child_factor(int child, int coff, int p, int a, double pe, double qe)
+GPH_DEV double child_factor(int child, const gdbl *cnd, int p, int a, double pe, double qe)
 {
   double s0, s1, s2, s3, sa, S, Sp;
   if (child < g_lay.n) {
@@ -287,10 +304,10 @@ GPH_DEV double child_factor(int child, int coff, int p, int a, double pe, double
     s2 = (code == 4 || code == 2) ? 1.0 : 0.0;
     s3 = (code == 4 || code == 3) ? 1.0 : 0.0;
   } else {
-    s0 = gf64(coff, 4 * p + 0);
-    s1 = gf64(coff, 4 * p + 1);
-    s2 = gf64(coff, 4 * p + 2);
-    s3 = gf64(coff, 4 * p + 3);
+    s0 = cnd[4 * p + 0];
+    s1 = cnd[4 * p + 1];
+    s2 = cnd[4 * p + 2];
+    s3 = cnd[4 * p + 3];
   }
   sa = a == 0 ? s0 : a == 1 ? s1 : a == 2 ? s2 : s3;
   S = 0.0;
@@ -313,18 +330,19 @@ GPH_DEV void prune_node(int node)
   double ql = 1 - 4.0 * pl;
   double pr = edge_prob(mut * (AGE(node) - AGE(r)));
   double qr = 1 - 4.0 * pr;
-  int po = cond_off(node, CBIT(node));
-  int lo = l >= g_lay.n ? cond_off(l, CBIT(l)) : 0;
-  int ro = r >= g_lay.n ? cond_off(r, CBIT(r)) : 0;
+  gdbl *cb = cond_base();
+  gdbl *pc = cb + cond_off(node, CBIT(node));
+  const gdbl *lc = cb + (l >= g_lay.n ? cond_off(l, CBIT(l)) : 0);
+  const gdbl *rc = cb + (r >= g_lay.n ? cond_off(r, CBIT(r)) : 0);
   int idx;
   for (idx = GPH_LANE; idx < 4 * P; idx += GPH_NLANES) {
     int p = idx >> 2, a = idx & 3;
     double v = 1.0, f;
-    f = child_factor(l, lo, p, a, pl, ql);
+    f = child_factor(l, lc, p, a, pl, ql);
     v *= f;
-    f = child_factor(r, ro, p, a, pr, qr);
+    f = child_factor(r, rc, p, a, pr, qr);
     v *= f;
-    sf64(po, idx, v);
+    pc[idx] = v;
   }
   GPH_SYNC();
 }
@@ -382,14 +400,14 @@ GPH_DEVNI double lik_compute(int useOld)
   /* root reduction, LocusDataLikelihood.c:466-479: per unphased pattern
    * gph_log(sum over phases and bases / (4*phases)) * count, summed in pattern order */
   {
-    int ro = cond_off(ISC(IS_ROOT), CBIT(ISC(IS_ROOT)));
+    const gdbl *rc = cond_base() + cond_off(ISC(IS_ROOT), CBIT(ISC(IS_ROOT)));
     int p;
     for (p = GPH_LANE; p < P; p += GPH_NLANES) {
       int ph = gu8v(g_lay.q_phases, p);
       if (ph > 0) {
         int nc = 4 * ph, c;
         double prob = 0.0;
-        for (c = 0; c < nc; c++) prob += gf64(ro, p * 4 + c);
+        for (c = 0; c < nc; c++) prob += rc[p * 4 + c];
         sf64(g_lay.s_terms, p, gph_log(prob / nc) * gi32v(g_lay.q_count, p));
       }
     }

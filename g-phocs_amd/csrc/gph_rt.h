@@ -44,6 +44,12 @@ extern __constant__ GphLayout g_lay;
 extern __constant__ GphModel g_model;
 #endif
 
+#ifdef GPH_HOSTEMU
+#define GPH_GLB
+#else
+#define GPH_GLB __attribute__((address_space(1)))
+#endif
+typedef GPH_GLB double gdbl;   // conditional-likelihood arrays live in global memory (L2 / Infinity Cache)
 typedef GPH_LDS double lf64;
 typedef GPH_LDS int16_t li16;
 typedef GPH_LDS int32_t li32;
