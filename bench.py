@@ -182,6 +182,17 @@ def main():
                 kern[nm] = {"launches": int(st["launches"]), "avg_ms": st["ms"] / st["launches"]}
         ach = (sweep["bytes"] / max(sweep["launches"], 1)) / (sweep["ms"] / max(sweep["launches"], 1) * 1e-3) / 1e9 \
             if sweep["ms"] > 0 else 0.0
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2
+        # gfx950 correction + WRITE_SIZE, per launch) committed under profiles/; null if absent
+        traffic = None
+        tf = os.path.join(REPO, "profiles", "traffic_k_sweep.json")
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                if tj.get("loci") == a.loci:
+                    traffic = tj["hbm_bytes_per_launch"]
+            except Exception:
+                pass
         line = {
             "metric": "locus-likelihood evals/sec (+ MCMC iters/sec), 100k loci per MI355X",
             "value": evals / tmax, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -197,7 +208,7 @@ def main():
                        "algorithmic_bytes_per_eval": cnt["eval_bytes"] / max(cnt["evals"], 1),
                        "parallelism": f"loci sharded over {world} rank(s), one process per GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (fused UpdateGB_InternalNode+MigrationNode+MigSPR)",
-                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                          "avg_launch_ms": sweep["ms"] / max(sweep["launches"], 1),
                          "algorithmic_bytes_per_launch": sweep["bytes"] / max(sweep["launches"], 1),
                          "evals_per_launch": sweep["evals"] / max(sweep["launches"], 1)},

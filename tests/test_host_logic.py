@@ -1,0 +1,60 @@
+"""CPU-only checks of the product's host logic and of its per-locus code compiled for the host.
+
+The HIP library has no CPU path; `tests/hostemu/` compiles the SAME sources with -DGPH_HOSTEMU (a
+1-lane "wave", plain memory instead of LDS/HBM) purely as a test/debug build (sanitizers, gdb, and
+the world_size-2 gloo test) -- it is not linked into libgphocs_hip.so.  These tests pin the engine's
+logic to the real-reference goldens in the GPU-less container; the -m gpu tests do the same on the
+device through the C ABI."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLDEN, REPO
+from parity_util import compare_records, compare_states
+
+sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
+
+
+@pytest.fixture(scope="module")
+def hostemu():
+    import run_hostemu as R
+    import gphocs_amd as G
+    return R, G.load_library(R.build_hostemu())
+
+
+@pytest.mark.parametrize("name,iters", [("g1", 30), ("g2", 30), ("m3", 120), ("m4", 60), ("c5", 30), ("s3", 40)])
+def test_hostemu_matches_reference_goldens(hostemu, name, iters, tmp_path):
+    R, lib = hostemu
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(os.path.join(GOLDEN, name + ".gpk"), iters, str(tr), str(st), iters - 1, lib=lib)
+    worst = compare_records(tr, os.path.join(GOLDEN, name + ".rtrace"))
+    compare_states(st, os.path.join(GOLDEN, name + ".state"))
+    assert worst < 1e-12
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """build the real HIP library (hipcc cross-compiles without a GPU) and check that every function
+    declared in include/gphocs_hip.h is exported (no compute calls: there is no GPU here)"""
+    import re
+    import gphocs_amd as G
+    G.build()
+    lib = ctypes.CDLL(G.LIB_PATH)
+    hdr = open(os.path.join(REPO, "include", "gphocs_hip.h")).read()
+    names = set(re.findall(r"\b(gph_[a-z_0-9]+)\s*\(", hdr)) - {"gph_allreduce_fn"}
+    assert len(names) >= 30
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in include/gphocs_hip.h but not exported"
+    assert names == set(G.EXPORTS), names ^ set(G.EXPORTS)
+
+
+def test_engine_creation_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import gphocs_amd as G
+    pk = G.Pack.load(os.path.join(GOLDEN, "g1.gpk"))
+    with pytest.raises(RuntimeError):
+        G.Sampler(pk)      # libgphocs_hip.so: no device -> GPH_EHIP, no silent CPU fallback

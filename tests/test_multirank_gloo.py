@@ -1,0 +1,61 @@
+"""world_size-2 test of the sharded path on CPU (gloo): two processes, each with an engine over its
+contiguous shard of loci, exchanging only the small reduced vectors through the all-reduce hook
+(gph_engine_set_allreduce) -- here torch.distributed/gloo, on the GPU box RCCL.  Uses the host
+build of the engine sources (tests/hostemu); the result must equal the single-rank run: accept
+counters exact, accumulators within 1e-10, and the conflict early-out must pick the same locus."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLDEN, REPO
+from parity_util import compare_records
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(repo)r); sys.path.insert(0, os.path.join(%(repo)r, "tests", "hostemu"))
+import numpy as np, torch, torch.distributed as dist
+import gphocs_amd as G, run_hostemu as R
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+def allreduce(sums, mins):
+    if sums.size:
+        t = torch.from_numpy(sums); dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if mins.size:
+        t = torch.from_numpy(mins); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+lib = G.load_library(R.build_hostemu())
+pk = G.Pack.load(%(pack)r)
+s = G.Sampler(pk, lib=lib, rank=rank, world=world, allreduce=allreduce)
+s.set_record_file(%(out)r + ".%%d" %% rank)
+s.initialize()
+for it in range(%(iters)d):
+    s.iteration(it)
+s.set_record_file(None)
+print("rank", rank, "loci", s.begin, s.end, "conflicts", s.accept_counts()[8])
+s.close()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("name,iters", [("m3", 60), ("g1", 12)])
+def test_two_ranks_equal_one_rank(name, iters, tmp_path):
+    sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
+    import run_hostemu as R
+    R.build_hostemu()
+    out = str(tmp_path / "rec")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(repo=REPO, pack=os.path.join(GOLDEN, name + ".gpk"), out=out, iters=iters))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    # every rank runs the same host driver and must have written identical records
+    assert open(out + ".0").read() == open(out + ".1").read()
+    # and they must equal the single-rank run (= the reference golden) up to reduction order
+    golden = open(os.path.join(GOLDEN, name + ".rtrace")).read().splitlines()
+    mine = open(out + ".0").read().splitlines()
+    # golden has more iterations: compare the common prefix line by line
+    cut = len(mine)
+    (tmp_path / "g").write_text("\n".join(golden[:cut]) + "\n")
+    compare_records(out + ".0", str(tmp_path / "g"))
