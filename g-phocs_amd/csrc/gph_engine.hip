@@ -15,6 +15,7 @@
 
 #ifdef GPH_HOSTEMU
 thread_local char *gph_sm = nullptr;
+thread_local GphLds gph_lds;
 GphLayout g_lay;
 GphModel g_model;
 #define GPH_KERNEL(name, ...) static void name(int gph_blk, __VA_ARGS__)
@@ -191,30 +192,19 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   y.o_ncoal = i16(K); y.o_nmig = i16(B > 0 ? B : 1); y.o_rb_i = i16(3 * y.RB);
   y.o_ev_type = u8(y.E); y.o_condbit = u8(y.N); y.o_dirty = u8(y.N);
   y.page_bytes = align_up(o, 16);
-  // LDS-only scratch
-  o = y.page_bytes;
-  y.o_scratch = o;
-  for (int k = 0; k < 2; k++) {
-    y.s_dcoal[k] = f64(K); y.s_dmig[k] = f64(B > 0 ? B : 1);
-  }
-  y.s_sprf = f64(GPH_MAX_MIGS + 2); y.s_terms = f64(Pmax); y.s_chkcoal = f64(K); y.s_chkmig = f64(B > 0 ? B : 1);
-  y.s_cntf = f64(3);
-  for (int k = 0; k < 2; k++) y.s_di[k] = i32(DI_COUNT);
-  y.s_spri = i32(SI_COUNT); y.s_cnt = i32(CN_COUNT);
-  for (int k = 0; k < 2; k++) { y.s_dev[k] = i16(y.E); y.s_dpops[k] = i16(K); y.s_dbands[k] = i16(B > 0 ? B : 1); }
-  y.s_spri16 = i16(4 * GPH_MAX_MIGS); y.s_ord = i16(y.N + 1); y.s_stack = i16(y.N + 1); y.s_targets = i16(y.N + 1);
-  y.s_chknc = i16(K); y.s_chknm = i16(B > 0 ? B : 1);
-  o = align_up(o, 16);
-  y.scratch_bytes = o - y.page_bytes;
-  // sequence block (fixed size per locus, also the HBM block size)
+  // dynamic LDS: sequence block (also the HBM block format) + per-pattern terms of the root
+  // reduction; the locus image itself is the static GphLds
+  o = 0;
+  y.o_scratch = 0;
+  y.scratch_bytes = (int)sizeof(GphLds);
   y.o_seq = o;
   y.q_leaf = o; o += Pmax * n;
   y.q_phases = o; o += Pmax;
   o = align_up(o, 4);
   y.q_count = o; o += 4 * Pmax;
   o = align_up(o, 16);
-  // end of the LDS image; the conditionals [2][n-1][P][4] fp64 stay in global memory
-  y.o_cond = o;
+  y.o_cond = o;     // end of the sequence block
+  y.s_terms = f64(Pmax);
   y.Pmax = Pmax;
   y.lds_bytes = align_up(o, 16);
 }
@@ -356,8 +346,8 @@ extern "C" {
 int gph_engine_create(const gph_config *cfg, gph_engine **out)
 {
   if (!cfg || !out) return GPH_EARG;
-  if (cfg->n < 2 || cfg->n > 32 || cfg->K > GPH_MAXK || cfg->B > GPH_MAXB || cfg->K != 2 * cfg->Kc - 1) {
-    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (caps: n<=32, K<=%d, B<=%d)\n", cfg->n, cfg->K, cfg->B, GPH_MAXK, GPH_MAXB);
+  if (cfg->n < 2 || cfg->n > GPH_CAP_LEAVES || cfg->K > GPH_CAP_K || cfg->B > GPH_CAP_B || cfg->K != 2 * cfg->Kc - 1) {
+    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (compiled capacities: n<=%d, K<=%d, B<=%d; rebuild with -DGPH_CAP_*)\n", cfg->n, cfg->K, cfg->B, GPH_CAP_LEAVES, GPH_CAP_K, GPH_CAP_B);
     return GPH_EARG;
   }
   gph_engine *e = new gph_engine();
@@ -419,7 +409,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   int Pmax = 1;
   for (int64_t g = 0; g < L; g++) { int P = (int)(poff[g + 1] - poff[g]); if (P > Pmax) Pmax = P; if (P < 1) return GPH_EARG; }
   build_layout(e->lay, n, e->cfg.Kc, e->cfg.K, e->cfg.B, e->cfg.rootPop, Pmax);
-  if (e->lay.lds_bytes > 160 * 1024) {
+  if (e->lay.lds_bytes + (int)sizeof(GphLds) > 160 * 1024) {
     fprintf(stderr, "gphocs_hip: a locus with %d phased patterns needs %d bytes of LDS (> 160 KiB)\n", Pmax, e->lay.lds_bytes);
     return GPH_EARG;
   }

@@ -41,19 +41,51 @@ GPH_DEV void copy16_g2l(int lds_off, const char *src, int bytes)
   for (i = GPH_LANE; i < n16; i += GPH_NLANES) d[i] = s[i];
 #endif
 }
-GPH_DEV void copy16_l2g(char *dst, int lds_off, int bytes)
+// compact HBM page (GphLayout offsets, actual n/K/B) <-> static LDS image (GphLds, capacities)
+template <class T, int NN> GPH_DEV void pg_in(T (GphLds::*m)[NN], const char *page, int off, int count)
 {
-  int i, n16 = bytes >> 4;
-#ifdef GPH_HOSTEMU
-  memcpy(dst, gph_sm + lds_off, bytes);
-  (void)i; (void)n16;
-#else
-  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
-  typedef GPH_LDS gu32x4 luint4;
-  gu32x4 *d = (gu32x4 *)dst;
-  const luint4 *s = (const luint4 *)(GPH_SMB + lds_off);
-  for (i = GPH_LANE; i < n16; i += GPH_NLANES) d[i] = s[i];
-#endif
+  const T *s = (const T *)(page + off);
+  for (int i = GPH_LANE; i < count; i += GPH_NLANES) (gph_lds.*m)[i] = s[i];
+}
+template <class T, int NN> GPH_DEV void pg_out(T (GphLds::*m)[NN], char *page, int off, int count)
+{
+  T *d = (T *)(page + off);
+  for (int i = GPH_LANE; i < count; i += GPH_NLANES) d[i] = (gph_lds.*m)[i];
+}
+#define GPH_PAGE_FIELDS(X, page)                                                                   \
+  X(&GphLds::age, page, g_lay.o_age, g_lay.N) X(&GphLds::sv_age, page, g_lay.o_sv_age, g_lay.N)     \
+  X(&GphLds::ev_time, page, g_lay.o_ev_time, g_lay.E) X(&GphLds::mig_age, page, g_lay.o_mig_age, GPH_MAX_MIGS) \
+  X(&GphLds::coal, page, g_lay.o_coal, g_lay.K) X(&GphLds::migst, page, g_lay.o_migst, g_lay.B)     \
+  X(&GphLds::rb_age, page, g_lay.o_rb_age, g_lay.RB) X(&GphLds::fscal, page, g_lay.o_fscal, FS_COUNT) \
+  X(&GphLds::iscal, page, g_lay.o_iscal, IS_COUNT)                                                  \
+  X(&GphLds::father, page, g_lay.o_father, g_lay.N) X(&GphLds::left, page, g_lay.o_left, g_lay.N)   \
+  X(&GphLds::right, page, g_lay.o_right, g_lay.N) X(&GphLds::npop, page, g_lay.o_npop, g_lay.N)     \
+  X(&GphLds::nev, page, g_lay.o_nev, g_lay.N) X(&GphLds::sv_father, page, g_lay.o_sv_father, g_lay.N) \
+  X(&GphLds::sv_left, page, g_lay.o_sv_left, g_lay.N) X(&GphLds::sv_right, page, g_lay.o_sv_right, g_lay.N) \
+  X(&GphLds::changed, page, g_lay.o_changed, 2 * g_lay.N) X(&GphLds::changedc, page, g_lay.o_changedc, 2 * g_lay.N) \
+  X(&GphLds::ev_next, page, g_lay.o_ev_next, g_lay.E) X(&GphLds::ev_prev, page, g_lay.o_ev_prev, g_lay.E) \
+  X(&GphLds::ev_node, page, g_lay.o_ev_node, g_lay.E) X(&GphLds::ev_nlin, page, g_lay.o_ev_nlin, g_lay.E) \
+  X(&GphLds::first, page, g_lay.o_first, g_lay.K) X(&GphLds::mig_i, page, g_lay.o_mig_i, GPH_MAX_MIGS * MG_COUNT) \
+  X(&GphLds::living, page, g_lay.o_living, GPH_MAX_MIGS) X(&GphLds::ncoal, page, g_lay.o_ncoal, g_lay.K) \
+  X(&GphLds::nmig, page, g_lay.o_nmig, g_lay.B)                                                     \
+  X(&GphLds::ev_type, page, g_lay.o_ev_type, g_lay.E) X(&GphLds::condbit, page, g_lay.o_condbit, g_lay.N) \
+  X(&GphLds::dirty, page, g_lay.o_dirty, g_lay.N)
+#define GPH_X_IN(m, page, off, cnt) pg_in(m, page, off, cnt);
+#define GPH_X_OUT(m, page, off, cnt) pg_out(m, page, off, cnt);
+
+GPH_DEV void page_in(const char *page)
+{
+  GPH_PAGE_FIELDS(GPH_X_IN, page)
+  for (int k = 0; k < 3; k++)   /* rb_i: [3][RB] in HBM, [3][GPH_CAP_RB] in LDS */
+    for (int i = GPH_LANE; i < g_lay.RB; i += GPH_NLANES)
+      gph_lds.rb_i[k * GPH_CAP_RB + i] = ((const int16_t *)(page + g_lay.o_rb_i))[k * g_lay.RB + i];
+}
+GPH_DEV void page_out(char *page)
+{
+  GPH_PAGE_FIELDS(GPH_X_OUT, page)
+  for (int k = 0; k < 3; k++)
+    for (int i = GPH_LANE; i < g_lay.RB; i += GPH_NLANES)
+      ((int16_t *)(page + g_lay.o_rb_i))[k * g_lay.RB + i] = gph_lds.rb_i[k * GPH_CAP_RB + i];
 }
 
 GPH_DEV void scratch_init(const GphDev &D, int g)
@@ -61,7 +93,7 @@ GPH_DEV void scratch_init(const GphDev &D, int g)
   int k;
   for (k = 0; k < CN_COUNT; k++) setCNT(k, 0);
   setCNT(CN_P, D.P[g]);
-  sf64(g_lay.s_cntf, 0, 0.0);
+  sf64(&GphLds::s_cntf, 0, 0.0);
   set_cond_base(D.cond + D.cond_off[g]);
   delta_clear(0);
   delta_clear(1);
@@ -71,7 +103,7 @@ GPH_DEV void scratch_init(const GphDev &D, int g)
 // Conditionals are never staged: kernels read/write them in place (see cond_base()).
 GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withSeq)
 {
-  copy16_g2l(0, pages + (size_t)g * g_lay.page_bytes, g_lay.page_bytes);
+  page_in(pages + (size_t)g * g_lay.page_bytes);
   if (withSeq) copy16_g2l(g_lay.o_seq, D.seq + D.seq_off[g], g_lay.o_cond - g_lay.o_seq);
   GPH_SYNC();
   scratch_init(D, g);
@@ -80,7 +112,7 @@ GPH_DEV void stage_out(const GphDev &D, int g, char *pages, int unused)
 {
   (void)unused;
   GPH_SYNC();
-  copy16_l2g(pages + (size_t)g * g_lay.page_bytes, 0, g_lay.page_bytes);
+  page_out(pages + (size_t)g * g_lay.page_bytes);
 }
 GPH_DEV void out_common(const GphDev &D, int g)
 {
@@ -88,7 +120,7 @@ GPH_DEV void out_common(const GphDev &D, int g)
     double *o = D.out + (size_t)g * GPH_OUT_SLOTS;
     o[8] = CNT(CN_EVALS);
     o[9] = CNT(CN_NODES);
-    o[10] = gf64(g_lay.s_cntf, 0);
+    o[10] = gf64(&GphLds::s_cntf, 0);
     o[11] = CNT(CN_ERROR);
     o[13] = CNT(CN_NOTENOUGH);
   }
@@ -113,7 +145,7 @@ GPH_DEV void random_gtree()
       num = g_model.cumSamples[pop] - node1;
       base = cur;
       for (node2 = 0; node2 < num; ++node2) {
-        si16(g_lay.s_targets, base + node2, node1 + node2);
+        si16(&GphLds::s_targets, base + node2, node1 + node2);
         setNPOP(node1 + node2, pop);
         setNEV(node1 + node2, -1);
         setLEFT(node1 + node2, -1);
@@ -122,10 +154,10 @@ GPH_DEV void random_gtree()
         setAGE(node1 + node2, g_model.sampleAge[pop]);
       }
     } else {
-      base = gi16(g_lay.s_ord, g_model.popSon0[pop]);
+      base = gi16(&GphLds::s_ord, g_model.popSon0[pop]);
       num = cur - base;
     }
-    si16(g_lay.s_ord, pop, base);
+    si16(&GphLds::s_ord, pop, base);
     T = g_model.popAge[pop];
     if (pop < g_lay.Kc) T = g_model.sampleAge[pop];
     for (; num > 1; num--, nextId++) {
@@ -133,11 +165,11 @@ GPH_DEV void random_gtree()
       T += t;
       if (pop != g_lay.rootPop && T > g_model.popAge[g_model.popFather[pop]]) break;
       choice = (int)(num * l_rndu());
-      a = gi16(g_lay.s_targets, base + choice);
-      si16(g_lay.s_targets, base + choice, gi16(g_lay.s_targets, base + num - 1));
+      a = gi16(&GphLds::s_targets, base + choice);
+      si16(&GphLds::s_targets, base + choice, gi16(&GphLds::s_targets, base + num - 1));
       choice = (int)((num - 1) * l_rndu());
-      b = gi16(g_lay.s_targets, base + choice);
-      si16(g_lay.s_targets, base + choice, nextId);
+      b = gi16(&GphLds::s_targets, base + choice);
+      si16(&GphLds::s_targets, base + choice, nextId);
       setRGHT(nextId, a);
       setLEFT(nextId, b);
       setFATH(nextId, -1);
@@ -156,7 +188,7 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate)
 {
   int i;
   /* blank page */
-  for (i = GPH_LANE; i < g_lay.page_bytes / 4; i += GPH_NLANES) ((li32 *)GPH_SMB)[i] = 0;
+  for (i = GPH_LANE; i < (int)(sizeof(GphLds) / 4); i += GPH_NLANES) ((GPH_LDS int32_t *)&gph_lds)[i] = 0;
   copy16_g2l(g_lay.o_seq, D.seq + D.seq_off[g], g_lay.o_cond - g_lay.o_seq);
   GPH_SYNC();
   scratch_init(D, g);
@@ -555,8 +587,8 @@ GPH_DEV void kb_mix_commit(const GphDev &D, int g, double c, double lnc)
   for (pop = 0; pop < g_lay.K; pop++) setCOALS(pop, COALS(pop) * c);
   for (b = 0; b < g_lay.B; b++) setMIGST(b, MIGST(b) * c);
   for (i = GPH_LANE; i < g_lay.E; i += GPH_NLANES) {
-    double t = gf64(g_lay.o_ev_time, i);
-    if (t > 0) sf64(g_lay.o_ev_time, i, t * c);
+    double t = gf64(&GphLds::ev_time, i);
+    if (t > 0) sf64(&GphLds::ev_time, i, t * c);
   }
   GPH_SYNC();
   {

@@ -12,88 +12,88 @@
 #include "gph_rt.h"
 
 // ---------------------------------------------------------------- accessors
-#define AGE(i) gf64(g_lay.o_age, (i))
-#define setAGE(i, v) sf64(g_lay.o_age, (i), (v))
-#define SVAGE(i) gf64(g_lay.o_sv_age, (i))
-#define setSVAGE(i, v) sf64(g_lay.o_sv_age, (i), (v))
-#define EVT(e) gf64(g_lay.o_ev_time, (e))
-#define setEVT(e, v) sf64(g_lay.o_ev_time, (e), (v))
-#define MAGE(m) gf64(g_lay.o_mig_age, (m))
-#define setMAGE(m, v) sf64(g_lay.o_mig_age, (m), (v))
-#define COALS(p) gf64(g_lay.o_coal, (p))
-#define setCOALS(p, v) sf64(g_lay.o_coal, (p), (v))
-#define MIGST(b) gf64(g_lay.o_migst, (b))
-#define setMIGST(b, v) sf64(g_lay.o_migst, (b), (v))
-#define RBAGE(i) gf64(g_lay.o_rb_age, (i))
-#define setRBAGE(i, v) sf64(g_lay.o_rb_age, (i), (v))
-#define FS(k) gf64(g_lay.o_fscal, (k))
-#define setFS(k, v) sf64(g_lay.o_fscal, (k), (v))
-#define FATH(i) gi16(g_lay.o_father, (i))
-#define setFATH(i, v) si16(g_lay.o_father, (i), (v))
-#define LEFT(i) gi16(g_lay.o_left, (i))
-#define setLEFT(i, v) si16(g_lay.o_left, (i), (v))
-#define RGHT(i) gi16(g_lay.o_right, (i))
-#define setRGHT(i, v) si16(g_lay.o_right, (i), (v))
-#define NPOP(i) gi16(g_lay.o_npop, (i))
-#define setNPOP(i, v) si16(g_lay.o_npop, (i), (v))
-#define NEV(i) gi16(g_lay.o_nev, (i))
-#define setNEV(i, v) si16(g_lay.o_nev, (i), (v))
-#define SVF(i) gi16(g_lay.o_sv_father, (i))
-#define SVL(i) gi16(g_lay.o_sv_left, (i))
-#define SVR(i) gi16(g_lay.o_sv_right, (i))
-#define CHG(i) gi16(g_lay.o_changed, (i))
-#define CHGC(i) gi16(g_lay.o_changedc, (i))
-#define ENEXT(e) gi16(g_lay.o_ev_next, (e))
-#define setENEXT(e, v) si16(g_lay.o_ev_next, (e), (v))
-#define EPREV(e) gi16(g_lay.o_ev_prev, (e))
-#define setEPREV(e, v) si16(g_lay.o_ev_prev, (e), (v))
-#define ENODE(e) gi16(g_lay.o_ev_node, (e))
-#define setENODE(e, v) si16(g_lay.o_ev_node, (e), (v))
-#define ENLIN(e) gi16(g_lay.o_ev_nlin, (e))
-#define setENLIN(e, v) si16(g_lay.o_ev_nlin, (e), (v))
-#define ETYPE(e) gu8(g_lay.o_ev_type, (e))
-#define setETYPE(e, v) su8(g_lay.o_ev_type, (e), (v))
-#define FIRSTEV(p) gi16(g_lay.o_first, (p))
-#define setFIRSTEV(p, v) si16(g_lay.o_first, (p), (v))
-#define MG(m, f) gi16(g_lay.o_mig_i, (m) * MG_COUNT + (f))
-#define setMG(m, f, v) si16(g_lay.o_mig_i, (m) * MG_COUNT + (f), (v))
-#define LIVING(i) gi16(g_lay.o_living, (i))
-#define setLIVING(i, v) si16(g_lay.o_living, (i), (v))
-#define NCOAL(p) gi16(g_lay.o_ncoal, (p))
-#define setNCOAL(p, v) si16(g_lay.o_ncoal, (p), (v))
-#define NMIGB(b) gi16(g_lay.o_nmig, (b))
-#define setNMIGB(b, v) si16(g_lay.o_nmig, (b), (v))
-#define RBI(k, i) gi16(g_lay.o_rb_i, (k) * g_lay.RB + (i))
-#define setRBI(k, i, v) si16(g_lay.o_rb_i, (k) * g_lay.RB + (i), (v))
-#define ISC(k) gi32(g_lay.o_iscal, (k))
-#define setISC(k, v) si32(g_lay.o_iscal, (k), (v))
-#define CBIT(i) gu8(g_lay.o_condbit, (i))
-#define setCBIT(i, v) su8(g_lay.o_condbit, (i), (v))
-#define DIRTY(i) gu8(g_lay.o_dirty, (i))
-#define setDIRTY(i, v) su8(g_lay.o_dirty, (i), (v))
+#define AGE(i) gf64(&GphLds::age, (i))
+#define setAGE(i, v) sf64(&GphLds::age, (i), (v))
+#define SVAGE(i) gf64(&GphLds::sv_age, (i))
+#define setSVAGE(i, v) sf64(&GphLds::sv_age, (i), (v))
+#define EVT(e) gf64(&GphLds::ev_time, (e))
+#define setEVT(e, v) sf64(&GphLds::ev_time, (e), (v))
+#define MAGE(m) gf64(&GphLds::mig_age, (m))
+#define setMAGE(m, v) sf64(&GphLds::mig_age, (m), (v))
+#define COALS(p) gf64(&GphLds::coal, (p))
+#define setCOALS(p, v) sf64(&GphLds::coal, (p), (v))
+#define MIGST(b) gf64(&GphLds::migst, (b))
+#define setMIGST(b, v) sf64(&GphLds::migst, (b), (v))
+#define RBAGE(i) gf64(&GphLds::rb_age, (i))
+#define setRBAGE(i, v) sf64(&GphLds::rb_age, (i), (v))
+#define FS(k) gf64(&GphLds::fscal, (k))
+#define setFS(k, v) sf64(&GphLds::fscal, (k), (v))
+#define FATH(i) gi16(&GphLds::father, (i))
+#define setFATH(i, v) si16(&GphLds::father, (i), (v))
+#define LEFT(i) gi16(&GphLds::left, (i))
+#define setLEFT(i, v) si16(&GphLds::left, (i), (v))
+#define RGHT(i) gi16(&GphLds::right, (i))
+#define setRGHT(i, v) si16(&GphLds::right, (i), (v))
+#define NPOP(i) gi16(&GphLds::npop, (i))
+#define setNPOP(i, v) si16(&GphLds::npop, (i), (v))
+#define NEV(i) gi16(&GphLds::nev, (i))
+#define setNEV(i, v) si16(&GphLds::nev, (i), (v))
+#define SVF(i) gi16(&GphLds::sv_father, (i))
+#define SVL(i) gi16(&GphLds::sv_left, (i))
+#define SVR(i) gi16(&GphLds::sv_right, (i))
+#define CHG(i) gi16(&GphLds::changed, (i))
+#define CHGC(i) gi16(&GphLds::changedc, (i))
+#define ENEXT(e) gi16(&GphLds::ev_next, (e))
+#define setENEXT(e, v) si16(&GphLds::ev_next, (e), (v))
+#define EPREV(e) gi16(&GphLds::ev_prev, (e))
+#define setEPREV(e, v) si16(&GphLds::ev_prev, (e), (v))
+#define ENODE(e) gi16(&GphLds::ev_node, (e))
+#define setENODE(e, v) si16(&GphLds::ev_node, (e), (v))
+#define ENLIN(e) gi16(&GphLds::ev_nlin, (e))
+#define setENLIN(e, v) si16(&GphLds::ev_nlin, (e), (v))
+#define ETYPE(e) gu8(&GphLds::ev_type, (e))
+#define setETYPE(e, v) su8(&GphLds::ev_type, (e), (v))
+#define FIRSTEV(p) gi16(&GphLds::first, (p))
+#define setFIRSTEV(p, v) si16(&GphLds::first, (p), (v))
+#define MG(m, f) gi16(&GphLds::mig_i, (m) * MG_COUNT + (f))
+#define setMG(m, f, v) si16(&GphLds::mig_i, (m) * MG_COUNT + (f), (v))
+#define LIVING(i) gi16(&GphLds::living, (i))
+#define setLIVING(i, v) si16(&GphLds::living, (i), (v))
+#define NCOAL(p) gi16(&GphLds::ncoal, (p))
+#define setNCOAL(p, v) si16(&GphLds::ncoal, (p), (v))
+#define NMIGB(b) gi16(&GphLds::nmig, (b))
+#define setNMIGB(b, v) si16(&GphLds::nmig, (b), (v))
+#define RBI(k, i) gi16(&GphLds::rb_i, (k) * GPH_CAP_RB + (i))
+#define setRBI(k, i, v) si16(&GphLds::rb_i, (k) * GPH_CAP_RB + (i), (v))
+#define ISC(k) gi32(&GphLds::iscal, (k))
+#define setISC(k, v) si32(&GphLds::iscal, (k), (v))
+#define CBIT(i) gu8(&GphLds::condbit, (i))
+#define setCBIT(i, v) su8(&GphLds::condbit, (i), (v))
+#define DIRTY(i) gu8(&GphLds::dirty, (i))
+#define setDIRTY(i, v) su8(&GphLds::dirty, (i), (v))
 // scratch
-#define DEV(inst, i) gi16(g_lay.s_dev[inst], (i))
-#define setDEV(inst, i, v) si16(g_lay.s_dev[inst], (i), (v))
-#define DCOAL(inst, i) gf64(g_lay.s_dcoal[inst], (i))
-#define setDCOAL(inst, i, v) sf64(g_lay.s_dcoal[inst], (i), (v))
-#define DMIG(inst, i) gf64(g_lay.s_dmig[inst], (i))
-#define setDMIG(inst, i, v) sf64(g_lay.s_dmig[inst], (i), (v))
-#define DPOPS(inst, i) gi16(g_lay.s_dpops[inst], (i))
-#define setDPOPS(inst, i, v) si16(g_lay.s_dpops[inst], (i), (v))
-#define DBANDS(inst, i) gi16(g_lay.s_dbands[inst], (i))
-#define setDBANDS(inst, i, v) si16(g_lay.s_dbands[inst], (i), (v))
-#define DI(inst, k) gi32(g_lay.s_di[inst], (k))
-#define setDI(inst, k, v) si32(g_lay.s_di[inst], (k), (v))
-#define SPRI(k) gi32(g_lay.s_spri, (k))
-#define setSPRI(k, v) si32(g_lay.s_spri, (k), (v))
-#define SPRA(k, i) gi16(g_lay.s_spri16, (k) * GPH_MAX_MIGS + (i))
-#define setSPRA(k, i, v) si16(g_lay.s_spri16, (k) * GPH_MAX_MIGS + (i), (v))
-#define SPRAGE(i) gf64(g_lay.s_sprf, (i))
-#define setSPRAGE(i, v) sf64(g_lay.s_sprf, (i), (v))
-#define SPRLN(r) gf64(g_lay.s_sprf, GPH_MAX_MIGS + (r))
-#define setSPRLN(r, v) sf64(g_lay.s_sprf, GPH_MAX_MIGS + (r), (v))
-#define CNT(k) gi32(g_lay.s_cnt, (k))
-#define setCNT(k, v) si32(g_lay.s_cnt, (k), (v))
+#define DEV(inst, i) gi16(&GphLds::s_dev, (inst), (i))
+#define setDEV(inst, i, v) si16(&GphLds::s_dev, (inst), (i), (v))
+#define DCOAL(inst, i) gf64(&GphLds::s_dcoal, (inst), (i))
+#define setDCOAL(inst, i, v) sf64(&GphLds::s_dcoal, (inst), (i), (v))
+#define DMIG(inst, i) gf64(&GphLds::s_dmig, (inst), (i))
+#define setDMIG(inst, i, v) sf64(&GphLds::s_dmig, (inst), (i), (v))
+#define DPOPS(inst, i) gi16(&GphLds::s_dpops, (inst), (i))
+#define setDPOPS(inst, i, v) si16(&GphLds::s_dpops, (inst), (i), (v))
+#define DBANDS(inst, i) gi16(&GphLds::s_dbands, (inst), (i))
+#define setDBANDS(inst, i, v) si16(&GphLds::s_dbands, (inst), (i), (v))
+#define DI(inst, k) RFL(gph_lds.s_di[inst][k])
+#define setDI(inst, k, v) (gph_lds.s_di[inst][k] = (v))
+#define SPRI(k) gi32(&GphLds::s_spri, (k))
+#define setSPRI(k, v) si32(&GphLds::s_spri, (k), (v))
+#define SPRA(k, i) gi16(&GphLds::s_spri16, (k) * GPH_MAX_MIGS + (i))
+#define setSPRA(k, i, v) si16(&GphLds::s_spri16, (k) * GPH_MAX_MIGS + (i), (v))
+#define SPRAGE(i) gf64(&GphLds::s_sprf, (i))
+#define setSPRAGE(i, v) sf64(&GphLds::s_sprf, (i), (v))
+#define SPRLN(r) gf64(&GphLds::s_sprf, GPH_MAX_MIGS + (r))
+#define setSPRLN(r, v) sf64(&GphLds::s_sprf, GPH_MAX_MIGS + (r), (v))
+#define CNT(k) gi32(&GphLds::s_cnt, (k))
+#define setCNT(k, v) si32(&GphLds::s_cnt, (k), (v))
 
 // ordered list of live migration bands (<= 16 entries of 4 bits): the reference keeps
 // int live_mig_bands[MAX_MIG_BANDS] with swap-removal; the order decides which band a
@@ -188,7 +188,7 @@ GPH_DEV int lik_mark_cond(int node)
   int k;
   if (CNT(CN_P) <= 0 || DIRTY(node)) return 1;
   k = ISC(IS_NCHANGEDC);
-  si16(g_lay.o_changedc, k, node);
+  si16(&GphLds::changedc, k, node);
   setISC(IS_NCHANGEDC, k + 1);
   setDIRTY(node, 1);
   setCBIT(node, CBIT(node) ^ 1);
@@ -200,12 +200,12 @@ GPH_DEV void lik_save_node(int node, int recalc)
   int k;
   if (recalc) lik_mark_cond(node);
   k = ISC(IS_NCHANGED);
-  si16(g_lay.o_changed, k, node);
+  si16(&GphLds::changed, k, node);
   setISC(IS_NCHANGED, k + 1);
   setSVAGE(node, AGE(node));
-  si16(g_lay.o_sv_father, node, FATH(node));
-  si16(g_lay.o_sv_left, node, LEFT(node));
-  si16(g_lay.o_sv_right, node, RGHT(node));
+  si16(&GphLds::sv_father, node, FATH(node));
+  si16(&GphLds::sv_left, node, LEFT(node));
+  si16(&GphLds::sv_right, node, RGHT(node));
 }
 // adjustGenNodeAge, LocusDataLikelihood.c:875-882
 GPH_DEV void lik_adjust_age(int node, double age)
@@ -276,14 +276,14 @@ GPH_DEV double edge_prob(double len)
 // LDS scratch words.
 GPH_DEV gdbl *cond_base()
 {
-  uint64_t lo = (uint32_t)gi32(g_lay.s_cntf + 8, 0), hi = (uint32_t)gi32(g_lay.s_cntf + 8, 1);
+  uint64_t lo = (uint32_t)RFL(gph_lds.s_condptr[0]), hi = (uint32_t)RFL(gph_lds.s_condptr[1]);
   return (gdbl *)(uintptr_t)(lo | (hi << 32));
 }
 GPH_DEV void set_cond_base(const void *p)
 {
   uint64_t v = (uint64_t)(uintptr_t)p;
-  si32(g_lay.s_cntf + 8, 0, (int)(uint32_t)v);
-  si32(g_lay.s_cntf + 8, 1, (int)(uint32_t)(v >> 32));
+  gph_lds.s_condptr[0] = (uint32_t)v;
+  gph_lds.s_condptr[1] = (uint32_t)(v >> 32);
 }
 // index (in doubles) of the conditional array (buffer `bit`) of internal node `node`
 GPH_DEV int cond_off(int node, int bit)
@@ -381,18 +381,18 @@ GPH_DEVNI double lik_compute(int useOld)
   /* pre-order list of needed internal nodes */
   nord = 0;
   sp = 0;
-  si16(g_lay.s_stack, sp++, node);
+  si16(&GphLds::s_stack, sp++, node);
   while (sp > 0) {
-    node = gi16(g_lay.s_stack, --sp);
+    node = gi16(&GphLds::s_stack, --sp);
     if (nord >= N) { gph_fail(100); return FS(FS_DATALNL); }
-    si16(g_lay.s_ord, nord++, node);
+    si16(&GphLds::s_ord, nord++, node);
     k = LEFT(node);
-    if (k >= n && ((need >> k) & 1)) si16(g_lay.s_stack, sp++, k);
+    if (k >= n && ((need >> k) & 1)) si16(&GphLds::s_stack, sp++, k);
     k = RGHT(node);
-    if (k >= n && ((need >> k) & 1)) si16(g_lay.s_stack, sp++, k);
+    if (k >= n && ((need >> k) & 1)) si16(&GphLds::s_stack, sp++, k);
   }
   for (i = nord - 1; i >= 0; i--) {
-    node = gi16(g_lay.s_ord, i);
+    node = gi16(&GphLds::s_ord, i);
     if (useOld) lik_mark_cond(node);
     prune_node(node);
   }
@@ -419,7 +419,7 @@ GPH_DEVNI double lik_compute(int useOld)
     }
   }
   setFS(FS_DATALNL, lnl);
-  if (useOld) sf64(g_lay.s_cntf, 0, gf64(g_lay.s_cntf, 0) + (96.0 * nord * P + 20.0 * N + 8.0 * U + 8.0));
+  if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (96.0 * nord * P + 20.0 * N + 8.0 * U + 8.0));
   return lnl;
 }
 
@@ -502,10 +502,10 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
   for (node = 0; node < g_lay.N; node++) {
     f = FATH(node);
     if (node == exc || AGE(node) > time || (f >= 0 && AGE(f) <= time)) continue;
-    if (pop == g_lay.rootPop) { si16(g_lay.s_targets, num++, node); continue; }
+    if (pop == g_lay.rootPop) { si16(&GphLds::s_targets, num++, node); continue; }
     mig = find_last_mig(node, time);
     pop1 = (mig >= 0) ? MG(mig, MG_SPOP) : NPOP(node);
-    if ((g_model.isAnc[pop] >> pop1) & 1) si16(g_lay.s_targets, num++, node);
+    if ((g_model.isAnc[pop] >> pop1) & 1) si16(&GphLds::s_targets, num++, node);
   }
   return num;
 }
@@ -584,26 +584,26 @@ GPH_DEVNI double recalc_stats(int pop)
     id = ENODE(ev);
     t = EVT(ev);
     cs += n * (n - 1) * t;
-    for (b = 0; b < live.n; b++) sf64(g_lay.s_chkmig, ll_get(live, b), gf64(g_lay.s_chkmig, ll_get(live, b)) + n * t);
+    for (b = 0; b < live.n; b++) sf64(&GphLds::s_chkmig, ll_get(live, b), gf64(&GphLds::s_chkmig, ll_get(live, b)) + n * t);
     switch (ETYPE(ev)) {
     case GPH_SAMPLES_START: n += g_model.samplesPerPop[pop]; break;
     case GPH_COAL: nc++; n--; break;
     case GPH_IN_MIG: {
       int bb = MG(id, MG_BAND);
-      si16(g_lay.s_chknm, bb, gi16(g_lay.s_chknm, bb) + 1);
+      si16(&GphLds::s_chknm, bb, gi16(&GphLds::s_chknm, bb) + 1);
       n--;
       break;
     }
     case GPH_OUT_MIG: n++; break;
     case GPH_MIG_BAND_START:
       ll_push(live, id);
-      si16(g_lay.s_chknm, id, 0);
-      sf64(g_lay.s_chkmig, id, 0.0);
+      si16(&GphLds::s_chknm, id, 0);
+      sf64(&GphLds::s_chkmig, id, 0.0);
       break;
     case GPH_MIG_BAND_END:
-      delta -= (gf64(g_lay.s_chkmig, id) - MIGST(id)) * g_model.migRate[id];
-      setMIGST(id, gf64(g_lay.s_chkmig, id));
-      setNMIGB(id, gi16(g_lay.s_chknm, id));
+      delta -= (gf64(&GphLds::s_chkmig, id) - MIGST(id)) * g_model.migRate[id];
+      setMIGST(id, gf64(&GphLds::s_chkmig, id));
+      setNMIGB(id, gi16(&GphLds::s_chknm, id));
       b = ll_find(live, id);
       if (b == live.n) { gph_fail(25); return 0.0; }
       ll_swap_remove(live, b);
@@ -1062,7 +1062,7 @@ GPH_DEVNI int trace_lineage(int node)
           num_targets = edges_for_time_pop((age - t) + EVT(ev) / 2, pop, node);
           if (num_targets != ENLIN(ev)) { gph_fail(11); break; }
           i = (int)((event_sample - mig_rate) * theta / 2);
-          target = gi16(g_lay.s_targets, i);
+          target = gi16(&GphLds::s_targets, i);
           lik_spr(node, target, age);
           setSPRI(SI_FPOP_NEW, pop);
           setSPRI(SI_TARGET, target);
@@ -1197,12 +1197,12 @@ GPH_DEV int check_gtree_structure()
   LiveList live = {0, 0};
   double age, dt, PREC = 0.0000000001, cs;
   /* lineages entering each population: LDS work list (s_stack is free here) */
-  for (pop = 0; pop < g_lay.K; pop++) si16(g_lay.s_stack, pop, 0);
+  for (pop = 0; pop < g_lay.K; pop++) si16(&GphLds::s_stack, pop, 0);
   for (i = 0; i < g_lay.K; i++) {
     pop = g_model.postOrder[i];
     cs = 0.0;
     nc = 0;
-    n = gi16(g_lay.s_stack, pop);
+    n = gi16(&GphLds::s_stack, pop);
     age = g_model.popAge[pop];
     live.n = 0;
     int guard = 0;
@@ -1214,7 +1214,7 @@ GPH_DEV int check_gtree_structure()
       dt = EVT(ev);
       age += dt;
       cs += n * (n - 1) * dt;
-      for (b = 0; b < live.n; b++) sf64(g_lay.s_chkmig, ll_get(live, b), gf64(g_lay.s_chkmig, ll_get(live, b)) + n * dt);
+      for (b = 0; b < live.n; b++) sf64(&GphLds::s_chkmig, ll_get(live, b), gf64(&GphLds::s_chkmig, ll_get(live, b)) + n * dt);
       switch (ETYPE(ev)) {
       case GPH_SAMPLES_START:
         n += g_model.samplesPerPop[pop];
@@ -1228,7 +1228,7 @@ GPH_DEV int check_gtree_structure()
         break;
       case GPH_IN_MIG: {
         int bb = MG(id, MG_BAND);
-        si16(g_lay.s_chknm, bb, gi16(g_lay.s_chknm, bb) + 1);
+        si16(&GphLds::s_chknm, bb, gi16(&GphLds::s_chknm, bb) + 1);
         n--;
         if (fabs(MAGE(id) - age) > PREC || MG(id, MG_TEV) != ev) res = 0;
         break;
@@ -1239,8 +1239,8 @@ GPH_DEV int check_gtree_structure()
         break;
       case GPH_MIG_BAND_START:
         ll_push(live, id);
-        si16(g_lay.s_chknm, id, 0);
-        sf64(g_lay.s_chkmig, id, 0.0);
+        si16(&GphLds::s_chknm, id, 0);
+        sf64(&GphLds::s_chkmig, id, 0.0);
         if (fabs(g_model.bandStart[id] - age) > PREC) res = 0;
         break;
       case GPH_MIG_BAND_END:
@@ -1252,25 +1252,25 @@ GPH_DEV int check_gtree_structure()
       case GPH_END_CHAIN:
         if (id != pop || live.n != 0 || ENEXT(ev) >= 0) res = 0;
         if (pop != g_lay.rootPop) {
-          si16(g_lay.s_stack, g_model.popFather[pop], gi16(g_lay.s_stack, g_model.popFather[pop]) + n);
+          si16(&GphLds::s_stack, g_model.popFather[pop], gi16(&GphLds::s_stack, g_model.popFather[pop]) + n);
           if (fabs(g_model.popAge[g_model.popFather[pop]] - age) > PREC) res = 0;
         }
         break;
       default: res = 0; break;
       }
     }
-    sf64(g_lay.s_chkcoal, pop, cs);
-    si16(g_lay.s_chknc, pop, nc);
+    sf64(&GphLds::s_chkcoal, pop, cs);
+    si16(&GphLds::s_chknc, pop, nc);
   }
   for (pop = 0; pop < g_lay.K; pop++) {
-    if (fabs(gf64(g_lay.s_chkcoal, pop) - COALS(pop)) > PREC) res = 0;
-    setCOALS(pop, gf64(g_lay.s_chkcoal, pop));
-    if (gi16(g_lay.s_chknc, pop) != NCOAL(pop)) res = 0;
+    if (fabs(gf64(&GphLds::s_chkcoal, pop) - COALS(pop)) > PREC) res = 0;
+    setCOALS(pop, gf64(&GphLds::s_chkcoal, pop));
+    if (gi16(&GphLds::s_chknc, pop) != NCOAL(pop)) res = 0;
   }
   for (b = 0; b < g_lay.B; b++) {
-    if (fabs(gf64(g_lay.s_chkmig, b) - MIGST(b)) > PREC) res = 0;
-    setMIGST(b, gf64(g_lay.s_chkmig, b));
-    if (gi16(g_lay.s_chknm, b) != NMIGB(b)) res = 0;
+    if (fabs(gf64(&GphLds::s_chkmig, b) - MIGST(b)) > PREC) res = 0;
+    setMIGST(b, gf64(&GphLds::s_chkmig, b));
+    if (gi16(&GphLds::s_chknm, b) != NMIGB(b)) res = 0;
   }
   return res;
 }

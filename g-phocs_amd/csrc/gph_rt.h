@@ -28,6 +28,7 @@
 #define GPH_SYNC() ((void)0)
 #define RFL(x) (x)
 extern thread_local char *gph_sm;
+extern thread_local GphLds gph_lds;
 extern GphLayout g_lay;
 extern GphModel g_model;
 #else
@@ -39,7 +40,8 @@ extern GphModel g_model;
 #define GPH_NLANES GPH_WAVE
 #define GPH_SYNC() __syncthreads()
 #define RFL(x) __builtin_amdgcn_readfirstlane((int)(x))
-extern __shared__ __attribute__((aligned(16))) char gph_sm[];
+extern __shared__ __attribute__((aligned(16))) char gph_sm[];   // dynamic part: sequence block + per-pattern terms
+__shared__ GphLds gph_lds;   // static part: the locus image (gph_types.h); this header is included by one TU only
 extern __constant__ GphLayout g_lay;
 extern __constant__ GphModel g_model;
 #endif
@@ -58,6 +60,24 @@ typedef GPH_LDS uint8_t lu8;
 typedef GPH_LDS char lchar;
 
 #define GPH_SMB ((lchar *)gph_sm)
+// static-image accessors: `m` is a pointer to an array member of GphLds; after inlining the
+// address is a compile-time constant + index.  Integer loads that steer control flow are
+// made wave-uniform (v_readfirstlane) so that branches are scalar.
+template <class T, int NN> GPH_DEV double gf64(T (GphLds::*m)[NN], int i) { return (gph_lds.*m)[i]; }
+template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[NN], int i, double v) { (gph_lds.*m)[i] = v; }
+template <class T, int NN> GPH_DEV int gi16(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[i]); }
+template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[i] = (T)v; }
+template <class T, int NN> GPH_DEV int gi32(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[i]); }
+template <class T, int NN> GPH_DEV void si32(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[i] = (T)v; }
+template <class T, int NN> GPH_DEV int gu8(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[i]); }
+template <class T, int NN> GPH_DEV void su8(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[i] = (T)v; }
+template <class T, int NN> GPH_DEV int gu8v(T (GphLds::*m)[NN], int i) { return (gph_lds.*m)[i]; }
+// two-dimensional scratch arrays [2][..] (instance 0/1 of the pending stat deltas)
+template <class T, int NN> GPH_DEV double gf64(T (GphLds::*m)[2][NN], int k, int i) { return (gph_lds.*m)[k][i]; }
+template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[2][NN], int k, int i, double v) { (gph_lds.*m)[k][i] = v; }
+template <class T, int NN> GPH_DEV int gi16(T (GphLds::*m)[2][NN], int k, int i) { return RFL((gph_lds.*m)[k][i]); }
+template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[2][NN], int k, int i, int v) { (gph_lds.*m)[k][i] = (T)v; }
+// dynamic-part accessors (byte offset from g_lay.q_* / g_lay.s_terms): lane-varying, pruning only
 GPH_DEV double gf64(int off, int i) { return ((lf64 *)(GPH_SMB + off))[i]; }
 GPH_DEV void sf64(int off, int i, double v) { ((lf64 *)(GPH_SMB + off))[i] = v; }
 GPH_DEV int gi16(int off, int i) { return RFL(((li16 *)(GPH_SMB + off))[i]); }

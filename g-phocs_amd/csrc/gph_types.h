@@ -27,6 +27,8 @@
 #define GPH_MAXN 63        // genealogy nodes per locus (n <= 32 leaves)
 #define GPH_OLDAGE 999.0   // patch.h:21
 #define GPH_WAVE 64
+#define FS_COUNT_ 5
+#define IS_COUNT_ 12
 
 enum { GPH_COAL = 0, GPH_IN_MIG, GPH_OUT_MIG, GPH_MIG_BAND_START, GPH_MIG_BAND_END,
        GPH_SAMPLES_START, GPH_END_CHAIN, GPH_DUMMY };
@@ -93,6 +95,47 @@ enum { MG_BRANCH = 0, MG_BAND, MG_SPOP, MG_TPOP, MG_SEV, MG_TEV, MG_COUNT };
 #define GPH_OUT_SLOTS 16
 enum { OUT_ACCEPT = 0, OUT_DDATA, OUT_DLOG, OUT_EVALS, OUT_EVALNODES, OUT_EVALBYTES,
        OUT_NTJ0, OUT_NTJ1, OUT_CONFLICT, OUT_ERROR, OUT_GENLNL, OUT_DATALNL, OUT_NMIGS };
+
+// ---------------------------------------------------------------------------------------
+// LDS image of one locus.  Statically laid out with compile-time capacities so that every
+// access is `ds_read/ds_write <constant offset>(index)` and the compiler knows that different
+// arrays do not alias (loads are hoisted, paired and kept in registers) -- with run-time
+// offsets every access cost an extra scalar add + v_mov and serialised behind every store.
+// HBM pages stay COMPACT (GphLayout, actual n/K/B); stage-in/out copies array by array.
+// Capacities cover every BASELINE config (config 5: 20 leaves, 13 populations, 4 bands).
+#ifndef GPH_CAP_LEAVES
+#define GPH_CAP_LEAVES 24
+#endif
+#ifndef GPH_CAP_K
+#define GPH_CAP_K 16
+#endif
+#ifndef GPH_CAP_B
+#define GPH_CAP_B 8
+#endif
+#define GPH_CAP_N (2 * GPH_CAP_LEAVES - 1)
+#define GPH_CAP_E (2 * GPH_CAP_LEAVES + 4 * GPH_MAX_MIGS + 3 * GPH_CAP_B + GPH_CAP_K + 10)
+#define GPH_CAP_RB (GPH_MAX_MIGS + 2 * GPH_CAP_B)
+
+struct GphLds {
+  // ---- page (mirrors the HBM page arrays, GphLayout o_*)
+  double age[GPH_CAP_N], sv_age[GPH_CAP_N], ev_time[GPH_CAP_E], mig_age[GPH_MAX_MIGS];
+  double coal[GPH_CAP_K], migst[GPH_CAP_B], rb_age[GPH_CAP_RB], fscal[FS_COUNT_];
+  int32_t iscal[IS_COUNT_];
+  int16_t father[GPH_CAP_N], left[GPH_CAP_N], right[GPH_CAP_N], npop[GPH_CAP_N], nev[GPH_CAP_N];
+  int16_t sv_father[GPH_CAP_N], sv_left[GPH_CAP_N], sv_right[GPH_CAP_N];
+  int16_t changed[2 * GPH_CAP_N], changedc[2 * GPH_CAP_N];
+  int16_t ev_next[GPH_CAP_E], ev_prev[GPH_CAP_E], ev_node[GPH_CAP_E], ev_nlin[GPH_CAP_E], first[GPH_CAP_K];
+  int16_t mig_i[GPH_MAX_MIGS * 6], living[GPH_MAX_MIGS], ncoal[GPH_CAP_K], nmig[GPH_CAP_B], rb_i[3 * GPH_CAP_RB];
+  uint8_t ev_type[GPH_CAP_E], condbit[GPH_CAP_N], dirty[GPH_CAP_N];
+  // ---- LDS-only scratch: pending-proposal storage of GENETREE_STATS_DELTA x2 (patch.h:60-72),
+  // MIG_SPR_STATS (patch.h:97-105), genetree_stats_check (patch.h:109), pruning work lists
+  double s_dcoal[2][GPH_CAP_K], s_dmig[2][GPH_CAP_B], s_sprf[GPH_MAX_MIGS + 2];
+  double s_chkcoal[GPH_CAP_K], s_chkmig[GPH_CAP_B], s_cntf[2];
+  int32_t s_di[2][8], s_spri[8], s_cnt[8];
+  uint32_t s_condptr[2];
+  int16_t s_dev[2][GPH_CAP_E], s_dpops[2][GPH_CAP_K], s_dbands[2][GPH_CAP_B], s_spri16[4 * GPH_MAX_MIGS];
+  int16_t s_ord[GPH_CAP_N + 1], s_stack[GPH_CAP_N + 1], s_targets[GPH_CAP_N + 1], s_chknc[GPH_CAP_K], s_chknm[GPH_CAP_B];
+};
 
 // arguments of the tau-evaluate kernel (host part of UpdateTau, GPhoCS.c:3224-3461)
 struct GphTauArgs {
