@@ -7,6 +7,7 @@
 // shared between workgroups, so L2 affinity is irrelevant).
 #include <stdio.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <string.h>
 #include <vector>
 #include <algorithm>
@@ -175,23 +176,23 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   y.n = n; y.N = 2 * n - 1; y.K = K; y.Kc = Kc; y.B = B; y.rootPop = rootPop;
   y.E = 2 * n + 4 * GPH_MAX_MIGS + 3 * B + K + 10;   // event pool, patch.c:92
   y.RB = GPH_MAX_MIGS + 2 * B;
+  // the HBM page IS the page part of the static LDS image (GphLds, capacity-sized arrays):
+  // staging is one fully coalesced 16-B/lane copy
   int o = 0;
   auto f64 = [&](int cnt) { o = align_up(o, 8); int r = o; o += 8 * cnt; return r; };
-  auto i16 = [&](int cnt) { o = align_up(o, 2); int r = o; o += 2 * cnt; return r; };
-  auto i32 = [&](int cnt) { o = align_up(o, 4); int r = o; o += 4 * cnt; return r; };
-  auto u8 = [&](int cnt) { int r = o; o += cnt; return r; };
-  y.o_age = f64(y.N); y.o_sv_age = f64(y.N); y.o_ev_time = f64(y.E); y.o_mig_age = f64(GPH_MAX_MIGS);
-  y.o_coal = f64(K); y.o_migst = f64(B > 0 ? B : 1); y.o_rb_age = f64(y.RB); y.o_fscal = f64(FS_COUNT);
-  y.o_iscal = i32(IS_COUNT);
-  y.o_father = i16(y.N); y.o_left = i16(y.N); y.o_right = i16(y.N); y.o_npop = i16(y.N); y.o_nev = i16(y.N);
-  y.o_sv_father = i16(y.N); y.o_sv_left = i16(y.N); y.o_sv_right = i16(y.N);
-  y.o_changed = i16(2 * y.N); y.o_changedc = i16(2 * y.N);
-  y.o_ev_next = i16(y.E); y.o_ev_prev = i16(y.E); y.o_ev_node = i16(y.E); y.o_ev_nlin = i16(y.E);
-  y.o_first = i16(K);
-  y.o_mig_i = i16(GPH_MAX_MIGS * MG_COUNT); y.o_living = i16(GPH_MAX_MIGS);
-  y.o_ncoal = i16(K); y.o_nmig = i16(B > 0 ? B : 1); y.o_rb_i = i16(3 * y.RB);
-  y.o_ev_type = u8(y.E); y.o_condbit = u8(y.N); y.o_dirty = u8(y.N);
-  y.page_bytes = align_up(o, 16);
+#define OFS(f) ((int32_t)offsetof(GphLds, f))
+  y.o_age = OFS(age); y.o_sv_age = OFS(sv_age); y.o_ev_time = OFS(ev_time); y.o_mig_age = OFS(mig_age);
+  y.o_coal = OFS(coal); y.o_migst = OFS(migst); y.o_rb_age = OFS(rb_age); y.o_fscal = OFS(fscal);
+  y.o_iscal = OFS(iscal);
+  y.o_father = OFS(father); y.o_left = OFS(left); y.o_right = OFS(right); y.o_npop = OFS(npop); y.o_nev = OFS(nev);
+  y.o_sv_father = OFS(sv_father); y.o_sv_left = OFS(sv_left); y.o_sv_right = OFS(sv_right);
+  y.o_changed = OFS(changed); y.o_changedc = OFS(changedc);
+  y.o_ev_next = OFS(ev_next); y.o_ev_prev = OFS(ev_prev); y.o_ev_node = OFS(ev_node); y.o_ev_nlin = OFS(ev_nlin);
+  y.o_first = OFS(first);
+  y.o_mig_i = OFS(mig_i); y.o_living = OFS(living); y.o_ncoal = OFS(ncoal); y.o_nmig = OFS(nmig); y.o_rb_i = OFS(rb_i);
+  y.o_ev_type = OFS(ev_type); y.o_condbit = OFS(condbit); y.o_dirty = OFS(dirty);
+  y.page_bytes = align_up(OFS(s_dcoal), 16);
+#undef OFS
   // dynamic LDS: sequence block (also the HBM block format) + per-pattern terms of the root
   // reduction; the locus image itself is the static GphLds
   o = 0;

@@ -41,51 +41,30 @@ GPH_DEV void copy16_g2l(int lds_off, const char *src, int bytes)
   for (i = GPH_LANE; i < n16; i += GPH_NLANES) d[i] = s[i];
 #endif
 }
-// compact HBM page (GphLayout offsets, actual n/K/B) <-> static LDS image (GphLds, capacities)
-template <class T, int NN> GPH_DEV void pg_in(T (GphLds::*m)[NN], const char *page, int off, int count)
-{
-  const T *s = (const T *)(page + off);
-  for (int i = GPH_LANE; i < count; i += GPH_NLANES) (gph_lds.*m)[i] = s[i];
-}
-template <class T, int NN> GPH_DEV void pg_out(T (GphLds::*m)[NN], char *page, int off, int count)
-{
-  T *d = (T *)(page + off);
-  for (int i = GPH_LANE; i < count; i += GPH_NLANES) d[i] = (gph_lds.*m)[i];
-}
-#define GPH_PAGE_FIELDS(X, page)                                                                   \
-  X(&GphLds::age, page, g_lay.o_age, g_lay.N) X(&GphLds::sv_age, page, g_lay.o_sv_age, g_lay.N)     \
-  X(&GphLds::ev_time, page, g_lay.o_ev_time, g_lay.E) X(&GphLds::mig_age, page, g_lay.o_mig_age, GPH_MAX_MIGS) \
-  X(&GphLds::coal, page, g_lay.o_coal, g_lay.K) X(&GphLds::migst, page, g_lay.o_migst, g_lay.B)     \
-  X(&GphLds::rb_age, page, g_lay.o_rb_age, g_lay.RB) X(&GphLds::fscal, page, g_lay.o_fscal, FS_COUNT) \
-  X(&GphLds::iscal, page, g_lay.o_iscal, IS_COUNT)                                                  \
-  X(&GphLds::father, page, g_lay.o_father, g_lay.N) X(&GphLds::left, page, g_lay.o_left, g_lay.N)   \
-  X(&GphLds::right, page, g_lay.o_right, g_lay.N) X(&GphLds::npop, page, g_lay.o_npop, g_lay.N)     \
-  X(&GphLds::nev, page, g_lay.o_nev, g_lay.N) X(&GphLds::sv_father, page, g_lay.o_sv_father, g_lay.N) \
-  X(&GphLds::sv_left, page, g_lay.o_sv_left, g_lay.N) X(&GphLds::sv_right, page, g_lay.o_sv_right, g_lay.N) \
-  X(&GphLds::changed, page, g_lay.o_changed, 2 * g_lay.N) X(&GphLds::changedc, page, g_lay.o_changedc, 2 * g_lay.N) \
-  X(&GphLds::ev_next, page, g_lay.o_ev_next, g_lay.E) X(&GphLds::ev_prev, page, g_lay.o_ev_prev, g_lay.E) \
-  X(&GphLds::ev_node, page, g_lay.o_ev_node, g_lay.E) X(&GphLds::ev_nlin, page, g_lay.o_ev_nlin, g_lay.E) \
-  X(&GphLds::first, page, g_lay.o_first, g_lay.K) X(&GphLds::mig_i, page, g_lay.o_mig_i, GPH_MAX_MIGS * MG_COUNT) \
-  X(&GphLds::living, page, g_lay.o_living, GPH_MAX_MIGS) X(&GphLds::ncoal, page, g_lay.o_ncoal, g_lay.K) \
-  X(&GphLds::nmig, page, g_lay.o_nmig, g_lay.B)                                                     \
-  X(&GphLds::ev_type, page, g_lay.o_ev_type, g_lay.E) X(&GphLds::condbit, page, g_lay.o_condbit, g_lay.N) \
-  X(&GphLds::dirty, page, g_lay.o_dirty, g_lay.N)
-#define GPH_X_IN(m, page, off, cnt) pg_in(m, page, off, cnt);
-#define GPH_X_OUT(m, page, off, cnt) pg_out(m, page, off, cnt);
-
+// HBM page <-> page part of the static LDS image: identical layout, one coalesced copy
 GPH_DEV void page_in(const char *page)
 {
-  GPH_PAGE_FIELDS(GPH_X_IN, page)
-  for (int k = 0; k < 3; k++)   /* rb_i: [3][RB] in HBM, [3][GPH_CAP_RB] in LDS */
-    for (int i = GPH_LANE; i < g_lay.RB; i += GPH_NLANES)
-      gph_lds.rb_i[k * GPH_CAP_RB + i] = ((const int16_t *)(page + g_lay.o_rb_i))[k * g_lay.RB + i];
+#ifdef GPH_HOSTEMU
+  memcpy((char *)&gph_lds, page, g_lay.page_bytes);
+#else
+  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
+  typedef GPH_LDS gu32x4 luint4;
+  const gu32x4 *s = (const gu32x4 *)page;
+  luint4 *d = (luint4 *)&gph_lds;
+  for (int i = GPH_LANE; i < (g_lay.page_bytes >> 4); i += GPH_NLANES) d[i] = s[i];
+#endif
 }
 GPH_DEV void page_out(char *page)
 {
-  GPH_PAGE_FIELDS(GPH_X_OUT, page)
-  for (int k = 0; k < 3; k++)
-    for (int i = GPH_LANE; i < g_lay.RB; i += GPH_NLANES)
-      ((int16_t *)(page + g_lay.o_rb_i))[k * g_lay.RB + i] = gph_lds.rb_i[k * GPH_CAP_RB + i];
+#ifdef GPH_HOSTEMU
+  memcpy(page, (const char *)&gph_lds, g_lay.page_bytes);
+#else
+  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
+  typedef GPH_LDS gu32x4 luint4;
+  gu32x4 *d = (gu32x4 *)page;
+  const luint4 *s = (const luint4 *)&gph_lds;
+  for (int i = GPH_LANE; i < (g_lay.page_bytes >> 4); i += GPH_NLANES) d[i] = s[i];
+#endif
 }
 
 GPH_DEV void scratch_init(const GphDev &D, int g)
@@ -236,14 +215,14 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune)
     }
     tnew = t + finetune * l_rnd2normal8();
     tnew = l_reflect(tnew, tb0, tb1);
-    if (fabs(tnew - t) < 1e-15) { acc++; continue; }
+    if (UNI(fabs(tnew - t) < 1e-15)) { acc++; continue; }
     lik_adjust_age(inode, tnew);
     lnLd = -FS(FS_DATALNL);
     lnLd += lik_compute(1);
     dgen = consider_event_move(0, NEV(inode), pop, t, pop, tnew);
     lnacc = dgen + lnLd;
     if (gph_failed()) break;
-    if (lnacc >= 0 || l_rndu() < gph_exp(lnacc)) {
+    if (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp(lnacc))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
       dData += lnLd;
@@ -287,12 +266,12 @@ GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune)
     }
     tnew = t + finetune * l_rnd2normal8();
     tnew = l_reflect(tnew, tb0, tb1);
-    if (fabs(tnew - t) < 1e-15) { acc++; continue; }
+    if (UNI(fabs(tnew - t) < 1e-15)) { acc++; continue; }
     dgen = consider_event_move(0, ev_s, pop_s, t, pop_s, tnew);
     dgen += consider_event_move(1, ev_t, pop_t, t, pop_t, tnew);
     lnacc = dgen;
     if (gph_failed()) break;
-    if (lnacc >= 0 || l_rndu() < gph_exp(lnacc)) {
+    if (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp(lnacc))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
       dLog += dgen / D.Ltot;
@@ -326,7 +305,7 @@ GPH_DEV void sweep_spr(const GphDev &D, int g)
     lnLd += lik_compute(1);
     lnacc = lnLd;
     if (gph_failed()) break;
-    if (res >= 0 && (lnacc >= 0 || l_rndu() < gph_exp(lnacc))) {
+    if (res >= 0 && (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp(lnacc)))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + (SPRLN(1) - SPRLN(0)));
       dData += lnLd;

@@ -141,7 +141,7 @@ GPH_DEV double l_rndnormal()
     u = 2 * l_rndu() - 1;
     v = 2 * l_rndu() - 1;
     s = u * u + v * v;
-    if (s > 0 && s < 1) break;
+    if (UNI(s > 0 && s < 1)) break;
   }
   s = sqrt(-2. * gph_log(s) / s);
   return u * s;
@@ -153,7 +153,7 @@ GPH_DEV double l_rnd2normal8()
   double m2N = sqrt(m2s2 / (m2s2 + 1.));
   double s2N = sqrt(1. / (m2s2 + 1.));
   double z = m2N + l_rndnormal() * s2N;
-  z = l_rndu() < 0.5 ? z : -z;
+  z = UNI(l_rndu() < 0.5) ? z : -z;
   return z;
 }
 // reflect, utils.c:333-398
@@ -163,18 +163,18 @@ GPH_DEV double l_reflect(double x, double a, double b)
   double xnew, di;
   a += slack;
   b -= slack;
-  if (b <= a) return (a + b) / 2.;
-  if (x < b && x > a) return x;
+  if (UNI(b <= a)) return (a + b) / 2.;
+  if (UNI(x < b && x > a)) return x;
   xnew = x;
-  if (xnew <= a) xnew = 2. * a - xnew;
+  if (UNI(xnew <= a)) xnew = 2. * a - xnew;
   di = 2. * (b - a);
   xnew = xnew - di * floor((xnew - a) / di);
-  if (xnew >= b) xnew = 2. * b - xnew;
+  if (UNI(xnew >= b)) xnew = 2. * b - xnew;
   /* the reference loops here until the value is inside; landing exactly on a bound
    * ping-pongs forever there.  A wavefront must not hang: bail out after 64 folds. */
   int guard = 0;
-  while (xnew <= a || xnew >= b) {
-    if (xnew >= b) xnew = 2. * b - xnew;
+  while (UNI(xnew <= a || xnew >= b)) {
+    if (UNI(xnew >= b)) xnew = 2. * b - xnew;
     else xnew = 2 * a - xnew;
     if (++guard > 64) { gph_fail(90); return (a + b) / 2.; }
   }
@@ -354,6 +354,7 @@ GPH_DEV void prune_node(int node)
 GPH_DEVNI double lik_compute(int useOld)
 {
   const int n = g_lay.n, N = g_lay.N;
+  useOld = RFL(useOld);
   int P = CNT(CN_P), i, node, k, sp, nord, ncc, U;
   uint64_t need = 0;
   double lnl;
@@ -501,7 +502,7 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
   if (g_model.popAge[pop] > time + 0.0000001) return 0;
   for (node = 0; node < g_lay.N; node++) {
     f = FATH(node);
-    if (node == exc || AGE(node) > time || (f >= 0 && AGE(f) <= time)) continue;
+    if (node == exc || UNI(AGE(node) > time) || (f >= 0 && UNI(AGE(f) <= time))) continue;
     if (pop == g_lay.rootPop) { si16(&GphLds::s_targets, num++, node); continue; }
     mig = find_last_mig(node, time);
     pop1 = (mig >= 0) ? MG(mig, MG_SPOP) : NPOP(node);
@@ -553,16 +554,17 @@ GPH_DEV int create_event_before(int pop, int ev, double elapsed)
 GPH_DEVNI int create_event(int pop, double age)
 {
   int ev;
+  pop = RFL(pop);
   double dt = age - g_model.popAge[pop];
-  if (dt < 0) return -1;
-  if (pop != g_lay.rootPop && age > g_model.popAge[g_model.popFather[pop]] + 0.000001) return -1;
+  if (UNI(dt < 0)) return -1;
+  if (pop != g_lay.rootPop && UNI(age > g_model.popAge[g_model.popFather[pop]] + 0.000001)) return -1;
   int guard = 0;
-  for (ev = FIRSTEV(pop); ETYPE(ev) != GPH_END_CHAIN && EVT(ev) < dt; ev = ENEXT(ev)) {
+  for (ev = FIRSTEV(pop); ETYPE(ev) != GPH_END_CHAIN && UNI(EVT(ev) < dt); ev = ENEXT(ev)) {
     dt -= EVT(ev);
     if (++guard > g_lay.E || ENEXT(ev) < 0) { gph_fail(92); return -1; }
   }
-  if (EVT(ev) < dt) {
-    if (EVT(ev) < dt - 0.000001) { gph_fail(18); return -1; }
+  if (UNI(EVT(ev) < dt)) {
+    if (UNI(EVT(ev) < dt - 0.000001)) { gph_fail(18); return -1; }
     dt = EVT(ev);
   }
   return create_event_before(pop, ev, dt);
@@ -572,6 +574,7 @@ GPH_DEVNI int create_event(int pop, double age)
 // here; the engine instead re-reduces the per-locus statistics after the kernel.
 GPH_DEVNI double recalc_stats(int pop)
 {
+  pop = RFL(pop);
   int n, id, b, ev, nc = 0;
   LiveList live = {0, 0};
   double t, delta = 0.0, cs = 0.0;
@@ -770,6 +773,7 @@ GPH_DEVNI double consider_event_move(int inst, int event_id, int source_pop, dou
 {
   int new_event, bottom_event, top_event, bottom_pop, dlin;
   double top_age, bottom_age, r;
+  inst = RFL(inst); event_id = RFL(event_id); source_pop = RFL(source_pop); target_pop = RFL(target_pop);
   new_event = create_event(target_pop, new_age);
   if (new_event < 0) { gph_fail(13); return 0.0; }
   setDI(inst, DI_ORIG, event_id);
@@ -850,6 +854,7 @@ GPH_DEVNI double rubber_band(int pop, double static_point, double moving_point, 
 {
   int i, ev, b, node_id, num_lins, count_events = 0, flag, ty;
   LiveList live = {0, 0};
+  pop = RFL(pop); post = RFL(post);
   double age, dt, mig_rate = 0.0, mig_delta, coal_delta = 0.0, lnLd = 0.0, age1;
   double fm1 = factor - 1.0;
   double start_time = gmin2(static_point, moving_point);
@@ -859,12 +864,12 @@ GPH_DEVNI double rubber_band(int pop, double static_point, double moving_point, 
   age = g_model.popAge[pop];
   flag = (age >= start_time);
   int guard = 0;
-  while (age < end_time) {
+  while (UNI(age < end_time)) {
     if (ev == -1) { gph_fail(11); break; }
     if (++guard > g_lay.E) { gph_fail(95); break; }
     dt = gmin2(EVT(ev), end_time - age);
     age += dt;
-    if (!flag && age > start_time) { flag = 1; dt = age - start_time; }
+    if (!flag && UNI(age > start_time)) { flag = 1; dt = age - start_time; }
     if (flag) {
       dt *= fm1;
       num_lins = ENLIN(ev);
@@ -877,7 +882,7 @@ GPH_DEVNI double rubber_band(int pop, double static_point, double moving_point, 
       }
     }
     ty = ETYPE(ev);
-    if (age >= end_time && ty != GPH_SAMPLES_START) break;
+    if (UNI(age >= end_time) && ty != GPH_SAMPLES_START) break;
     node_id = ENODE(ev);
     switch (ty) {
     case GPH_COAL:
@@ -962,6 +967,7 @@ template <int RECONNECT>
 GPH_DEVNI int trace_lineage(int node)
 {
   const int inst = RECONNECT;
+  node = RFL(node);
   int i, pop, ev, node_id, b = -1, mig_source, proceed;
   LiveList live = {0, 0};
   int target, num_targets, nev = 0;
@@ -1030,15 +1036,15 @@ GPH_DEVNI int trace_lineage(int node)
       }
     } else {
       rate = mig_rate + 2 * ENLIN(ev) / theta;
-      if (rate <= 0) t = EVT(ev);
+      if (UNI(rate <= 0)) t = EVT(ev);
       else t = -(1 / rate) * gph_log(l_rndu());
-      if (t >= EVT(ev)) {
+      if (UNI(t >= EVT(ev))) {
         t = EVT(ev);
         age += t;
       } else {
         age += t;
         event_sample = rate * l_rndu();
-        if (event_sample < mig_rate) {
+        if (UNI(event_sample < mig_rate)) {
           int k = SPRI(SI_NNEW);
           if (GPH_MAX_MIGS <= ISC(IS_NUM_MIGS) + k - SPRI(SI_NOLD)) {
             setCNT(CN_NOTENOUGH, CNT(CN_NOTENOUGH) + 1);

@@ -52,6 +52,23 @@ extern __constant__ GphModel g_model;
 #define GPH_GLB __attribute__((address_space(1)))
 #endif
 typedef GPH_GLB double gdbl;   // conditional-likelihood arrays live in global memory (L2 / Infinity Cache)
+// wave-uniform helpers: every lane holds the same value; moving it through SGPRs lets the
+// compiler use scalar loads for table look-ups and scalar branches for control flow
+#ifdef GPH_HOSTEMU
+#define RFLD(x) (x)
+#define UNI(c) (c)
+#else
+__device__ inline double gph_rfl64(double x)
+{
+  union { double d; int32_t i[2]; } v;
+  v.d = x;
+  v.i[0] = __builtin_amdgcn_readfirstlane(v.i[0]);
+  v.i[1] = __builtin_amdgcn_readfirstlane(v.i[1]);
+  return v.d;
+}
+#define RFLD(x) gph_rfl64(x)
+#define UNI(c) (__builtin_amdgcn_readfirstlane((int)(c)) != 0)
+#endif
 typedef GPH_LDS double lf64;
 typedef GPH_LDS int16_t li16;
 typedef GPH_LDS int32_t li32;

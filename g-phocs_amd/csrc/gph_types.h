@@ -101,7 +101,7 @@ enum { OUT_ACCEPT = 0, OUT_DDATA, OUT_DLOG, OUT_EVALS, OUT_EVALNODES, OUT_EVALBY
 // access is `ds_read/ds_write <constant offset>(index)` and the compiler knows that different
 // arrays do not alias (loads are hoisted, paired and kept in registers) -- with run-time
 // offsets every access cost an extra scalar add + v_mov and serialised behind every store.
-// HBM pages stay COMPACT (GphLayout, actual n/K/B); stage-in/out copies array by array.
+// The HBM page is the page part of this struct verbatim (one coalesced copy in, one out).
 // Capacities cover every BASELINE config (config 5: 20 leaves, 13 populations, 4 bands).
 #ifndef GPH_CAP_LEAVES
 #define GPH_CAP_LEAVES 24
@@ -116,7 +116,7 @@ enum { OUT_ACCEPT = 0, OUT_DDATA, OUT_DLOG, OUT_EVALS, OUT_EVALNODES, OUT_EVALBY
 #define GPH_CAP_E (2 * GPH_CAP_LEAVES + 4 * GPH_MAX_MIGS + 3 * GPH_CAP_B + GPH_CAP_K + 10)
 #define GPH_CAP_RB (GPH_MAX_MIGS + 2 * GPH_CAP_B)
 
-struct GphLds {
+struct alignas(16) GphLds {
   // ---- page (mirrors the HBM page arrays, GphLayout o_*)
   double age[GPH_CAP_N], sv_age[GPH_CAP_N], ev_time[GPH_CAP_E], mig_age[GPH_MAX_MIGS];
   double coal[GPH_CAP_K], migst[GPH_CAP_B], rb_age[GPH_CAP_RB], fscal[FS_COUNT_];
