@@ -20,18 +20,24 @@ thread_local GphLds gph_lds;
 GphLayout g_lay;
 GphModel g_model;
 #define GPH_KERNEL(name, ...) static void name(int gph_blk, __VA_ARGS__)
+#define GPH_SWEEP_ATTR
 #define GPH_BLK gph_blk
 #else
 __constant__ GphLayout g_lay;
 __constant__ GphModel g_model;
 #define GPH_KERNEL(name, ...) __global__ __launch_bounds__(GPH_WAVE) void name(__VA_ARGS__)
 #define GPH_BLK ((int)blockIdx.x)
+// 5 waves per SIMD (<= 96 VGPRs): the sweep is a latency-bound dependent chain per wave, LDS allows 20 waves/CU
+#ifndef GPH_SWEEP_WAVES
+#define GPH_SWEEP_WAVES 5
+#endif
+#define GPH_SWEEP_ATTR __attribute__((amdgpu_waves_per_eu(GPH_SWEEP_WAVES, GPH_SWEEP_WAVES)))
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "gphocs_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return GPH_EHIP; } } while (0)
 #endif
 
 // j0 = first slot of the bucket being launched (see GphDev)
 GPH_KERNEL(k_init, GphDev D, int j0, uint32_t seedz, const double *mutRate) { kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0); }
-GPH_KERNEL(k_sweep, GphDev D, int j0, int flags, double ftCoal, double ftMig) { kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
+GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphDev D, int j0, int flags, double ftCoal, double ftMig) { kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
 GPH_KERNEL(k_tau_eval, GphDev D, int j0, GphTauArgs A) { kb_tau_eval(D, j0 + GPH_BLK, A); }
 GPH_KERNEL(k_tau_commit, GphDev D, int j0, GphTauArgs A) { kb_tau_commit(D, j0 + GPH_BLK, A); }
 GPH_KERNEL(k_tau_revert, GphDev D, int j0, long long limit) { kb_tau_revert(D, j0 + GPH_BLK, limit); }

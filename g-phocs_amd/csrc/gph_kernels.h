@@ -73,6 +73,7 @@ GPH_DEV void scratch_init(const GphDev &D, int g)
   for (k = 0; k < CN_COUNT; k++) setCNT(k, 0);
   setCNT(CN_P, D.P[g]);
   sf64(&GphLds::s_cntf, 0, 0.0);
+  for (k = 0; k < 8; k++) gph_lds.s_stamp[k] = 0.0;
   set_cond_base(D.cond + D.cond_off[g]);
   delta_clear(0);
   delta_clear(1);
@@ -140,7 +141,7 @@ GPH_DEV void random_gtree()
     T = g_model.popAge[pop];
     if (pop < g_lay.Kc) T = g_model.sampleAge[pop];
     for (; num > 1; num--, nextId++) {
-      t = -(g_model.theta[pop] / (num * (num - 1.))) * gph_log(l_rndu());
+      t = -(g_model.theta[pop] / (num * (num - 1.))) * gph_log_u(l_rndu());
       T += t;
       if (pop != g_lay.rootPop && T > g_model.popAge[g_model.popFather[pop]]) break;
       choice = (int)(num * l_rndu());
@@ -218,11 +219,11 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune)
     if (UNI(fabs(tnew - t) < 1e-15)) { acc++; continue; }
     lik_adjust_age(inode, tnew);
     lnLd = -FS(FS_DATALNL);
-    lnLd += lik_compute(1);
-    dgen = consider_event_move(0, NEV(inode), pop, t, pop, tnew);
+    { STAMP_BEGIN(1); lnLd += lik_compute(1); STAMP_END(1); }
+    { STAMP_BEGIN(2); dgen = consider_event_move(0, NEV(inode), pop, t, pop, tnew); STAMP_END(2); }
     lnacc = dgen + lnLd;
     if (gph_failed()) break;
-    if (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp(lnacc))) {
+    if (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp_u(lnacc))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
       dData += lnLd;
@@ -271,7 +272,7 @@ GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune)
     dgen += consider_event_move(1, ev_t, pop_t, t, pop_t, tnew);
     lnacc = dgen;
     if (gph_failed()) break;
-    if (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp(lnacc))) {
+    if (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp_u(lnacc))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
       dLog += dgen / D.Ltot;
@@ -299,13 +300,13 @@ GPH_DEV void sweep_spr(const GphDev &D, int g)
     father = FATH(node);
     father_pop_old = NPOP(father);
     sibling = LEFT(father) + RGHT(father) - node;
-    trace_lineage<0>(node);
-    res = trace_lineage<1>(node);
+    { STAMP_BEGIN(3); trace_lineage<0>(node); STAMP_END(3); }
+    { STAMP_BEGIN(4); res = trace_lineage<1>(node); STAMP_END(4); }
     lnLd = -FS(FS_DATALNL);
-    lnLd += lik_compute(1);
+    { STAMP_BEGIN(1); lnLd += lik_compute(1); STAMP_END(1); }
     lnacc = lnLd;
     if (gph_failed()) break;
-    if (res >= 0 && (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp(lnacc)))) {
+    if (res >= 0 && (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp_u(lnacc)))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + (SPRLN(1) - SPRLN(0)));
       dData += lnLd;
@@ -360,13 +361,19 @@ GPH_DEV void sweep_spr(const GphDev &D, int g)
 // order with nothing in between) -- one load and one store of the locus instead of three
 GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double ftMig)
 {
+  STAMP_BEGIN(0);
   stage_in(D, g, D.pages, 1);
   OUT(g, 0, 0.0); OUT(g, 1, 0.0); OUT(g, 2, 0.0); OUT(g, 3, 0.0); OUT(g, 4, 0.0);
   OUT(g, 5, 0.0); OUT(g, 6, 0.0); OUT(g, 7, 0.0); OUT(g, 12, 0.0);
-  if ((flags & 1) && ftCoal > 0.0) sweep_internal(D, g, ftCoal);
+  { STAMP_BEGIN(5); if ((flags & 1) && ftCoal > 0.0) sweep_internal(D, g, ftCoal); STAMP_END(5); }
   if ((flags & 2) && ftMig > 0.0 && !gph_failed()) sweep_mignodes(D, g, ftMig);
-  if ((flags & 4) && !gph_failed()) sweep_spr(D, g);
+  { STAMP_BEGIN(6); if ((flags & 4) && !gph_failed()) sweep_spr(D, g); STAMP_END(6); }
   out_common(D, g);
+  STAMP_END(0);
+#if defined(GPH_STAMPS) && !defined(GPH_HOSTEMU)
+  /* diagnostic build: the result slots carry cycle sums instead (tools/stamp_breakdown.py) */
+  for (int k = 0; k < 8; k++) OUT(g, k, gph_lds.s_stamp[k]);
+#endif
   stage_out(D, g, D.pages, 1);
 }
 

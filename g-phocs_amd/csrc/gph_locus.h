@@ -112,6 +112,15 @@ GPH_DEV void ll_swap_remove(LiveList &l, int i) { l.n--; ll_set(l, i, ll_get(l, 
 #define gmin2(a, b) ((a) < (b) ? (a) : (b))
 #define gmax2(a, b) ((a) > (b) ? (a) : (b))
 
+// optional in-kernel cycle attribution (diagnostic builds only: -DGPH_STAMPS); the sums
+// leave the kernel through OUT slots 14/15 and a side buffer, never through a result
+#if defined(GPH_STAMPS) && !defined(GPH_HOSTEMU)
+#define STAMP_BEGIN(k) long long stamp_t0_##k = __builtin_readcyclecounter()
+#define STAMP_END(k) gph_lds.s_stamp[k] += (double)(__builtin_readcyclecounter() - stamp_t0_##k)
+#else
+#define STAMP_BEGIN(k) ((void)0)
+#define STAMP_END(k) ((void)0)
+#endif
 GPH_DEV void gph_fail(int code) { if (CNT(CN_ERROR) == 0) setCNT(CN_ERROR, code); }
 GPH_DEV int gph_failed() { return CNT(CN_ERROR) != 0; }
 
@@ -143,7 +152,7 @@ GPH_DEV double l_rndnormal()
     s = u * u + v * v;
     if (UNI(s > 0 && s < 1)) break;
   }
-  s = sqrt(-2. * gph_log(s) / s);
+  s = sqrt(-2. * gph_log_u(s) / s);
   return u * s;
 }
 // rnd2normal8, utils.c:482-488 (kernel constants utils.c:427-431)
@@ -265,7 +274,7 @@ GPH_DEV void lik_revert()
 GPH_DEV double edge_prob(double len)
 {
   if (len < 1e-100) return 0.0;
-  return ((1 - gph_exp(-4 * len / 3.0)) / 4.0);
+  return ((1 - gph_exp_u(-4 * len / 3.0)) / 4.0);
 }
 
 // The fp64 conditional arrays [2][n-1][P][4] of the locus stay in global memory: they are
@@ -395,11 +404,11 @@ GPH_DEVNI double lik_compute(int useOld)
   for (i = nord - 1; i >= 0; i--) {
     node = gi16(&GphLds::s_ord, i);
     if (useOld) lik_mark_cond(node);
-    prune_node(node);
+    { STAMP_BEGIN(7); prune_node(node); STAMP_END(7); }
   }
   setCNT(CN_NODES, CNT(CN_NODES) + nord);
   /* root reduction, LocusDataLikelihood.c:466-479: per unphased pattern
-   * gph_log(sum over phases and bases / (4*phases)) * count, summed in pattern order */
+   * gph_log_u(sum over phases and bases / (4*phases)) * count, summed in pattern order */
   {
     const gdbl *rc = cond_base() + cond_off(ISC(IS_ROOT), CBIT(ISC(IS_ROOT)));
     int p;
@@ -644,11 +653,11 @@ GPH_DEV double gtree_lnl()
   double lnLd = 0, theta, rate;
   for (pop = 0; pop < g_lay.K; pop++) {
     theta = g_model.theta[pop];
-    lnLd += NCOAL(pop) * gph_log(2 / theta) - COALS(pop) / (theta);
+    lnLd += NCOAL(pop) * gph_log_u(2 / theta) - COALS(pop) / (theta);
   }
   for (b = 0; b < g_lay.B; b++) {
     rate = g_model.migRate[b];
-    if (rate > 0.0) lnLd += NMIGB(b) * gph_log(rate) - MIGST(b) * rate;
+    if (rate > 0.0) lnLd += NMIGB(b) * gph_log_u(rate) - MIGST(b) * rate;
   }
   return lnLd;
 }
@@ -798,7 +807,7 @@ GPH_DEVNI double consider_event_move(int inst, int event_id, int source_pop, dou
   mig_stats_delta(inst, bottom_age, bottom_pop, top_age, dlin);
   r = delta_lnld(inst);
   if (ETYPE(event_id) == GPH_COAL && source_pop != target_pop)
-    r += gph_log(g_model.theta[source_pop] / g_model.theta[target_pop]);
+    r += gph_log_u(g_model.theta[source_pop] / g_model.theta[target_pop]);
   return r;
 }
 GPH_DEV void delta_clear(int inst)
@@ -1037,7 +1046,7 @@ GPH_DEVNI int trace_lineage(int node)
     } else {
       rate = mig_rate + 2 * ENLIN(ev) / theta;
       if (UNI(rate <= 0)) t = EVT(ev);
-      else t = -(1 / rate) * gph_log(l_rndu());
+      else t = -(1 / rate) * gph_log_u(l_rndu());
       if (UNI(t >= EVT(ev))) {
         t = EVT(ev);
         age += t;
@@ -1084,7 +1093,7 @@ GPH_DEVNI int trace_lineage(int node)
     nev++;
     lnld -= (mig_rate + 2 * ENLIN(ev) / theta) * t;
     if (mig_source >= 0) {
-      lnld += gph_log(g_model.migRate[b]);
+      lnld += gph_log_u(g_model.migRate[b]);
       ev = mig_source;
       pop = g_model.bandSrc[b];
       theta = g_model.theta[pop];
@@ -1108,7 +1117,7 @@ GPH_DEVNI int trace_lineage(int node)
     }
     ev = ENEXT(ev);
   }
-  lnld += gph_log(2 / theta);
+  lnld += gph_log_u(2 / theta);
   setDI(inst, DI_NEV, nev);
   setSPRLN(RECONNECT, lnld);
   return 0;

@@ -49,7 +49,15 @@ static const double gph_log_t_h[256] = GPH_LOG_TAB;
 GPH_MATH_FN uint64_t gph_asu64(double x) { union { double d; uint64_t u; } v; v.d = x; return v.u; }
 GPH_MATH_FN double gph_asf64(uint64_t u) { union { double d; uint64_t u; } v; v.u = u; return v.d; }
 
-GPH_MATH_FN double gph_exp(double x)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GPH_UIDX(i) (UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(i)) : (uint32_t)(i))
+#else
+#define GPH_UIDX(i) ((uint32_t)(i))
+#endif
+// UNIFORM = the argument is the same in every lane (chain logic): the table index goes through
+// an SGPR so the two table words come from scalar loads instead of a vector gather
+template <bool UNIFORM>
+GPH_MATH_FN double gph_exp_t(double x)
 {
   const double InvLn2N = GPH_EXPC[0], Shift = GPH_EXPC[1], NegLn2hiN = GPH_EXPC[2], NegLn2loN = GPH_EXPC[3];
   const double C2 = GPH_EXPC[4], C3 = GPH_EXPC[5], C4 = GPH_EXPC[6], C5 = GPH_EXPC[7];
@@ -70,7 +78,7 @@ GPH_MATH_FN double gph_exp(double x)
   double kd = kds - Shift;
   double r = __builtin_fma(kd, NegLn2hiN, x);
   r = __builtin_fma(kd, NegLn2loN, r);
-  uint32_t idx = 2 * (uint32_t)(ki & 0x7f);
+  uint32_t idx = GPH_UIDX(2 * (uint32_t)(ki & 0x7f));
   uint64_t top = ki << 45;
   double tail = gph_asf64(GPH_EXPT[idx]);
   uint64_t sbits = GPH_EXPT[idx + 1] + top;
@@ -110,7 +118,11 @@ GPH_MATH_FN double gph_exp(double x)
   return __builtin_fma(scale, tmp, scale);
 }
 
-GPH_MATH_FN double gph_log(double x)
+GPH_MATH_FN double gph_exp(double x) { return gph_exp_t<false>(x); }
+GPH_MATH_FN double gph_exp_u(double x) { return gph_exp_t<true>(x); }
+
+template <bool UNIFORM>
+GPH_MATH_FN double gph_log_t(double x)
 {
   const double Ln2hi = GPH_LOGC[0], Ln2lo = GPH_LOGC[1];
   const double A0 = GPH_LOGC[2], A1 = GPH_LOGC[3], A2 = GPH_LOGC[4], A3 = GPH_LOGC[5], A4 = GPH_LOGC[6];
@@ -155,7 +167,7 @@ GPH_MATH_FN double gph_log(double x)
     ix += 0xfcc0000000000000ull;                                   /* -= 52 << 52 */
   }
   uint64_t tmp = ix + 0xc01a000000000000ull;                       /* ix - OFF */
-  uint32_t i = (uint32_t)(tmp >> 45) & 0x7f;
+  uint32_t i = GPH_UIDX((uint32_t)(tmp >> 45) & 0x7f);
   int32_t k = (int32_t)((int64_t)tmp >> 52);
   uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
   double kd = (double)k;
@@ -176,3 +188,5 @@ GPH_MATH_FN double gph_log(double x)
   double y = __builtin_fma(r3, q34, lo);
   return y + hi;
 }
+GPH_MATH_FN double gph_log(double x) { return gph_log_t<false>(x); }
+GPH_MATH_FN double gph_log_u(double x) { return gph_log_t<true>(x); }

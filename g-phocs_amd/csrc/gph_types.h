@@ -130,7 +130,7 @@ struct alignas(16) GphLds {
   // ---- LDS-only scratch: pending-proposal storage of GENETREE_STATS_DELTA x2 (patch.h:60-72),
   // MIG_SPR_STATS (patch.h:97-105), genetree_stats_check (patch.h:109), pruning work lists
   double s_dcoal[2][GPH_CAP_K], s_dmig[2][GPH_CAP_B], s_sprf[GPH_MAX_MIGS + 2];
-  double s_chkcoal[GPH_CAP_K], s_chkmig[GPH_CAP_B], s_cntf[2];
+  double s_chkcoal[GPH_CAP_K], s_chkmig[GPH_CAP_B], s_cntf[2], s_stamp[8];
   int32_t s_di[2][8], s_spri[8], s_cnt[8];
   uint32_t s_condptr[2];
   int16_t s_dev[2][GPH_CAP_E], s_dpops[2][GPH_CAP_K], s_dbands[2][GPH_CAP_B], s_spri16[4 * GPH_MAX_MIGS];
