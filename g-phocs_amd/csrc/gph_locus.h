@@ -231,7 +231,12 @@ GPH_DEV void lik_reset_saved()
   setISC(IS_NCHANGEDC, 0);
   setISC(IS_SV_ROOT, -1);
   setFS(FS_SV_DATALNL, FS(FS_DATALNL));
+#ifdef GPH_HOSTEMU
   for (i = 0; i < g_lay.N; i++) setDIRTY(i, 0);
+#else
+  (void)i;
+  if (GPH_LANE < g_lay.N) gph_lds.dirty[GPH_LANE] = 0;   /* one lane per node */
+#endif
 }
 // revertToSaved, LocusDataLikelihood.c:768-841 (value semantics: a node's saved
 // record and its previous conditional array are restored)
@@ -356,6 +361,146 @@ GPH_DEV void prune_node(int node)
   GPH_SYNC();
 }
 
+#ifndef GPH_HOSTEMU
+GPH_DEV double rdlane64(double v, int l)
+{
+  union { double d; int32_t i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+  return u.d;
+}
+// prune_node() with every tree scalar already in (scalar) registers
+GPH_DEV void prune_node_r(int node, int l, int r, double an, double al, double ar, int cbn, int cbl, int cbr,
+                          int P, double mut, gdbl *cb)
+{
+  double pl = edge_prob(mut * (an - al));
+  double ql = 1 - 4.0 * pl;
+  double pr = edge_prob(mut * (an - ar));
+  double qr = 1 - 4.0 * pr;
+  const int nint = g_lay.n - 1;
+  gdbl *pc = cb + ((cbn * nint + (node - g_lay.n)) * P) * 4;
+  const gdbl *lc = cb + (l >= g_lay.n ? ((cbl * nint + (l - g_lay.n)) * P) * 4 : 0);
+  const gdbl *rc = cb + (r >= g_lay.n ? ((cbr * nint + (r - g_lay.n)) * P) * 4 : 0);
+  for (int idx = GPH_LANE; idx < 4 * P; idx += GPH_NLANES) {
+    int p = idx >> 2, a = idx & 3;
+    double v = 1.0, f;
+    f = child_factor(l, lc, p, a, pl, ql);
+    v *= f;
+    f = child_factor(r, rc, p, a, pr, qr);
+    v *= f;
+    pc[idx] = v;
+  }
+  GPH_SYNC();
+}
+
+// computeLocusDataLikelihood, LocusDataLikelihood.c:426-483.  Device form: the genealogy
+// (father/left/right/age, one node per lane) and the dirty / current-buffer sets (64-bit
+// masks) are pulled into registers once; "which nodes must be recomputed" is a ballot
+// fix-point over the tree instead of the recursion of computeConditionalJC_new (:1559-1636),
+// nodes are processed as soon as their recomputed children are done (any such order gives
+// bit-identical conditionals), copyNodeConditionals bookkeeping is applied to the masks and
+// written back once, and the per-pattern terms are added in pattern order through v_readlane.
+GPH_DEVNI double lik_compute(int useOld)
+{
+  const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
+  useOld = RFL(useOld);
+  const int P = CNT(CN_P);
+  if (P == 0) return 0.0;
+  const bool isnode = lane < N;
+  const int le = isnode ? (int)gph_lds.left[lane] : -1;
+  const int ri = isnode ? (int)gph_lds.right[lane] : -1;
+  const double ag = isnode ? gph_lds.age[lane] : 0.0;
+  uint64_t dirty = __ballot(isnode && gph_lds.dirty[lane] != 0);
+  uint64_t cbit = __ballot(isnode && gph_lds.condbit[lane] != 0);
+  const uint64_t internal = (((uint64_t)1 << N) - 1) & ~(((uint64_t)1 << n) - 1);
+  uint64_t newly = 0, need, todo;
+  if (!useOld) { newly = internal & ~dirty; dirty |= internal; cbit ^= newly; }
+  setFS(FS_SV_DATALNL, FS(FS_DATALNL));
+  if (!useOld) {
+    need = internal;
+  } else {
+    need = dirty;
+    for (int it = 0; it <= N; it++) {
+      bool up = isnode && lane >= n && ((((need >> le) | (need >> ri)) & 1) != 0);
+      uint64_t nn = need | __ballot(up);
+      if (nn == need) break;
+      need = nn;
+    }
+    setCNT(CN_EVALS, CNT(CN_EVALS) + 1);
+  }
+  const int root = ISC(IS_ROOT);
+  if (!((need >> root) & 1)) return FS(FS_DATALNL);
+  todo = need & internal;
+  const int nord = __builtin_popcountll(todo);
+  gdbl *cb = cond_base();
+  const double mut = FS(FS_MUTRATE);
+  for (int guard = 0; todo != 0; guard++) {
+    bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
+    uint64_t rmask = __ballot(rdy);
+    if (rmask == 0 || guard > N) { gph_fail(100); return FS(FS_DATALNL); }
+    while (rmask) {
+      const int node = __builtin_ctzll(rmask);
+      const uint64_t bit = (uint64_t)1 << node;
+      rmask &= rmask - 1;
+      if (useOld && !(dirty & bit)) { dirty |= bit; cbit ^= bit; newly |= bit; }   /* copyNodeConditionals */
+      const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
+      STAMP_BEGIN(7);
+      prune_node_r(node, l, r, rdlane64(ag, node), rdlane64(ag, l), rdlane64(ag, r), (int)((cbit >> node) & 1),
+                   (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, mut, cb);
+      STAMP_END(7);
+      todo &= ~bit;
+    }
+  }
+  setCNT(CN_NODES, CNT(CN_NODES) + nord);
+  /* write the dirty / current-buffer sets back, append the newly marked nodes to the list */
+  if (isnode) {
+    gph_lds.dirty[lane] = (uint8_t)((dirty >> lane) & 1);
+    gph_lds.condbit[lane] = (uint8_t)((cbit >> lane) & 1);
+    if ((newly >> lane) & 1) {
+      int pos = ISC(IS_NCHANGEDC) + __builtin_popcountll(newly & (((uint64_t)1 << lane) - 1));
+      gph_lds.changedc[pos] = (int16_t)lane;
+    }
+  }
+  setISC(IS_NCHANGEDC, ISC(IS_NCHANGEDC) + __builtin_popcountll(newly));
+  GPH_SYNC();
+  /* root reduction, LocusDataLikelihood.c:466-479: per unphased pattern
+   * log(sum over phases and bases / (4*phases)) * count, summed in pattern order */
+  double lnl = 0.0;
+  int U;
+  const gdbl *rc = cb + (((int)((cbit >> root) & 1) * (n - 1) + (root - n)) * P) * 4;
+  if (P <= GPH_WAVE) {
+    double term = 0.0;
+    const int ph = lane < P ? gu8v(g_lay.q_phases, lane) : 0;
+    if (ph > 0) {
+      const int nc = 4 * ph;
+      double prob = 0.0;
+      for (int c = 0; c < nc; c++) prob += rc[lane * 4 + c];
+      term = gph_log(prob / nc) * gi32v(g_lay.q_count, lane);
+    }
+    uint64_t pm = __ballot(ph > 0);
+    U = __builtin_popcountll(pm);
+    while (pm) { lnl += rdlane64(term, __builtin_ctzll(pm)); pm &= pm - 1; }
+  } else {
+    for (int p = lane; p < P; p += GPH_NLANES) {
+      int ph = gu8v(g_lay.q_phases, p);
+      if (ph > 0) {
+        int nc = 4 * ph;
+        double prob = 0.0;
+        for (int c = 0; c < nc; c++) prob += rc[p * 4 + c];
+        sf64(g_lay.s_terms, p, gph_log(prob / nc) * gi32v(g_lay.q_count, p));
+      }
+    }
+    GPH_SYNC();
+    U = 0;
+    for (int p = 0; p < P; p++)
+      if (gu8(g_lay.q_phases, p) > 0) { lnl += gf64(g_lay.s_terms, p); U++; }
+  }
+  setFS(FS_DATALNL, lnl);
+  if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (96.0 * nord * P + 20.0 * N + 8.0 * U + 8.0));
+  return lnl;
+}
+#else
 // computeLocusDataLikelihood, LocusDataLikelihood.c:426-483, with the recursion of
 // computeConditionalJC_new (:1559-1636) replaced by: mark the ancestors of every
 // dirty node, list the marked internal nodes parent-before-child, process the
@@ -432,6 +577,8 @@ GPH_DEVNI double lik_compute(int useOld)
   if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (96.0 * nord * P + 20.0 * N + 8.0 * U + 8.0));
   return lnl;
 }
+
+#endif
 
 // scaleAllNodeAges, LocusDataLikelihood.c:895-917
 GPH_DEV double lik_scale_ages(double factor)
