@@ -136,7 +136,21 @@ GPH_DEV double l_rndu()
   setISC(IS_RX, (int)x);
   setISC(IS_RY, (int)y);
   setISC(IS_RZ, (int)z);
+#ifdef GPH_HOSTEMU
   r = x / 30269.0 + y / 30307.0 + z / 30323.0;
+#else
+  /* IEEE-exact quotients without the 14-instruction divide expansion: for a 32-bit integer x
+   * and d in {30269, 30307, 30323}, q = fma(fma(-q0, d, x), 1/d, q0) with q0 = x * RN(1/d)
+   * equals RN(x / d) for ALL 2^32 values of x (exhaustively verified, tools/verify_rng_div.c) */
+  {
+    const double rx = 1.0 / 30269.0, ry = 1.0 / 30307.0, rz = 1.0 / 30323.0;
+    double xd = (double)x, yd = (double)y, zd = (double)z, q;
+    q = xd * rx; double qx = __builtin_fma(__builtin_fma(-q, 30269.0, xd), rx, q);
+    q = yd * ry; double qy = __builtin_fma(__builtin_fma(-q, 30307.0, yd), ry, q);
+    q = zd * rz; double qz = __builtin_fma(__builtin_fma(-q, 30323.0, zd), rz, q);
+    r = qx + qy + qz;
+  }
+#endif
   r = (r - (int)r);
   return r;
 }
@@ -651,11 +665,39 @@ GPH_DEV int find_first_mig(int node, double age)
   }
   return first;
 }
-// getEdgesForTimePop, patch.c:526-571 (targets written to s_targets)
+// getEdgesForTimePop, patch.c:526-571 (targets written to s_targets, increasing node id).
+// Device form: one lane per genealogy node evaluates the membership test, a ballot yields the
+// candidate set in node order (the order decides which edge a sampled coalescence picks).
 GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
 {
   int node, mig, pop1, num = 0, f;
-  if (g_model.popAge[pop] > time + 0.0000001) return 0;
+  if (UNI(g_model.popAge[pop] > time + 0.0000001)) return 0;
+#ifndef GPH_HOSTEMU
+  {
+    const int lane = GPH_LANE;
+    bool in = false;
+    if (lane < g_lay.N && lane != exc) {
+      f = gph_lds.father[lane];
+      in = !(gph_lds.age[lane] > time) && !(f >= 0 && gph_lds.age[f] <= time);
+      if (in && pop != g_lay.rootPop) {
+        /* findLastMig(node = lane, time), patch.c:374-391 */
+        int last = -1, nm = ISC(IS_NUM_MIGS);
+        for (int i = 0; i < nm; i++) {
+          mig = LIVING(i);
+          if (MG(mig, MG_BRANCH) != lane) continue;
+          if ((time < 0 || MAGE(mig) < time) && (last < 0 || MAGE(mig) > MAGE(last))) last = mig;
+        }
+        pop1 = (last >= 0) ? (int)gph_lds.mig_i[last * MG_COUNT + MG_SPOP] : (int)gph_lds.npop[lane];
+        in = ((g_model.isAnc[pop] >> pop1) & 1) != 0;
+      }
+    }
+    uint64_t m = __ballot(in);
+    num = __builtin_popcountll(m);
+    if (in) gph_lds.s_targets[__builtin_popcountll(m & (((uint64_t)1 << lane) - 1))] = (int16_t)lane;
+    GPH_SYNC();
+    return num;
+  }
+#else
   for (node = 0; node < g_lay.N; node++) {
     f = FATH(node);
     if (node == exc || UNI(AGE(node) > time) || (f >= 0 && UNI(AGE(f) <= time))) continue;
@@ -665,6 +707,7 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
     if ((g_model.isAnc[pop] >> pop1) & 1) si16(&GphLds::s_targets, num++, node);
   }
   return num;
+#endif
 }
 
 // ---------------------------------------------------------------- event chain
