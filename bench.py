@@ -78,6 +78,73 @@ def build_workload(G, config, L, mut_scale, seed0, cache_dir):
     return base
 
 
+BASE_CODE = "TCAG"
+IUPAC = {frozenset("CT"): "Y", frozenset("AG"): "R", frozenset("AC"): "M", frozenset("GT"): "K",
+         frozenset("CG"): "S", frozenset("AT"): "W"}
+
+
+def write_seq_sample(pack, nloci, path):
+    """sequence file (the reference's unchanged input format) for the first `nloci` loci of a synthetic
+    pack: every unphased pattern becomes `count` alignment columns of diploid genotypes (IUPAC het codes)"""
+    nd = pack.n // 2
+    with open(path, "w") as f:
+        f.write(f"{nloci}\n\n")
+        for g in range(nloci):
+            o0, o1 = int(pack.pattern_offsets[g]), int(pack.pattern_offsets[g + 1])
+            cols = [[] for _ in range(nd)]
+            for r in range(o0, o1):
+                if pack.numPhases[r] == 0:
+                    continue
+                row, cnt = pack.leafcodes[r], int(pack.counts[r])
+                for d in range(nd):
+                    a, b = int(row[2 * d]), int(row[2 * d + 1])
+                    if a == 4 or b == 4:
+                        ch = "N"
+                    elif a == b:
+                        ch = BASE_CODE[a]
+                    else:
+                        ch = IUPAC[frozenset((BASE_CODE[a], BASE_CODE[b]))]
+                    cols[d].append(ch * cnt)
+            seqs = ["".join(c) for c in cols]
+            f.write(f"locus{g + 1} {nd} {len(seqs[0])}\n")
+            for d in range(nd):
+                f.write(f"s{d}\t{seqs[d]}\n")
+            f.write("\n")
+
+
+def cpu_baseline_reference(config, pack, nloci, iters):
+    """the REAL reference (oracle/_ref, compiled from its own sources in the build container) timed on a
+    bounded sample of the same workload: serial build on 1 core and its OpenMP build on all cores"""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import gen_synth
+    ref = os.path.join(REPO, "oracle", "_ref", "gphocs_ref")
+    ref_omp = os.path.join(REPO, "oracle", "_ref", "gphocs_ref_omp")
+    if not os.path.exists(ref):
+        return None
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        write_seq_sample(pack, nloci, os.path.join(td, "s.seq"))
+        gen_synth.write_ctl(os.path.join(td, "s.ctl"), gen_synth.CONFIGS[config], "s.seq", "s.trace", nloci, 12345,
+                            1000, 100000)
+        r = json.loads(subprocess.run([ref, "time", "s.ctl", str(iters), "2"], cwd=td, check=True,
+                                      capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1])
+        out = {"value": r["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "reference",
+               "sample": f"first {nloci} loci of the workload written as a sequence file, {iters} iterations after "
+                         f"2 warm-up ({r['seconds']:.1f} s), serial reference build; "
+                         f"{r['iters_per_s'] * nloci:.0f} locus-iterations/s",
+               "iters_per_s_at_sample": r["iters_per_s"]}
+        if os.path.exists(ref_omp):
+            nc = os.cpu_count() or 1
+            env = dict(os.environ, OMP_NUM_THREADS=str(nc))
+            try:
+                r2 = json.loads(subprocess.run([ref_omp, "time", "s.ctl", str(iters), "2"], cwd=td, check=True, env=env,
+                                               capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1])
+                out["openmp_all_cores"] = {"value": r2["evals_per_s"], "cores": nc, "seconds": r2["seconds"]}
+            except Exception as ex:  # pragma: no cover
+                out["openmp_all_cores"] = {"error": str(ex)}
+    return out
+
+
 def cpu_baseline(G, pack, nloci, iters):
     """oracle restatement, single thread, bounded sample of the same workload"""
     from gphocs_amd_pkg import synth
@@ -217,7 +284,13 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(G, pack, min(a.cpu_loci, L_total), a.cpu_iters)
+                cb = cpu_baseline_reference(a.config, pack, min(a.cpu_loci, L_total), a.cpu_iters)
+                port = cpu_baseline(G, pack, min(a.cpu_loci, L_total), a.cpu_iters)
+                if cb is None:
+                    cb = port
+                else:
+                    cb["port_single_thread"] = {"value": port["value"], "kind": "port"}
+                line["cpu_baseline"] = cb
             except Exception as ex:  # pragma: no cover
                 line["cpu_baseline"] = {"error": str(ex)}
         print(json.dumps(line), flush=True)
