@@ -134,7 +134,7 @@ def cpu_baseline_reference(config, pack, nloci, iters):
                          f"{r['iters_per_s'] * nloci:.0f} locus-iterations/s",
                "iters_per_s_at_sample": r["iters_per_s"]}
         if os.path.exists(ref_omp):
-            nc = os.cpu_count() or 1
+            nc = min(os.cpu_count() or 1, 8)   # the reference scales ~3x on 8 threads and collapses beyond (atomics)
             env = dict(os.environ, OMP_NUM_THREADS=str(nc))
             try:
                 r2 = json.loads(subprocess.run([ref_omp, "time", "s.ctl", str(iters), "2"], cwd=td, check=True, env=env,

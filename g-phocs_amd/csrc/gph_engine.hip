@@ -73,37 +73,41 @@ __global__ void k_apply_migrate(GphDev D, int band, double lnc, double rate_diff
   double ms = ((double *)(pg + g_lay.o_migst))[band];
   fs[FS_GENLNL] += (lnc * nm - rate_diff * ms);
 }
-// column value of locus g: mode 0 = out slots, mode 1 = page statistics
-// (coal_stats[K], num_coals[K], mig_stats[B], num_migs[B])
-__device__ inline double red_value(const GphDev &D, int mode, int g, int col)
-{
-  if (mode == 0) return D.out[(size_t)g * GPH_OUT_SLOTS + col];
-  const char *pg = D.pages + (size_t)g * g_lay.page_bytes;
-  const int K = g_lay.K, B = g_lay.B;
-  if (col < K) return ((const double *)(pg + g_lay.o_coal))[col];
-  if (col < 2 * K) return (double)((const int16_t *)(pg + g_lay.o_ncoal))[col - K];
-  if (col < 2 * K + B) return ((const double *)(pg + g_lay.o_migst))[col - 2 * K];
-  return (double)((const int16_t *)(pg + g_lay.o_nmig))[col - 2 * K - B];
-}
-// fixed-shape two-level reduction (deterministic run to run): block b sums a contiguous
-// chunk of loci in index order per column; the final pass adds the 256 partials in order.
+// fixed-shape two-level reduction (deterministic run to run): block b owns a contiguous chunk of
+// loci; inside it 8 sub-sequences (g = g0+s, g0+s+8, ...) are summed in index order by 8 thread
+// groups and combined in sub order; the final pass adds the 256 block partials in order.
+// mode 0 = per-locus outputs (GPH_OUT_SLOTS columns), mode 1 = compact statistics (2K+2B columns)
 // part: [3][GPH_RED_BLOCKS][GPH_RED_COLS] (sum, min, max)
-__global__ void k_reduce_partial(GphDev D, int mode, int ncols, double *part)
+#define GPH_RED_SUBS 8
+__global__ void __launch_bounds__(GPH_RED_SUBS * 64) k_reduce_partial(GphDev D, int mode, int ncols, double *part)
 {
-  int col = threadIdx.x, b = blockIdx.x;
-  if (col >= ncols) return;
-  int chunk = (D.L + GPH_RED_BLOCKS - 1) / GPH_RED_BLOCKS;
-  int g0 = b * chunk, g1 = g0 + chunk < D.L ? g0 + chunk : D.L;
+  __shared__ double sh[3][GPH_RED_SUBS][64];
+  const int col = threadIdx.x & 63, sub = threadIdx.x >> 6, b = blockIdx.x;
+  const int chunk = (D.L + GPH_RED_BLOCKS - 1) / GPH_RED_BLOCKS;
+  const int g0 = b * chunk, g1 = g0 + chunk < D.L ? g0 + chunk : D.L;
+  const double *src = mode == 0 ? D.out : D.stats;
+  const int stride = mode == 0 ? GPH_OUT_SLOTS : ncols;
   double s = 0.0, mn = 1e300, mx = -1e300;
-  for (int g = g0; g < g1; g++) {
-    double v = red_value(D, mode, g, col);
-    s += v;
-    mn = v < mn ? v : mn;
-    mx = v > mx ? v : mx;
+  if (col < ncols)
+    for (int g = g0 + sub; g < g1; g += GPH_RED_SUBS) {
+      double v = src[(size_t)g * stride + col];
+      s += v;
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
+    }
+  sh[0][sub][col] = s; sh[1][sub][col] = mn; sh[2][sub][col] = mx;
+  __syncthreads();
+  if (sub == 0 && col < ncols) {
+    s = 0.0; mn = 1e300; mx = -1e300;
+    for (int k = 0; k < GPH_RED_SUBS; k++) {
+      s += sh[0][k][col];
+      mn = sh[1][k][col] < mn ? sh[1][k][col] : mn;
+      mx = sh[2][k][col] > mx ? sh[2][k][col] : mx;
+    }
+    part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = s;
+    part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = mn;
+    part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = mx;
   }
-  part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = s;
-  part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = mn;
-  part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = mx;
 }
 __global__ void k_reduce_final(int ncols, const double *part, double *red)
 {
@@ -300,21 +304,14 @@ static int reduce_local(gph_engine *e, int mode, int ncols)
     for (int64_t g = 0; g < e->L; g++) {
       double v;
       if (mode == 0) v = e->dev.out[(size_t)g * GPH_OUT_SLOTS + c];
-      else {
-        const char *pg = e->dev.pages + (size_t)g * e->lay.page_bytes;
-        const int K = e->lay.K, B = e->lay.B;
-        if (c < K) v = ((const double *)(pg + e->lay.o_coal))[c];
-        else if (c < 2 * K) v = ((const int16_t *)(pg + e->lay.o_ncoal))[c - K];
-        else if (c < 2 * K + B) v = ((const double *)(pg + e->lay.o_migst))[c - 2 * K];
-        else v = ((const int16_t *)(pg + e->lay.o_nmig))[c - 2 * K - B];
-      }
+      else v = e->dev.stats[(size_t)g * ncols + c];
       s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
     }
     e->h_red[c] = s; e->h_red[GPH_RED_COLS + c] = mn; e->h_red[2 * GPH_RED_COLS + c] = mx;
   }
   return 0;
 #else
-  hipLaunchKernelGGL(k_reduce_partial, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_COLS), 0, e->stream, e->dev, mode, ncols, e->d_part);
+  hipLaunchKernelGGL(k_reduce_partial, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_SUBS * 64), 0, e->stream, e->dev, mode, ncols, e->d_part);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(GPH_RED_COLS), 0, e->stream, ncols, e->d_part, e->d_red);
   HIPCHK(hipGetLastError());
   return d2h(e, e->h_red, e->d_red, sizeof(double) * 3 * GPH_RED_COLS);
@@ -390,7 +387,7 @@ void gph_engine_destroy(gph_engine *e)
 {
   if (!e) return;
   dev_free(e->dev.pages); dev_free(e->dev.shadow); dev_free(e->dev.cond); dev_free((void *)e->dev.cond_off);
-  dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->d_mutRate);
+  dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
   dev_free(e->d_part); dev_free(e->d_red);
 #ifndef GPH_HOSTEMU
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -494,6 +491,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   rc |= dev_alloc((void **)&e->dev.P, sizeof(int32_t) * L);
   rc |= dev_alloc((void **)&e->dev.orig, sizeof(int32_t) * L);
   rc |= dev_alloc((void **)&e->dev.out, sizeof(double) * GPH_OUT_SLOTS * L);
+  rc |= dev_alloc((void **)&e->dev.stats, sizeof(double) * (2 * e->cfg.K + 2 * e->cfg.B) * L);
   rc |= dev_alloc((void **)&e->d_part, sizeof(double) * 3 * GPH_RED_BLOCKS * GPH_RED_COLS);
   rc |= dev_alloc((void **)&e->d_red, sizeof(double) * 3 * GPH_RED_COLS);
   if (mutRates) rc |= dev_alloc((void **)&e->d_mutRate, sizeof(double) * L);

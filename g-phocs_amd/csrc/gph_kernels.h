@@ -18,6 +18,7 @@ struct GphDev {            // device pointers (passed by value to every kernel)
   const int32_t *P;        // phased patterns per locus
   const int32_t *orig;     // original (input-order) local index of the locus stored at slot g
   double *out;             // L * GPH_OUT_SLOTS
+  double *stats;           // L * (2K+2B): coal_stats, num_coals, mig_stats, num_migs of every locus, compact
   int32_t L;               // loci on this device
   int32_t Ltot;            // loci over all devices (dataSetup.numLoci)
   int64_t locus_begin;     // global index of this device's first locus
@@ -93,6 +94,18 @@ GPH_DEV void stage_out(const GphDev &D, int g, char *pages, int unused)
   (void)unused;
   GPH_SYNC();
   page_out(pages + (size_t)g * g_lay.page_bytes);
+  if (pages == D.pages) {
+    /* compact copy of the sufficient statistics for the totals reduction (computeTotalStats) */
+    const int K = g_lay.K, B = g_lay.B, C = 2 * K + 2 * B;
+    for (int c = GPH_LANE; c < C; c += GPH_NLANES) {
+      double v;
+      if (c < K) v = gph_lds.coal[c];
+      else if (c < 2 * K) v = (double)gph_lds.ncoal[c - K];
+      else if (c < 2 * K + B) v = gph_lds.migst[c - 2 * K];
+      else v = (double)gph_lds.nmig[c - 2 * K - B];
+      D.stats[(size_t)g * C + c] = v;
+    }
+  }
 }
 GPH_DEV void out_common(const GphDev &D, int g)
 {
