@@ -405,7 +405,7 @@ GPH_DEV void prune_node_r(int node, int l, int r, double an, double al, double a
     v *= f;
     pc[idx] = v;
   }
-  GPH_SYNC();
+  GPH_WAVE_FENCE();
 }
 
 // computeLocusDataLikelihood, LocusDataLikelihood.c:426-483.  Device form: the genealogy
@@ -415,7 +415,7 @@ GPH_DEV void prune_node_r(int node, int l, int r, double an, double al, double a
 // nodes are processed as soon as their recomputed children are done (any such order gives
 // bit-identical conditionals), copyNodeConditionals bookkeeping is applied to the masks and
 // written back once, and the per-pattern terms are added in pattern order through v_readlane.
-GPH_DEVNI double lik_compute(int useOld)
+GPH_DEVHOT double lik_compute(int useOld)
 {
   const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
   useOld = RFL(useOld);
@@ -477,7 +477,7 @@ GPH_DEVNI double lik_compute(int useOld)
     }
   }
   setISC(IS_NCHANGEDC, ISC(IS_NCHANGEDC) + __builtin_popcountll(newly));
-  GPH_SYNC();
+  GPH_WAVE_FENCE();
   /* root reduction, LocusDataLikelihood.c:466-479: per unphased pattern
    * log(sum over phases and bases / (4*phases)) * count, summed in pattern order */
   double lnl = 0.0;
@@ -519,7 +519,7 @@ GPH_DEVNI double lik_compute(int useOld)
 // computeConditionalJC_new (:1559-1636) replaced by: mark the ancestors of every
 // dirty node, list the marked internal nodes parent-before-child, process the
 // list backwards.  Same set of recomputed nodes, children always before parents.
-GPH_DEVNI double lik_compute(int useOld)
+GPH_DEVHOT double lik_compute(int useOld)
 {
   const int n = g_lay.n, N = g_lay.N;
   useOld = RFL(useOld);
@@ -750,7 +750,7 @@ GPH_DEV int create_event_before(int pop, int ev, double elapsed)
   return nw;
 }
 // createEvent, patch.c:1753-1802
-GPH_DEVNI int create_event(int pop, double age)
+GPH_DEVHOT int create_event(int pop, double age)
 {
   int ev;
   pop = RFL(pop);
@@ -967,7 +967,7 @@ GPH_DEV double delta_lnld(int inst)
   return r;
 }
 // considerEventMove, patch.c:1434-1507
-GPH_DEVNI double consider_event_move(int inst, int event_id, int source_pop, double original_age,
+GPH_DEVHOT double consider_event_move(int inst, int event_id, int source_pop, double original_age,
                                      int target_pop, double new_age)
 {
   int new_event, bottom_event, top_event, bottom_pop, dlin;
@@ -1163,7 +1163,7 @@ GPH_DEV double rubber_band_ripple(int do_or_redo)
 // traceLineage, patch.c:886-1331.  RECONNECT == 0: walk the existing edge above
 // `node`, removing one lineage; RECONNECT == 1: re-sample its path from the prior
 template <int RECONNECT>
-GPH_DEVNI int trace_lineage(int node)
+GPH_DEVHOT int trace_lineage(int node)
 {
   const int inst = RECONNECT;
   node = RFL(node);

@@ -22,10 +22,12 @@
 #include <string.h>
 #define GPH_DEV static inline
 #define GPH_DEVNI static
+#define GPH_DEVHOT static inline
 #define GPH_LDS
 #define GPH_LANE 0
 #define GPH_NLANES 1
 #define GPH_SYNC() ((void)0)
+#define GPH_WAVE_FENCE() ((void)0)
 #define RFL(x) (x)
 extern thread_local char *gph_sm;
 extern thread_local GphLds gph_lds;
@@ -35,10 +37,21 @@ extern GphModel g_model;
 #include <hip/hip_runtime.h>
 #define GPH_DEV __device__ inline
 #define GPH_DEVNI __device__ __noinline__
+// hot-path functions are inlined into the kernels: an out-of-line call costs ~150 instructions of
+// callee-saved SGPR/VGPR save+restore (v_writelane/scratch) on a path that is instruction-bound
+#ifndef GPH_DEVHOT
+#define GPH_DEVHOT __device__ __attribute__((always_inline)) inline
+#endif
 #define GPH_LDS __attribute__((address_space(3)))
 #define GPH_LANE ((int)threadIdx.x)
 #define GPH_NLANES GPH_WAVE
 #define GPH_SYNC() __syncthreads()
+// hand-off between lanes of the SAME wavefront (the only kind there is: one wave per workgroup).
+// LDS and vector-memory operations of one wave are issued and performed in order and the CU's L1
+// is write-through, so no wait for completion is needed -- only a compiler barrier (a
+// wavefront-scope fence emits no instruction).  Used in the pruning loop, where waiting for each
+// node's store to be acknowledged (what __syncthreads' workgroup fence does) cost ~25 % of lik_compute.
+#define GPH_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 #define RFL(x) __builtin_amdgcn_readfirstlane((int)(x))
 extern __shared__ __attribute__((aligned(16))) char gph_sm[];   // dynamic part: sequence block + per-pattern terms
 __shared__ GphLds gph_lds;   // static part: the locus image (gph_types.h); this header is included by one TU only
