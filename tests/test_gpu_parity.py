@@ -62,6 +62,60 @@ def test_against_live_oracle(G, oracle_cli, tmp_path):
     compare_states(st1, os_)
 
 
+def test_many_patterns_against_live_oracle(G, oracle_cli, tmp_path):
+    """loci with up to 75 phased patterns (more than one wavefront of (pattern, base) pairs and more
+    than 64 per-pattern terms: exercises the multi-pass pruning and the LDS fallback of the root sum)"""
+    pack = os.path.join(GOLDEN, "bigp.gpk")
+    tr, _, st1, _ = _run(G, pack, 40, tmp_path, "bigp")
+    ot, os_ = tmp_path / "o.trace", tmp_path / "o.state"
+    subprocess.run([oracle_cli, "run", pack, "40", str(ot), str(os_), "39", "1"], check=True, timeout=600)
+    compare_records(tr, ot)
+    compare_states(st1, os_)
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(repo)r)
+import numpy as np, torch, torch.distributed as dist
+import gphocs_amd as G
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+def allreduce(sums, mins):
+    if sums.size:
+        t = torch.from_numpy(sums); dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if mins.size:
+        t = torch.from_numpy(mins); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+s = G.Sampler(G.Pack.load(%(pack)r), device=0, rank=rank, world=world, allreduce=allreduce)
+s.set_record_file(%(out)r + ".%%d" %% rank)
+s.initialize()
+for it in range(%(iters)d):
+    s.iteration(it)
+s.set_record_file(None)
+s.close()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_sharded_on_device(G, tmp_path):
+    """the sharded path on the device: two processes (both on cuda:0 here -- the box has one GPU), each
+    with the engine over its contiguous shard, exchanging only the reduced vectors through the
+    all-reduce hook (gloo here; bench.py uses RCCL).  Must equal the single-rank reference golden."""
+    import sys
+    from conftest import REPO
+    out = str(tmp_path / "rec")
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % dict(repo=REPO, pack=os.path.join(GOLDEN, "m3.gpk"), out=out, iters=50))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    assert open(out + ".0").read() == open(out + ".1").read()
+    mine = open(out + ".0").read().splitlines()
+    golden = open(os.path.join(GOLDEN, "m3.rtrace")).read().splitlines()[:len(mine)]
+    (tmp_path / "g").write_text("\n".join(golden) + "\n")
+    compare_records(out + ".0", str(tmp_path / "g"))
+
+
 def test_native_library_is_the_path(G):
     """the ops must come from the in-tree HIP library; without it construction fails loudly"""
     import gphocs_amd
