@@ -771,7 +771,7 @@ GPH_DEVHOT int create_event(int pop, double age)
 
 // recalcStats, patch.c:2387-2513.  The reference also patches the global totals
 // here; the engine instead re-reduces the per-locus statistics after the kernel.
-GPH_DEVNI double recalc_stats(int pop)
+GPH_DEVHOT double recalc_stats(int pop)
 {
   pop = RFL(pop);
   int n, id, b, ev, nc = 0;
@@ -1048,7 +1048,7 @@ GPH_DEV void reject_event_chain_changes(int inst)
 
 // ---------------------------------------------------------------- rubber band
 // rubberBand, patch.c:596-801
-GPH_DEVNI double rubber_band(int pop, double static_point, double moving_point, double factor, int post,
+GPH_DEVHOT double rubber_band(int pop, double static_point, double moving_point, double factor, int post,
                              int *out_num_events)
 {
   int i, ev, b, node_id, num_lins, count_events = 0, flag, ty;
