@@ -24,18 +24,42 @@ CSRC = os.path.join(_HERE, "csrc")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-result"]
 
+# Capacity variants of the same library (same C ABI, same sources): the static LDS image of a locus is
+# sized by compile-time capacities (csrc/gph_types.h), and a tighter image means more resident
+# wavefronts per CU.  `load_library(dims=...)` picks the smallest variant that fits the model.
+VARIANTS = {  # name: (max leaves, max pops, max bands, waves per SIMD of the sweep kernel, file)
+    "s": (16, 9, 4, 6, "libgphocs_hip_s.so"),
+    "m": (24, 16, 8, 5, "libgphocs_hip.so"),
+}
+
+
+def variant_for(n, K, B):
+    for name in ("s", "m"):
+        cl, ck, cb, _, _ = VARIANTS[name]
+        if n <= cl and K <= ck and B <= cb:
+            return name
+    raise RuntimeError(f"model (leaves={n}, pops={K}, bands={B}) exceeds the largest compiled capacity "
+                       f"{VARIANTS['m'][:3]}; rebuild with larger -DGPH_CAP_* (csrc/gph_types.h)")
+
+
+def lib_path(name="m"):
+    return os.path.join(_HERE, VARIANTS[name][4])
+
 
 def build(verbose=False):
-    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU), every variant."""
     srcs = [os.path.join(CSRC, "gph_engine.hip"), os.path.join(CSRC, "gph_mcmc.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
         [os.path.join(REPO, "include", "gphocs_hip.h")]
-    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
-    cmd = ["hipcc"] + HIPCC_FLAGS + srcs + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    for name, (cl, ck, cb, waves, fn) in VARIANTS.items():
+        out = os.path.join(_HERE, fn)
+        if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+            continue
+        cmd = ["hipcc"] + HIPCC_FLAGS + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}",
+                                         f"-DGPH_SWEEP_WAVES={waves}"] + srcs + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     return LIB_PATH
 
 
@@ -92,8 +116,22 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
 ]
 
 
-def load_library(path=None):
+_LIBS = {}
+
+
+def load_library(path=None, dims=None):
+    """dims = (leaves, pops, bands): load the tightest capacity variant that fits"""
+    if path is None and dims is not None:
+        path = lib_path(variant_for(*dims))
     path = path or LIB_PATH
+    if path in _LIBS:
+        return _LIBS[path]
+    lib = _load_library(path)
+    _LIBS[path] = lib
+    return lib
+
+
+def _load_library(path):
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
@@ -222,7 +260,7 @@ class Sampler:
     """Engine + host MCMC driver for one rank's shard of a Pack."""
 
     def __init__(self, pack, lib=None, device=0, rank=0, world=1, allreduce=None):
-        self.lib = lib or load_library()
+        self.lib = lib or load_library(dims=(pack.n, pack.K, pack.B))
         self.pack = pack
         self.rank, self.world = rank, world
         self.begin, self.end = pack.shard(rank, world)
