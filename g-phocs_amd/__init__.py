@@ -89,7 +89,8 @@ class GphMcmcConfig(C.Structure):
     _fields_ = [("thetaAlpha", C.POINTER(C.c_double)), ("thetaBeta", C.POINTER(C.c_double)),
                 ("thetaStart", C.POINTER(C.c_double)), ("ageAlpha", C.POINTER(C.c_double)),
                 ("ageBeta", C.POINTER(C.c_double)), ("ageStart", C.POINTER(C.c_double)),
-                ("sampleAge", C.POINTER(C.c_double)), ("mrAlpha", C.POINTER(C.c_double)),
+                ("sampleAge", C.POINTER(C.c_double)), ("updateSampleAge", C.POINTER(C.c_int32)),
+                ("mrAlpha", C.POINTER(C.c_double)),
                 ("mrBeta", C.POINTER(C.c_double)),
                 ("ftCoalTime", C.c_double), ("ftMigTime", C.c_double), ("ftTheta", C.c_double),
                 ("ftMigRate", C.c_double), ("ftMixing", C.c_double),
@@ -197,6 +198,7 @@ class Pack:
         p.popSon0 = np.zeros(K, np.int32)
         p.popSon1 = np.zeros(K, np.int32)
         p.sampleAge = np.zeros(K)
+        p.updateSampleAge = np.zeros(K, np.int32)
         p.thetaAlpha, p.thetaBeta, p.thetaStart = np.zeros(K), np.zeros(K), np.zeros(K)
         p.ageAlpha, p.ageBeta, p.ageStart = np.zeros(K), np.zeros(K), np.zeros(K)
         for k in range(K):
@@ -204,7 +206,7 @@ class Pack:
             p.popName.append(nxt())
             p.popFather[k], p.popSon0[k], p.popSon1[k] = int(nxt()), int(nxt()), int(nxt())
             p.sampleAge[k] = fl()
-            nxt()  # updateSampleAge
+            p.updateSampleAge[k] = int(nxt())
             p.thetaAlpha[k], p.thetaBeta[k], p.thetaStart[k] = fl(), fl(), fl()
             p.ageAlpha[k], p.ageBeta[k], p.ageStart[k] = fl(), fl(), fl()
         p.bandSrc, p.bandTgt = np.zeros(max(B, 1), np.int32), np.zeros(max(B, 1), np.int32)
@@ -301,9 +303,11 @@ class Sampler:
                                                 ph.ctypes.data, cn.ctypes.data,
                                                 rates.ctypes.data if use_rates else None), "load_loci")
         k.update(ta=p.thetaAlpha, tb=p.thetaBeta, ts=p.thetaStart, aa=p.ageAlpha, ab=p.ageBeta,
-                 as_=p.ageStart, sa=p.sampleAge, ma=p.mrAlpha, mb=p.mrBeta, ft=p.ftTaus, pf_=p.printFactors)
+                 as_=p.ageStart, sa=p.sampleAge, ma=p.mrAlpha, mb=p.mrBeta, ft=p.ftTaus, pf_=p.printFactors,
+                 usa=np.ascontiguousarray(getattr(p, "updateSampleAge", np.zeros(p.K, np.int32)), dtype=np.int32))
         self.mcfg = GphMcmcConfig(_dp(k["ta"]), _dp(k["tb"]), _dp(k["ts"]), _dp(k["aa"]), _dp(k["ab"]),
-                                  _dp(k["as_"]), _dp(k["sa"]), _dp(k["ma"]), _dp(k["mb"]),
+                                  _dp(k["as_"]), _dp(k["sa"]), k["usa"].ctypes.data_as(C.POINTER(C.c_int32)),
+                                  _dp(k["ma"]), _dp(k["mb"]),
                                   p.ftCoalTime, p.ftMigTime, p.ftTheta, p.ftMigRate, p.ftMixing,
                                   _dp(k["ft"]), p.seed, p.startMig, p.doMixing, p.samplesPerLog,
                                   p.numParameters, _dp(k["pf_"]))

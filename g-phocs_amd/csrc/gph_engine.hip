@@ -575,7 +575,7 @@ int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result
   if (a->num_aff > 2 * GPH_MAXB) return GPH_EARG;
   GphTauArgs &A = e->tau;
   memset(&A, 0, sizeof A);
-  A.ap = a->ap; A.son0 = a->son0; A.son1 = a->son1; A.isRoot = a->isRoot; A.num_aff = a->num_aff;
+  A.ap = a->ap; A.son0 = a->son0; A.son1 = a->son1; A.isRoot = a->isRoot; A.num_aff = a->num_aff; A.mode = a->mode;
   A.tauold = a->tauold; A.taunew = a->taunew; A.taub0 = a->taub0; A.taub1 = a->taub1;
   A.taufactor0 = a->taufactor0; A.taufactor1 = a->taufactor1;
   for (int i = 0; i < a->num_aff; i++) {

@@ -412,6 +412,24 @@ GPH_DEV void kb_tau_eval(const GphDev &D, int g, const GphTauArgs &A)
       tgtP = MG(mig, MG_TPOP);
       age_mt = MAGE(mig);
       if (age_mt < A.taub0 || age_mt > A.taub1) continue;
+      if (A.mode) {
+        /* UpdateSampleAge, GPhoCS.c:4222-4243: below / above the old sample age */
+        const int up = age_mt > A.tauold;
+        const double tb = up ? A.taub1 : A.taub0, tf = up ? A.taufactor1 : A.taufactor0;
+        if (srcP == ap) {
+          inORout = 1;
+          ev = MG(mig, MG_TEV);
+          pop = tgtP;
+          new_age = tb + tf * (age_mt - tb);
+          if (up) n1_1++; else n1_0++;
+        } else if (tgtP == ap) {
+          inORout = 0;
+          ev = MG(mig, MG_SEV);
+          pop = srcP;
+          new_age = tb + tf * (age_mt - tb);
+          if (up) n1_1++; else n1_0++;
+        }
+      } else
       if ((srcP == s0 && tgtP == s1) || (srcP == s1 && tgtP == s0)) {
         n1_0++;
       } else if (srcP == ap) {
@@ -492,13 +510,18 @@ GPH_DEV void kb_tau_eval(const GphDev &D, int g, const GphTauArgs &A)
     }
     if (!gph_failed()) {
       gd = rubber_band_ripple(1);
-      if (A.isRoot) gd += rubber_band(ap, A.taub0, A.tauold, A.taufactor1, 0, &n1_1);
-      else gd += rubber_band(ap, A.taub1, A.tauold, A.taufactor1, 0, &n1_1);
-      gd += rubber_band(s0, A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
-      gd += rubber_band(s1, A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
+      if (A.mode) {
+        gd += rubber_band(ap, A.taub1, A.tauold, A.taufactor1, 0, &n1_1);
+        gd += rubber_band(ap, A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
+      } else {
+        if (A.isRoot) gd += rubber_band(ap, A.taub0, A.tauold, A.taufactor1, 0, &n1_1);
+        else gd += rubber_band(ap, A.taub1, A.tauold, A.taufactor1, 0, &n1_1);
+        gd += rubber_band(s0, A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
+        gd += rubber_band(s1, A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
+      }
       setFS(FS_GENDELTA, gd);
       dGen += gd;
-      if (n1_0 + n1_1) {
+      if (A.mode || n1_0 + n1_1) {     /* UpdateSampleAge always re-evaluates (GPhoCS.c:4431) */
         dData -= FS(FS_DATALNL);
         dData += lik_compute(1);
       }
@@ -521,10 +544,15 @@ GPH_DEV void kb_tau_commit(const GphDev &D, int g, const GphTauArgs &A)
   double age;
   stage_in(D, g, D.shadow, 0);
   setFS(FS_GENLNL, FS(FS_GENLNL) + FS(FS_GENDELTA));
-  if (A.isRoot) rubber_band(A.ap, A.taub0, A.tauold, A.taufactor1, 1, &dummy);
-  else rubber_band(A.ap, A.taub1, A.tauold, A.taufactor1, 1, &dummy);
-  rubber_band(A.son0, A.taub0, A.tauold, A.taufactor0, 1, &dummy);
-  rubber_band(A.son1, A.taub0, A.tauold, A.taufactor0, 1, &dummy);
+  if (A.mode) {   /* UpdateSampleAge commit, GPhoCS.c:4500-4509 */
+    rubber_band(A.ap, A.taub1, A.tauold, A.taufactor1, 1, &dummy);
+    rubber_band(A.ap, A.taub0, A.tauold, A.taufactor0, 1, &dummy);
+  } else {
+    if (A.isRoot) rubber_band(A.ap, A.taub0, A.tauold, A.taufactor1, 1, &dummy);
+    else rubber_band(A.ap, A.taub1, A.tauold, A.taufactor1, 1, &dummy);
+    rubber_band(A.son0, A.taub0, A.tauold, A.taufactor0, 1, &dummy);
+    rubber_band(A.son1, A.taub0, A.tauold, A.taufactor0, 1, &dummy);
+  }
   lik_reset_saved();
   for (i = 0; i < ISC(IS_RB_NUM); i++) {
     nw = RBI(1, i);

@@ -24,7 +24,7 @@ struct gph_mcmc {
   gph_engine *e;
   int n, Kc, K, B, rootPop;
   int64_t Ltot;
-  std::vector<int> popFather, popSon0, popSon1, bandSrc, bandTgt;
+  std::vector<int> popFather, popSon0, popSon1, bandSrc, bandTgt, updateSampleAge;
   std::vector<double> theta, popAge, sampleAge, migRate, bandStart, bandEnd;
   std::vector<double> thetaAlpha, thetaBeta, thetaStart, ageAlpha, ageBeta, ageStart, mrAlpha, mrBeta, ftTaus;
   std::vector<double> printFactors, paramVals;
@@ -299,6 +299,71 @@ static int update_tau(gph_mcmc *m, int iteration, int *accepted)
   return push_model(m);
 }
 
+// UpdateSampleAge, GPhoCS.c:4006-4584: host part (bounds, proposal, affected bands, decision);
+// the per-locus loops run in the tau kernels with mode = 1
+static int update_sample_age(gph_mcmc *m, int iteration, int *accepted)
+{
+  int rc;
+  for (int pop = 0; pop < m->Kc; ++pop) {
+    accepted[pop] = 0;
+    if (!m->updateSampleAge[pop]) continue;
+    gph_tau_args A;
+    gph_tau_result R;
+    int k, b, num_aff = 0;
+    double tauold, taunew, taub[2], taufactor[2], lnacc, age;
+    memset(&A, 0, sizeof A);
+    tauold = m->sampleAge[pop];
+    taub[0] = 0.0;
+    taub[1] = m->popAge[m->popFather[pop]];
+    taunew = tauold + m->ftTaus[pop] * g_rnd2normal8(m);
+    taunew = h_reflect(taunew, taub[0], taub[1]);
+    for (k = 0; k < 2; ++k) taufactor[k] = (taunew - taub[k]) / (tauold - taub[k]);
+    for (b = 0; b < m->B; ++b) {
+      if (m->bandTgt[b] != pop) continue;
+      if (m->bandEnd[b] < taub[1] && m->bandEnd[b] > taub[0]) {
+        age = m->bandEnd[b];
+        A.aff_bands[num_aff] = b; A.start_or_end[num_aff] = 0;
+        A.new_band_ages[num_aff] = taub[age > taunew] + (age - taub[age > taunew]) / taufactor[age > taunew];
+        ++num_aff;
+      }
+      if (m->bandStart[b] < taub[1] && m->bandStart[b] > taub[0]) {
+        age = m->bandStart[b];
+        A.aff_bands[num_aff] = b; A.start_or_end[num_aff] = 1;
+        A.new_band_ages[num_aff] = taub[age > taunew] + (age - taub[age > taunew]) / taufactor[age > taunew];
+        if (A.new_band_ages[num_aff] < tauold) A.new_band_ages[num_aff] = tauold;
+        ++num_aff;
+      }
+    }
+    /* kernels see the OLD sample age (GPhoCS.c:4116) */
+    lnacc = log(taunew / tauold) * (m->ageAlpha[pop] - 1) - (taunew - tauold) * m->ageBeta[pop];
+    A.ap = pop; A.son0 = -1; A.son1 = -1; A.isRoot = 0; A.num_aff = num_aff; A.mode = 1;
+    A.tauold = tauold; A.taunew = taunew; A.taub0 = taub[0]; A.taub1 = taub[1];
+    A.taufactor0 = taufactor[0]; A.taufactor1 = taufactor[1];
+    if ((rc = push_model(m))) return rc;
+    if ((rc = gph_engine_tau_evaluate(m->e, &A, &R))) return rc;
+    int mig_conflict = R.first_conflict_locus >= 0;
+    lnacc += R.dataDelta + R.genDelta + R.ntj0 * log(taufactor[0]) + R.ntj1 * log(taufactor[1]);
+    if (!mig_conflict && (lnacc >= 0 || g_rndu(m) < exp(lnacc))) {
+      ++accepted[pop];
+      m->dataLogLikelihood += R.dataDelta;
+      m->logLikelihood += (R.dataDelta + R.genDelta) / m->Ltot;
+      if ((rc = gph_engine_tau_commit(m->e))) return rc;
+      m->sampleAge[pop] = taunew;
+    } else {
+      if (mig_conflict) m->rubberband_conflicts++;
+      if ((rc = gph_engine_tau_revert(m->e, R.first_conflict_locus))) return rc;
+    }
+  }
+  for (int pop = 0; pop < m->Kc; ++pop) {
+    char nm[32];
+    if (!m->updateSampleAge[pop]) continue;
+    snprintf(nm, sizeof nm, "SAGE%d", pop);
+    rec_line(m, iteration, nm, accepted[pop]);
+    if (m->rec) fprintf(m->rec, "CONFLICTS %lld\n", (long long)m->rubberband_conflicts);
+  }
+  return push_model(m);
+}
+
 // mixing, GPhoCS.c:4688-4912: host part
 static int mixing(gph_mcmc *m, double finetune, int *accepted)
 {
@@ -369,7 +434,7 @@ static void record_param_vals(gph_mcmc *m)
   for (int pop = m->Kc; pop < m->K; pop++) m->paramVals[ind++] = m->popAge[pop];
   for (int b = 0; b < m->B; b++) m->paramVals[ind++] = m->migRate[b];
   for (int pop = 0; pop < m->Kc; pop++)
-    if (m->sampleAge[pop] > 0.0) m->paramVals[ind++] = m->sampleAge[pop];
+    if (m->updateSampleAge[pop] || m->sampleAge[pop] > 0.0) m->paramVals[ind++] = m->sampleAge[pop];
 }
 
 extern "C" {
@@ -386,6 +451,8 @@ int gph_mcmc_create(gph_engine *e, const gph_config *cfg, const gph_mcmc_config 
   if (m->B) { m->bandSrc.assign(cfg->bandSrc, cfg->bandSrc + m->B); m->bandTgt.assign(cfg->bandTgt, cfg->bandTgt + m->B); }
   m->theta.assign(m->K, 0.0); m->popAge.assign(m->K, 0.0);
   m->sampleAge.assign(mc->sampleAge, mc->sampleAge + m->K);
+  m->updateSampleAge.assign(m->K, 0);
+  if (mc->updateSampleAge) for (int p = 0; p < m->Kc; p++) m->updateSampleAge[p] = mc->updateSampleAge[p] != 0;
   m->migRate.assign(m->B + 1, 0.0); m->bandStart.assign(m->B + 1, 0.0); m->bandEnd.assign(m->B + 1, 0.0);
   m->thetaAlpha.assign(mc->thetaAlpha, mc->thetaAlpha + m->K);
   m->thetaBeta.assign(mc->thetaBeta, mc->thetaBeta + m->K);
@@ -475,6 +542,8 @@ int gph_mcmc_iteration(gph_mcmc *m, int32_t iteration)
   }
   if ((rc = update_tau(m, iteration, accArr.data()))) return rc;
   for (int pop = m->Kc; pop < m->K; pop++) m->acc[5] += accArr[pop];
+  if ((rc = update_sample_age(m, iteration, accArr.data()))) return rc;
+  for (int pop = 0; pop < m->Kc; pop++) m->acc[5] += accArr[pop];
   if (m->doMixing) {
     if ((rc = refresh_totals(m))) return rc;
     if ((rc = mixing(m, m->ftMixing, &acc))) return rc;

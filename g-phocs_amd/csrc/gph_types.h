@@ -139,7 +139,7 @@ struct alignas(16) GphLds {
 
 // arguments of the tau-evaluate kernel (host part of UpdateTau, GPhoCS.c:3224-3461)
 struct GphTauArgs {
-  int32_t ap, son0, son1, isRoot, num_aff;
+  int32_t ap, son0, son1, isRoot, num_aff, mode;   // mode 1 = UpdateSampleAge (GPhoCS.c:4006)
   double tauold, taunew, taub0, taub1, taufactor0, taufactor1;
   int16_t aff_bands[GPH_MAXB * 2];
   int16_t start_or_end[GPH_MAXB * 2];

@@ -71,8 +71,11 @@ typedef struct {
   int64_t total_mig_nodes;    /* sum of num_migs after the migration-node sweep (GPhoCS.c:1517-1520) */
 } gph_sweep_result;
 
+/* host part of UpdateTau (GPhoCS.c:3224-3461) or, with mode = 1, of UpdateSampleAge
+ * (GPhoCS.c:4006-4128; ap = the current population whose sample age moves, son0 = son1 = -1,
+ * taub0 = 0, taub1 = father age, tauold/taunew = old/new sample age) */
 typedef struct {
-  int32_t ap, son0, son1, isRoot, num_aff;
+  int32_t ap, son0, son1, isRoot, num_aff, mode;
   double tauold, taunew, taub0, taub1, taufactor0, taufactor1;
   int32_t aff_bands[32];
   int32_t start_or_end[32];
@@ -138,11 +141,12 @@ int gph_engine_hbm_bytes(gph_engine *e, double *bytes);
  * host MCMC driver: the iteration body of performMCMC (GPhoCS.c:1476-1821) above the
  * engine: general-slot RNG, priors, accept decisions of the global proposals
  * (UpdateTheta GPhoCS.c:3037, UpdateMigRates :3115, UpdateTau :3224 host part,
- * mixing :4688 host part), accumulators dataState.{logLikelihood,dataLogLikelihood}. */
+ * UpdateSampleAge :4006 host part, mixing :4688 host part), accumulators dataState.{logLikelihood,dataLogLikelihood}. */
 typedef struct {
   const double *thetaAlpha, *thetaBeta, *thetaStart;   /* [K] */
   const double *ageAlpha, *ageBeta, *ageStart;         /* [K] (ancestral pops) */
   const double *sampleAge;                             /* [K] */
+  const int32_t *updateSampleAge;                      /* [K] 1 = estimated ("age x e"), NULL = none */
   const double *mrAlpha, *mrBeta;                      /* [B] */
   double ftCoalTime, ftMigTime, ftTheta, ftMigRate, ftMixing;
   const double *ftTaus;                                /* [K] */

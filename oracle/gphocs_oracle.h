@@ -158,6 +158,7 @@ int go_update_mig_spr(go_state *s);
 int go_update_theta(go_state *s, double finetune);
 int go_update_mig_rates(go_state *s, double finetune);
 void go_update_tau(go_state *s, const double *finetunes, int *accepted);
+void go_update_sample_age(go_state *s, const double *finetunes, int *accepted);
 int go_mixing(go_state *s, double finetune);
 int go_synchronize_events(go_state *s, go_locus *q);
 int go_check_all(go_state *s);

@@ -651,6 +651,180 @@ void go_update_tau(go_state *s, const double *finetunes, int *accepted)
   }
 }
 
+/* UpdateSampleAge, GPhoCS.c:4006-4584: the sample age of a current population with an
+ * estimated ("e") age is moved inside [0, father age]; the population's single chain is
+ * rubber-banded around the old sample age (below it with factor[0], above with factor[1]) */
+void go_update_sample_age(go_state *s, const double *finetunes, int *accepted)
+{
+  go_model *m = &s->m;
+  int k, pop, g, ntj[2], num_aff, aff_bands[2 * GO_MAXB], start_or_end[2 * GO_MAXB], b, tgt, mig_conflict;
+  double tauold, taunew, taub[2], taufactor[2], lnacc, new_band_ages[2 * GO_MAXB], dData, dGen, age;
+  for (pop = 0; pop < m->Kc; pop++) {
+    accepted[pop] = 0;
+    if (!m->updateSampleAge[pop]) continue;
+    tauold = m->sampleAge[pop];
+    taub[0] = 0.0;
+    taub[1] = m->popAge[m->popFather[pop]];
+    taunew = tauold + finetunes[pop] * go_rnd2normal8(&s->gx, &s->gy, &s->gz);
+    taunew = go_reflect(taunew, taub[0], taub[1]);
+    for (k = 0; k < 2; ++k) taufactor[k] = (taunew - taub[k]) / (tauold - taub[k]);
+    num_aff = 0;
+    for (b = 0; b < m->B; ++b) {
+      tgt = m->bandTgt[b];
+      if (tgt == pop) {
+        if (m->bandEnd[b] < taub[1] && m->bandEnd[b] > taub[0]) {
+          aff_bands[num_aff] = b;
+          start_or_end[num_aff] = 0;
+          age = m->bandEnd[b];
+          new_band_ages[num_aff] = taub[age > taunew] + (age - taub[age > taunew]) / taufactor[age > taunew];
+          ++num_aff;
+        }
+        if (m->bandStart[b] < taub[1] && m->bandStart[b] > taub[0]) {
+          aff_bands[num_aff] = b;
+          start_or_end[num_aff] = 1;
+          age = m->bandStart[b];
+          new_band_ages[num_aff] = taub[age > taunew] + (age - taub[age > taunew]) / taufactor[age > taunew];
+          if (new_band_ages[num_aff] < tauold) new_band_ages[num_aff] = tauold;
+          ++num_aff;
+        }
+      }
+    }
+    /* the model keeps the OLD sample age during the evaluation (GPhoCS.c:4116) */
+    lnacc = log(taunew / tauold) * (m->ageAlpha[pop] - 1) - (taunew - tauold) * m->ageBeta[pop];
+    dData = 0.0;
+    dGen = 0.0;
+    mig_conflict = 0;
+    ntj[0] = ntj[1] = 0;
+    for (g = 0; g < s->L; ++g) {
+      go_locus *q = &s->loc[g];
+      double age_mt, new_age = 0.0, dGen_l = 0, dData_l = 0;
+      int srcP, tgtP, fatherNode, inode, inORout = -1, ev = -1, n1[2] = {0, 0}, i, mig, mig1, band, migPop = -1;
+      q->mig_conflict_log = 0;
+      if (mig_conflict == 0) {
+        q->mig_conflict_log = 1;
+        q->rb_num_moved = 0;
+        for (i = 0; i < q->num_migs; ++i) {
+          if (mig_conflict == 0) {
+            mig = q->living[i];
+            band = q->mig[mig].band;
+            srcP = q->mig[mig].source_pop;
+            tgtP = q->mig[mig].target_pop;
+            age_mt = q->mig[mig].age;
+            if (age_mt < taub[0] || age_mt > taub[1]) continue;
+            if (srcP == pop) {
+              inORout = 1;
+              ev = q->mig[mig].target_event;
+              migPop = tgtP;
+              new_age = taub[age_mt > tauold] + taufactor[age_mt > tauold] * (age_mt - taub[age_mt > tauold]);
+              ++n1[age_mt > tauold];
+            } else if (tgtP == pop) {
+              inORout = 0;
+              ev = q->mig[mig].source_event;
+              migPop = srcP;
+              new_age = taub[age_mt > tauold] + taufactor[age_mt > tauold] * (age_mt - taub[age_mt > tauold]);
+              ++n1[age_mt > tauold];
+            }
+            if (ev >= 0) {
+              inode = q->mig[mig].branch;
+              if (new_age >= m->bandEnd[band]) mig_conflict = 1;
+              else if (new_age <= m->bandStart[band]) mig_conflict = 1;
+              else if (inORout == 0 && new_age > age_mt) {
+                fatherNode = q->father[inode];
+                mig1 = go_find_first_mig(q, inode, q->mig[mig].age);
+                if (mig1 >= 0 && pop != q->mig[mig1].source_pop && new_age >= q->mig[mig1].age) mig_conflict = 1;
+                else if (fatherNode >= 0 && new_age >= q->age[fatherNode]) mig_conflict = 1;
+              } else if (inORout == 1 && new_age < age_mt) {
+                mig1 = go_find_last_mig(q, inode, q->mig[mig].age);
+                if (mig1 >= 0 && pop != q->mig[mig1].target_pop && new_age <= q->mig[mig1].age) mig_conflict = 1;
+                else if (new_age <= q->age[inode]) mig_conflict = 1;
+              }
+              if (mig_conflict == 0) {
+                q->rb_orig[q->rb_num_moved] = ev;
+                q->rb_pops[q->rb_num_moved] = migPop;
+                q->rb_new_ages[q->rb_num_moved] = new_age;
+                q->rb_num_moved++;
+                ev = -1;
+              }
+            }
+          }
+        }
+        if (mig_conflict) {
+          q->rb_num_moved = 0;
+        } else {
+          for (i = 0; i < num_aff; ++i) {
+            band = aff_bands[i];
+            tgtP = m->bandTgt[band];
+            for (ev = q->first_event[tgtP]; ev >= 0; ev = q->ev_next[ev]) {
+              if (q->ev_node[ev] == band &&
+                  ((start_or_end[i] && q->ev_type[ev] == GO_MIG_BAND_START) || q->ev_type[ev] == GO_MIG_BAND_END))
+                break;
+            }
+            if (ev < 0) go_fatal(s, 174, "UpdateSampleAge: band event not found");
+            q->rb_orig[q->rb_num_moved] = ev;
+            q->rb_pops[q->rb_num_moved] = tgtP;
+            q->rb_new_ages[q->rb_num_moved] = new_band_ages[i];
+            q->rb_num_moved++;
+          }
+          q->genDelta = go_rubber_band_ripple(s, q, 1);
+          q->genDelta += go_rubber_band(s, q, pop, taub[1], tauold, taufactor[1], 0, &n1[1]);
+          q->genDelta += go_rubber_band(s, q, pop, taub[0], tauold, taufactor[0], 0, &n1[0]);
+          dGen_l += q->genDelta;
+          ntj[0] += n1[0];
+          ntj[1] += n1[1];
+          dData_l -= q->dataLnL;
+          dData_l += go_lik_compute(s, q, 1);
+          dData += dData_l;
+          dGen += dGen_l;
+        }
+      }
+    }
+    lnacc += dData + dGen + ntj[0] * log(taufactor[0]) + ntj[1] * log(taufactor[1]);
+    if (!mig_conflict && (lnacc >= 0 || GRND(s) < exp(lnacc))) {
+      ++accepted[pop];
+      s->dataLogLikelihood += dData;
+      s->logLikelihood += (dData + dGen) / s->L;
+      for (g = 0; g < s->L; g++) {
+        go_locus *q = &s->loc[g];
+        int dummy = 0, i, mig, nw;
+        q->genLnL += q->genDelta;
+        go_rubber_band(s, q, pop, taub[1], tauold, taufactor[1], 1, &dummy);
+        go_rubber_band(s, q, pop, taub[0], tauold, taufactor[0], 1, &dummy);
+        go_lik_reset_saved(s, q);
+        for (i = 0; i < q->rb_num_moved; ++i) {
+          nw = q->rb_new[i];
+          mig = q->ev_node[nw];
+          if (q->ev_type[nw] == GO_IN_MIG) {
+            q->mig[mig].target_event = nw;
+            q->mig[mig].age = q->rb_new_ages[i];
+          } else if (q->ev_type[nw] == GO_OUT_MIG) {
+            q->mig[mig].source_event = nw;
+          }
+          go_remove_event(q, q->rb_orig[i]);
+        }
+        q->rb_num_moved = 0;
+      }
+      m->sampleAge[pop] = taunew;
+    } else {
+      if (mig_conflict) {
+        s->rubberband_mig_conflicts++;
+        for (g = 0; g < s->L; ++g) {
+          go_locus *q = &s->loc[g];
+          if (q->mig_conflict_log == 1) {
+            go_lik_revert(s, q);
+            go_rubber_band_ripple(s, q, 0);
+          }
+        }
+      } else {
+        for (g = s->L - 1; g >= 0; --g) {
+          go_locus *q = &s->loc[g];
+          go_lik_revert(s, q);
+          go_rubber_band_ripple(s, q, 0);
+        }
+      }
+    }
+  }
+}
+
 /* mixing, GPhoCS.c:4688-4912 */
 int go_mixing(go_state *s, double finetune)
 {
@@ -871,7 +1045,7 @@ static void rec(go_state *s, FILE *tf, int it, const char *what, int acc)
 }
 
 /* one iteration of performMCMC, GPhoCS.c:1476-1821 (genetreeSamples == 1, no
- * find-finetunes, no admixture, no UpdateSampleAge / UpdateLocusRate) */
+ * find-finetunes, no admixture, no UpdateLocusRate) */
 int go_iteration(go_state *s, int iteration, FILE *tf)
 {
   go_model *m = &s->m;
@@ -895,6 +1069,14 @@ int go_iteration(go_state *s, int iteration, FILE *tf)
     rec(s, tf, iteration, nm, accArr[pop]);
   }
   if (tf) fprintf(tf, "CONFLICTS %d\n", s->rubberband_mig_conflicts);
+  go_update_sample_age(s, m->ftTaus, accArr);
+  for (pop = 0; pop < m->Kc; pop++) {
+    char nm[32];
+    if (!m->updateSampleAge[pop]) continue;
+    snprintf(nm, sizeof nm, "SAGE%d", pop);
+    rec(s, tf, iteration, nm, accArr[pop]);
+    if (tf) fprintf(tf, "CONFLICTS %d\n", s->rubberband_mig_conflicts);
+  }
   if (m->doMixing) {
     acc = go_mixing(s, m->ftMixing);
     rec(s, tf, iteration, "MIX", acc);

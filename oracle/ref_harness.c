@@ -253,6 +253,15 @@ static int one_iteration(FILE *tf, int iteration, int *acceptCountArray, int ver
     fprintf(tf, "CONFLICTS %d\n", misc_stats.rubberband_mig_conflicts);
   }
   UpdateSampleAge(mcmcSetup.finetunes.taus, acceptCountArray);
+  if (verboseTrace) {
+    for (pop = 0; pop < pt->numCurPops; pop++) {
+      char nm[32];
+      if (!pt->pops[pop]->updateSampleAge) continue;
+      snprintf(nm, sizeof nm, "SAGE%d", pop);
+      rec(tf, iteration, nm, acceptCountArray[pop]);
+      fprintf(tf, "CONFLICTS %d\n", misc_stats.rubberband_mig_conflicts);
+    }
+  }
   if (mcmcSetup.doMixing) {
     acc = mixing(mcmcSetup.finetunes.mixing);
     if (verboseTrace) rec(tf, iteration, "MIX", acc);

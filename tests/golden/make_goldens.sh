@@ -29,4 +29,8 @@ gen m3 3 16 300 120 40 --mig-beta 0.00000004
 gen m4 4 12 300 60 20 --mig-beta 0.00000004
 gen c5 5 10 300 30 10
 gen s3 3 12 300 40 20 --start-mig 10 --mig-beta 0.0000001 --no-mixing
+
+# estimated sample ages ("age x e"): UpdateSampleAge (GPhoCS.c:4006) is live
+gen a6 6 12 300 80 20 --mig-beta 0.00000004
+gen a7 7 12 300 100 25 --mig-beta 0.00000004
 ls -la

@@ -30,6 +30,9 @@ CONFIGS = {
     4: dict(pops=[2, 2, 2, 1, 1], bands=[(0, 1), (1, 0), (3, 2), (4, 3)], loci=100000),
     5: dict(pops=[2, 2, 2, 1, 1, 1, 1], bands=[(0, 1), (1, 0), (3, 2), (4, 3)], loci=200000,
             ancient=6),
+    # estimated ("e") sample ages: UpdateSampleAge is live, mixing stays on
+    6: dict(pops=[2, 2, 2, 1], bands=[(0, 1), (3, 2), (2, 3)], loci=1000, ancient=3, ancient_est=True),
+    7: dict(pops=[2, 1, 2], bands=[(0, 1), (1, 0), (2, 1)], loci=1000, ancient=1, ancient_est=True),
 }
 
 
@@ -99,7 +102,7 @@ def write_ctl(path, cfg, seqfile, tracefile, loci, seed, iters, samples_per_log,
         sid += cfg["pops"][i]
         out.append(f"\t\tsamples\t\t{samples}")
         if cfg.get("ancient") == i:
-            out.append("\t\tage\t\t0.000002 f")
+            out.append("\t\tage\t\t0.000002 " + ("e" if cfg.get("ancient_est") else "f"))
         out.append("\tPOP-END\n")
     out.append("CURRENT-POPS-END\n")
     out.append("ANCESTRAL-POPS-START\n")
