@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libgphocs_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wno-unused-result"]
+               "-Wno-unused-result", "-pthread"]
 
 # Capacity variants of the same library (same C ABI, same sources): the static LDS image of a locus is
 # sized by compile-time capacities (csrc/gph_types.h), and a tighter image means more resident
@@ -48,7 +48,7 @@ def lib_path(name="m"):
 
 def build(verbose=False):
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU), every variant."""
-    srcs = [os.path.join(CSRC, "gph_engine.hip"), os.path.join(CSRC, "gph_mcmc.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
         [os.path.join(REPO, "include", "gphocs_hip.h")]
     for name, (cl, ck, cb, waves, fn) in VARIANTS.items():
@@ -57,6 +57,13 @@ def build(verbose=False):
             continue
         cmd = ["hipcc"] + HIPCC_FLAGS + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}",
                                          f"-DGPH_SWEEP_WAVES={waves}"] + srcs + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    # the program: same command line as the reference's G-PhoCS binary (GPhoCS.c:84-238)
+    exe, main = os.path.join(_HERE, "G-PhoCS-hip"), os.path.join(CSRC, "gph_main.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(main), os.path.getmtime(deps[-1])):
+        cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(REPO, "include"), main, "-ldl", "-o", exe]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
@@ -100,6 +107,14 @@ class GphMcmcConfig(C.Structure):
                 ("printFactors", C.POINTER(C.c_double))]
 
 
+class GphControlInfo(C.Structure):
+    _fields_ = [("seqFile", C.c_char_p), ("traceFile", C.c_char_p), ("rateFile", C.c_char_p),
+                ("numLoci", C.c_int32), ("burnin", C.c_int32), ("numSamples", C.c_int32),
+                ("sampleSkip", C.c_int32), ("logsPerLine", C.c_int32), ("mutRateMode", C.c_int32),
+                ("findFinetunes", C.c_int32), ("numSampleSlots", C.c_int32),
+                ("varRatesAlpha", C.c_double), ("ftLocusRate", C.c_double)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32,
                            C.POINTER(C.c_double), C.c_int32)
 
@@ -114,6 +129,8 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_engine_num_loci", "gph_engine_hbm_bytes", "gph_debug_math", "gph_engine_class_stats",
     "gph_mcmc_create", "gph_mcmc_destroy", "gph_mcmc_initialize", "gph_mcmc_set_record_file",
     "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
+    "gph_mcmc_param_vals", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
+    "gph_control_sample_name", "gph_loci_read", "gph_loci_free", "gph_loci_arrays", "gph_run_control_file",
 ]
 
 
@@ -159,6 +176,21 @@ def _load_library(path):
     lib.gph_engine_last_kernel_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
     lib.gph_engine_get_counters.argtypes = [C.c_void_p, C.POINTER(GphCounters), C.c_int32]
     lib.gph_engine_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    lib.gph_mcmc_param_vals.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.gph_control_read.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.gph_control_free.argtypes = [C.c_void_p]
+    lib.gph_control_free.restype = None
+    lib.gph_control_get.argtypes = [C.c_void_p, C.POINTER(GphConfig), C.POINTER(GphMcmcConfig),
+                                    C.POINTER(GphControlInfo)]
+    lib.gph_control_pop_name.argtypes = [C.c_void_p, C.c_int32]
+    lib.gph_control_pop_name.restype = C.c_char_p
+    lib.gph_control_sample_name.argtypes = [C.c_void_p, C.c_int32]
+    lib.gph_control_sample_name.restype = C.c_char_p
+    lib.gph_loci_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_void_p), C.c_char_p, C.c_int32]
+    lib.gph_loci_free.argtypes = [C.c_void_p]
+    lib.gph_loci_free.restype = None
+    lib.gph_loci_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+    lib.gph_run_control_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
     return lib
 
 
@@ -242,6 +274,73 @@ class Pack:
         p.counts = np.array(counts, dtype=np.int32)
         p.mutRates = np.array(rates)
         return p
+
+    @staticmethod
+    def from_control(ctl_path, lib=None, secondary=None, seq_path=None, threads=0):
+        """control file + sequence file -> Pack, through the library's own front end
+        (gph_control_read / gph_loci_read; the reference's readControlFile / readSeqFile path)"""
+        lib = lib or load_library()
+        ctl = C.c_void_p()
+        rc = lib.gph_control_read(os.fsencode(ctl_path), os.fsencode(secondary) if secondary else None, C.byref(ctl))
+        if rc:
+            raise ValueError(f"gph_control_read({ctl_path}) failed with status {rc}")
+        try:
+            cfg, mc, info = GphConfig(), GphMcmcConfig(), GphControlInfo()
+            lib.gph_control_get(ctl, C.byref(cfg), C.byref(mc), C.byref(info))
+            p = Pack()
+            p.n, p.Kc, p.K, p.B, p.rootPop = cfg.n, cfg.Kc, cfg.K, cfg.B, cfg.rootPop
+            K, B = p.K, p.B
+
+            def arr(ptr, k, dt):
+                return np.array([ptr[i] for i in range(k)], dtype=dt)
+            p.samplesPerPop = arr(cfg.samplesPerPop, p.Kc, np.int32)
+            p.popFather, p.popSon0, p.popSon1 = (arr(cfg.popFather, K, np.int32), arr(cfg.popSon0, K, np.int32),
+                                                 arr(cfg.popSon1, K, np.int32))
+            p.bandSrc = arr(cfg.bandSrc, B, np.int32) if B else np.zeros(1, np.int32)
+            p.bandTgt = arr(cfg.bandTgt, B, np.int32) if B else np.zeros(1, np.int32)
+            p.popName = [lib.gph_control_pop_name(ctl, k).decode() for k in range(K)]
+            p.sampleNames = [lib.gph_control_sample_name(ctl, i).decode() for i in range(p.n)]
+            for nm in ("thetaAlpha", "thetaBeta", "thetaStart", "ageAlpha", "ageBeta", "ageStart", "sampleAge", "ftTaus"):
+                setattr(p, nm, arr(getattr(mc, nm), K, np.float64))
+            p.updateSampleAge = arr(mc.updateSampleAge, K, np.int32)
+            p.mrAlpha = arr(mc.mrAlpha, B, np.float64) if B else np.zeros(1)
+            p.mrBeta = arr(mc.mrBeta, B, np.float64) if B else np.ones(1)
+            p.ftCoalTime, p.ftMigTime, p.ftTheta, p.ftMigRate, p.ftMixing = (mc.ftCoalTime, mc.ftMigTime, mc.ftTheta,
+                                                                             mc.ftMigRate, mc.ftMixing)
+            p.seed, p.startMig, p.doMixing, p.samplesPerLog = mc.seed, mc.startMig, mc.doMixing, mc.samplesPerLog
+            p.burnin, p.numSamplesMcmc, p.sampleSkip, p.mutRateMode = (info.burnin, info.numSamples, info.sampleSkip,
+                                                                       info.mutRateMode)
+            p.numParameters = mc.numParameters
+            p.printFactors = arr(mc.printFactors, p.numParameters, np.float64)
+            p.traceFile, p.seqFile = info.traceFile.decode(), info.seqFile.decode()
+            loci = C.c_void_p()
+            err = C.create_string_buffer(512)
+            rc = lib.gph_loci_read(ctl, os.fsencode(seq_path) if seq_path else None, threads, C.byref(loci), err, 512)
+            if rc:
+                raise ValueError(f"gph_loci_read failed with status {rc}: {err.value.decode()}")
+            try:
+                L, n = C.c_int64(), C.c_int32()
+                po, lf, ph, cn, mr, up = (C.c_void_p() for _ in range(6))
+                lib.gph_loci_arrays(loci, C.byref(L), C.byref(n), C.byref(po), C.byref(lf), C.byref(ph), C.byref(cn),
+                                    C.byref(mr), C.byref(up))
+                p.L = p.numLoci = L.value
+
+                def view(ptr, count, ct, dt):
+                    if count == 0:
+                        return np.zeros(0, dt)
+                    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(count,)).astype(dt, copy=True)
+                p.pattern_offsets = view(po, p.L + 1, C.c_int64, np.int64)
+                Ptot = int(p.pattern_offsets[-1])
+                p.leafcodes = view(lf, Ptot * p.n, C.c_uint8, np.uint8).reshape(-1, p.n)
+                p.numPhases = view(ph, Ptot, C.c_uint8, np.uint8)
+                p.counts = view(cn, Ptot, C.c_int32, np.int32)
+                p.mutRates = view(mr, p.L, C.c_double, np.float64)
+                p.unphased = view(up, p.L, C.c_int32, np.int32)
+            finally:
+                lib.gph_loci_free(loci)
+            return p
+        finally:
+            lib.gph_control_free(ctl)
 
     def shard(self, rank, world):
         """contiguous block of ceil(L/world) loci (mirrors OpenMP static scheduling,

@@ -626,6 +626,13 @@ int gph_mcmc_dump_state(gph_mcmc *m, const char *path, int32_t withCond)
   return 0;
 }
 
+int gph_mcmc_param_vals(gph_mcmc *m, double *vals, int32_t n)
+{
+  if (!m || !vals) return GPH_EARG;
+  for (int i = 0; i < n && i < (int)m->paramVals.size(); i++) vals[i] = m->paramVals[i];
+  return 0;
+}
+
 int gph_mcmc_accept_counts(gph_mcmc *m, int64_t *counts9)
 {
   if (!m || !counts9) return GPH_EARG;

@@ -166,6 +166,42 @@ int gph_mcmc_get_state(gph_mcmc *m, double *logLikelihood, double *dataLogLikeli
                        double *popAge, double *migRate);
 int gph_mcmc_dump_state(gph_mcmc *m, const char *path, int32_t withConditionals);
 int gph_mcmc_accept_counts(gph_mcmc *m, int64_t *counts9);
+/* recordParamVals (GPhoCS.c:802-849) of the last iteration: thetas, taus, migration rates, sample ages */
+int gph_mcmc_param_vals(gph_mcmc *m, double *vals, int32_t n);
+
+/* ------------------------------------------------------------------------------------
+ * input front end (host only, no GPU): the reference's file formats, unchanged.
+ *   gph_control_read   readControlFile + readSecondaryControlFile + checkSettings +
+ *                      finalizeNumParameters              (MCMCcontrol.c:118-463, 575-1478)
+ *   gph_loci_read      readSeqFile + processLocusAlignment + processHetPatterns
+ *                      (AlignmentProcessor.c:468-1158, 1595-1894, 2242-2339) and readRateFile
+ *                      (GPhoCS.c:491-579); the result is what gph_engine_load_loci takes
+ *   gph_run_control_file   main() + the trace-file side of performMCMC (GPhoCS.c:84-238, 1232-1330,
+ *                      1763-1769): same control file, same sequence file, same trace file */
+typedef struct gph_control gph_control;
+typedef struct gph_loci gph_loci;
+typedef struct {
+  const char *seqFile, *traceFile, *rateFile;
+  int32_t numLoci;          /* num-loci of the control file, -1 = all loci of the sequence file */
+  int32_t burnin, numSamples, sampleSkip, logsPerLine;
+  int32_t mutRateMode;      /* 0 CONST, 1 VAR, 2 FIXED */
+  int32_t findFinetunes;
+  int32_t numSampleSlots;   /* haploid leaves per locus (a diploid sample takes two) */
+  double varRatesAlpha, ftLocusRate;
+} gph_control_info;
+int gph_control_read(const char *ctl_path, const char *secondary_ctl_path_or_null, gph_control **out);
+void gph_control_free(gph_control *c);
+/* fills any non-NULL output; pointers inside stay owned by (and valid as long as) the control object */
+int gph_control_get(const gph_control *c, gph_config *cfg, gph_mcmc_config *mc, gph_control_info *info);
+const char *gph_control_pop_name(const gph_control *c, int32_t pop);
+const char *gph_control_sample_name(const gph_control *c, int32_t slot);   /* "" = second haploid of a diploid */
+/* seq_path NULL = the control file's seq-file; threads <= 0 = all host threads; err receives the
+ * reference's error text when the file is rejected */
+int gph_loci_read(const gph_control *c, const char *seq_path, int32_t threads, gph_loci **out, char *err, int32_t errlen);
+void gph_loci_free(gph_loci *l);
+int gph_loci_arrays(const gph_loci *l, int64_t *L, int32_t *n, const int64_t **pattern_offsets, const uint8_t **leafcodes,
+                    const uint8_t **numPhases, const int32_t **counts, const double **mutRates, const int32_t **unphased);
+int gph_run_control_file(const char *ctl_path, const char *secondary_ctl_path_or_null, int32_t device, int32_t verbose);
 
 #ifdef __cplusplus
 }

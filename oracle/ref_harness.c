@@ -356,6 +356,21 @@ static int cmd_time(int argc, char **argv)
   return 0;
 }
 
+/* ingest: wall time of the reference's own start-up path (readControlFile + readSeqFile +
+ * processAlignments, GPhoCS.c:150-205): the CPU baseline of the sequence front end */
+static int cmd_ingest(char *ctl)
+{
+  double t0 = now_s(), t1;
+  long phased = 0;
+  int g;
+  startup(ctl);
+  t1 = now_s();
+  for (g = 0; g < dataSetup.numLoci; g++) phased += dataState.lociData[g]->seqData.numPatterns;
+  printf("{\"loci\": %d, \"samples\": %d, \"phased_patterns\": %ld, \"seconds\": %.6f}\n", dataSetup.numLoci,
+         dataSetup.numSamples, phased, t1 - t0);
+  return 0;
+}
+
 static int cmd_rng(int argc, char **argv)
 {
   unsigned int seed = (unsigned int)strtoul(argv[2], NULL, 10);
@@ -397,6 +412,7 @@ int main(int argc, char **argv)
   if (!strcmp(argv[1], "pack") && argc >= 4) return cmd_pack(argv[2], argv[3]);
   if (!strcmp(argv[1], "run") && argc >= 5) return cmd_run(argc, argv);
   if (!strcmp(argv[1], "time") && argc >= 4) return cmd_time(argc, argv);
+  if (!strcmp(argv[1], "ingest") && argc >= 3) return cmd_ingest(argv[2]);
   if (!strcmp(argv[1], "rng") && argc >= 4) return cmd_rng(argc, argv);
   if (!strcmp(argv[1], "reflect")) return cmd_reflect();
   if (!strcmp(argv[1], "main")) return gphocs_main(argc - 1, argv + 1);

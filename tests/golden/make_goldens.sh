@@ -33,4 +33,9 @@ gen s3 3 12 300 40 20 --start-mig 10 --mig-beta 0.0000001 --no-mixing
 # estimated sample ages ("age x e"): UpdateSampleAge (GPhoCS.c:4006) is live
 gen a6 6 12 300 80 20 --mig-beta 0.00000004
 gen a7 7 12 300 100 25 --mig-beta 0.00000004
+# the reference's own trace files (its main(), unmodified): what G-PhoCS-hip must reproduce
+for name in g1 m3 a7; do timeout 900 $REF main -n 1 $name.ctl >/dev/null 2>&1; done
+# front-end stress input (IUPAC codes, haploids, missing/unknown samples, all-N columns)
+python3 make_stress.py
+timeout 600 $REF pack stress.ctl stress.gpk >/dev/null
 ls -la

@@ -1,0 +1,140 @@
+"""Input front end (g-phocs_amd/csrc/gph_input.cpp, gph_program.cpp): the reference's control-file,
+sequence-file and trace-file formats, unchanged.
+
+  * gph_control_read + gph_loci_read against the processed-locus packs the REAL reference produced
+    from the same files (tests/golden/*.gpk, written by oracle/_ref/gphocs_ref pack): model,
+    priors, finetunes, print factors and -- bit for bit -- every locus's phased pattern table
+    (pattern order, phase order, counts).  stress.* exercises 2-/3-way IUPAC codes, haploids,
+    missing samples, unknown samples, all-N columns, lower case (tests/golden/make_stress.py).
+  * gph_run_control_file (the G-PhoCS main() equivalent) in the host-emulation build against the
+    trace FILES the real reference binary wrote for the same control files (tests/golden/*.trace).
+  * the reference's rejection behaviour for malformed sequence files.
+These run on the CPU: the front end is host code; the chain itself runs in the hostemu build here
+and on the MI355X in test_gpu_parity.py::test_program_trace_file.
+"""
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
+import gphocs_amd as G  # noqa: E402
+import run_hostemu as R  # noqa: E402
+
+CASES = ["g1", "g2", "m3", "m4", "c5", "s3", "a6", "a7", "stress"]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return G.load_library(R.build_hostemu())
+
+
+def _in_dir(path):
+    class _Cd:
+        def __enter__(self):
+            self.old = os.getcwd()
+            os.chdir(path)
+
+        def __exit__(self, *a):
+            os.chdir(self.old)
+    return _Cd()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_control_and_sequences_match_reference_pack(lib, name):
+    ref = G.Pack.load(os.path.join(GOLDEN, name + ".gpk"))
+    with _in_dir(GOLDEN):   # seq-file names in the control files are relative
+        got = G.Pack.from_control(name + ".ctl", lib=lib, threads=3)
+    for f in ("n", "Kc", "K", "B", "rootPop", "L", "seed", "startMig", "doMixing", "samplesPerLog", "mutRateMode",
+              "numParameters", "burnin", "sampleSkip", "ftCoalTime", "ftMigTime", "ftTheta", "ftMigRate",
+              "ftMixing", "popName"):
+        assert getattr(ref, f) == getattr(got, f), f
+    for f in ("samplesPerPop", "popFather", "popSon0", "popSon1", "sampleAge", "updateSampleAge", "thetaAlpha",
+              "thetaBeta", "thetaStart", "ageAlpha", "ageBeta", "ageStart", "ftTaus", "printFactors", "mutRates"):
+        assert np.array_equal(np.asarray(getattr(ref, f)), np.asarray(getattr(got, f))), f   # bit-exact
+    for f in ("bandSrc", "bandTgt", "mrAlpha", "mrBeta"):
+        assert np.array_equal(np.asarray(getattr(ref, f))[:ref.B], np.asarray(getattr(got, f))[:ref.B]), f
+    # the phased pattern tables: integer/byte data, bit-exact, order included
+    for f in ("pattern_offsets", "leafcodes", "numPhases", "counts"):
+        a, b = np.asarray(getattr(ref, f)), np.asarray(getattr(got, f))
+        assert a.shape == b.shape and np.array_equal(a, b), f
+
+
+def test_thread_count_does_not_change_the_result(lib):
+    with _in_dir(GOLDEN):
+        a = G.Pack.from_control("stress.ctl", lib=lib, threads=1)
+        b = G.Pack.from_control("stress.ctl", lib=lib, threads=8)
+    for f in ("pattern_offsets", "leafcodes", "numPhases", "counts"):
+        assert np.array_equal(getattr(a, f), getattr(b, f))
+
+
+@pytest.mark.parametrize("name", ["g1", "m3", "a7"])
+def test_program_writes_the_reference_trace_file(lib, name, tmp_path):
+    """same control file + sequence file -> the trace file of the real G-PhoCS binary, byte for byte"""
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    with _in_dir(tmp_path):
+        assert lib.gph_run_control_file((name + ".ctl").encode(), None, 0, 0) == 0
+    want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
+    got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
+    assert want[0] == got[0]                      # header
+    assert len(want) == len(got)
+    for w, g in zip(want[1:], got[1:]):
+        if w == g:
+            continue
+        # printed with %8.5f / %.6f: allow one unit in the last printed digit (values agree to 1e-10 relative)
+        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
+        assert len(wf) == len(gf) and wf[0] == gf[0]
+        assert all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
+
+
+def _seq_error(lib, tmp_path, mutate):
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, "g1" + ext), tmp_path)
+    p = os.path.join(tmp_path, "g1.seq")
+    text = mutate(open(p).read())
+    open(p, "w").write(text)
+    with _in_dir(tmp_path):
+        with pytest.raises(ValueError) as e:
+            G.Pack.from_control("g1.ctl", lib=lib)
+    return str(e.value)
+
+
+def test_rejects_what_the_reference_rejects(lib, tmp_path):
+    # blank first line: "Unexpected End of File when trying to read number of loci" (AlignmentProcessor.c:514-524)
+    assert "number of loci" in _seq_error(lib, tmp_path, lambda s: "\n" + s)
+    # '-' and '?' are not in the accepted alphabet TCAGYWKMSRVDBHN (AlignmentProcessor.c:61, 1467)
+    def bad_base(s):
+        lines = s.split("\n")
+        name, seq = lines[3].split()
+        lines[3] = name + "\t" + seq[:5] + "-" + seq[6:]
+        return "\n".join(lines)
+    assert "Illegal base type '-'" in _seq_error(lib, tmp_path, bad_base)
+    # short sequence
+    def short(s):
+        lines = s.split("\n")
+        name, seq = lines[3].split()
+        lines[3] = name + "\t" + seq[:-3]
+        return "\n".join(lines)
+    assert "contained only" in _seq_error(lib, tmp_path, short)
+    # fewer loci than announced
+    assert "only contains" in _seq_error(lib, tmp_path, lambda s: s[:s.index("locus8 ")])
+    # a sample of the control file that never occurs
+    assert "no samples for this name" in _seq_error(lib, tmp_path, lambda s: s.replace("s0\t", "zz\t").replace("s0 ", "zz "))
+
+
+def test_control_file_errors(lib, tmp_path):
+    txt = open(os.path.join(GOLDEN, "m3.ctl")).read()
+    p = os.path.join(tmp_path, "bad.ctl")
+    open(p, "w").write(txt.replace("finetune-theta", "finetune-thetaX"))
+    with pytest.raises(ValueError):
+        G.Pack.from_control(p, lib=lib)
+    # a band whose source is an ancestor of its target is refused (MCMCcontrol.c:1229-1237)
+    open(p, "w").write(txt.replace("source  A", "source  AB", 1))
+    with pytest.raises(ValueError):
+        G.Pack.from_control(p, lib=lib)

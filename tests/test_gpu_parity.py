@@ -9,7 +9,7 @@ import subprocess
 
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, REPO
 from parity_util import compare_records, compare_states
 
 pytestmark = pytest.mark.gpu
@@ -122,3 +122,31 @@ def test_native_library_is_the_path(G):
     assert os.path.exists(gphocs_amd.LIB_PATH)
     with pytest.raises(RuntimeError):
         gphocs_amd.load_library("/nonexistent/libgphocs_hip.so")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["g1", "m3", "a7"])
+def test_program_trace_file(name, tmp_path):
+    """G-PhoCS-hip <control-file> on the MI355X: the trace file of the real G-PhoCS binary for the same
+    control + sequence files (tests/golden/*.trace), to the printed precision (%8.5f / %.6f)."""
+    import shutil
+    import subprocess
+    exe = os.path.join(REPO, "g-phocs_amd", "G-PhoCS-hip")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    r = subprocess.run([exe, name + ".ctl"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
+    got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
+    assert want[0] == got[0] and len(want) == len(got)
+    ndiff = 0
+    for w, g in zip(want[1:], got[1:]):
+        if w == g:
+            continue
+        ndiff += 1
+        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
+        assert len(wf) == len(gf) and wf[0] == gf[0]
+        # one unit of the last printed digit at most (values agree to 1e-10 relative)
+        assert all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
+    assert ndiff <= len(want) // 10
