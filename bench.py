@@ -42,21 +42,25 @@ def _gen_chunk(args):
     return G.make_synthetic_pack(G.Pack, config, n, mut_scale=mut_scale, data_seed=seed)
 
 
-def build_workload(G, config, L, mut_scale, seed0, cache_dir):
-    """L loci of the config's shape, generated in parallel chunks and cached as .npz"""
+def build_workload(G, config, L, mut_scale, seed0, cache_dir, begin=0, L_total=None):
+    """loci [begin, begin + L) of an L_total-locus synthetic data set of the config's shape, generated in
+    parallel chunks (chunk c always has seed seed0 + 1000 + c, so a rank's shard is the same data whether it
+    is generated alone or as part of the whole set) and cached as .npz"""
     os.makedirs(cache_dir, exist_ok=True)
-    key = os.path.join(cache_dir, f"synth_c{config}_L{L}_m{mut_scale}_s{seed0}.npz")
+    L_total = L if L_total is None else L_total
+    key = os.path.join(cache_dir, f"synth_c{config}_L{L}_b{begin}_m{mut_scale}_s{seed0}.npz")
     base = G.Pack()
     from gphocs_amd_pkg import synth
     synth.make_model(base, config)
+    chunk = 4000
+    assert begin % chunk == 0 or L_total == L
     if os.path.exists(key):
         z = np.load(key)
         base.pattern_offsets, base.leafcodes = z["offs"], z["leaf"]
         base.numPhases, base.counts = z["phases"], z["counts"]
     else:
-        chunk = 4000
-        jobs = [(config, min(chunk, L - i), seed0 + 1000 + i // chunk, mut_scale) for i in range(0, L, chunk)]
-        nproc = min(len(jobs), max(1, (os.cpu_count() or 2) - 1), 16)
+        jobs = [(config, min(chunk, L - i), seed0 + 1000 + (begin + i) // chunk, mut_scale) for i in range(0, L, chunk)]
+        nproc = min(len(jobs), max(1, ((os.cpu_count() or 2) - 1) // max(1, L_total // L)), 16)
         if nproc > 1:
             with mp.get_context("fork").Pool(nproc) as pool:
                 parts = pool.map(_gen_chunk, jobs)
@@ -70,11 +74,15 @@ def build_workload(G, config, L, mut_scale, seed0, cache_dir):
         base.numPhases = np.concatenate([p.numPhases for p in parts])
         base.counts = np.concatenate([p.counts for p in parts])
         try:
-            np.savez(key, offs=base.pattern_offsets, leaf=base.leafcodes, phases=base.numPhases, counts=base.counts)
+            tmp = key + f".tmp{os.getpid()}.npz"
+            np.savez(tmp, offs=base.pattern_offsets, leaf=base.leafcodes, phases=base.numPhases, counts=base.counts)
+            os.replace(tmp, key)
         except OSError:
             pass
     base.L = base.numLoci = L
     base.mutRates = np.ones(L)
+    if L_total != L:
+        base.global_L, base.global_begin = L_total, begin
     return base
 
 
@@ -209,8 +217,9 @@ def main():
                 mins[:] = t.cpu().numpy()
 
     L_total = a.loci * world
-    pack = build_workload(G, a.config, L_total, a.mut_scale, 20261002 + a.config,
-                          os.path.join(REPO, "bench_cache"))
+    # weak scaling: every rank generates (and holds) only its own a.loci loci of the L_total-locus data set
+    pack = build_workload(G, a.config, a.loci, a.mut_scale, 20261002 + a.config,
+                          os.path.join(REPO, "bench_cache"), begin=rank * a.loci, L_total=L_total)
     P = np.diff(pack.pattern_offsets)
     s = G.Sampler(pack, device=local_rank, rank=rank, world=world, allreduce=allreduce)
     s.initialize()

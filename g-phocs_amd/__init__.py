@@ -366,6 +366,12 @@ class Sampler:
         self.rank, self.world = rank, world
         self.begin, self.end = pack.shard(rank, world)
         p = pack
+        # a pack that already holds only this rank's loci (bench.py, weak scaling): global_L loci over
+        # all ranks, this rank's first locus at global_begin
+        L_total, g_begin = p.L, self.begin
+        if getattr(p, "global_L", None) is not None:
+            L_total, g_begin = int(p.global_L), int(p.global_begin)
+            self.begin, self.end = 0, p.L
         self._keep = dict(spp=np.ascontiguousarray(p.samplesPerPop, np.int32),
                           pf=np.ascontiguousarray(p.popFather, np.int32),
                           s0=np.ascontiguousarray(p.popSon0, np.int32),
@@ -374,7 +380,7 @@ class Sampler:
                           bt=np.ascontiguousarray(p.bandTgt, np.int32))
         k = self._keep
         self.cfg = GphConfig(p.n, p.Kc, p.K, p.B, p.rootPop, _ip(k["spp"]), _ip(k["pf"]), _ip(k["s0"]),
-                             _ip(k["s1"]), _ip(k["bs"]), _ip(k["bt"]), device, p.L, self.begin)
+                             _ip(k["s1"]), _ip(k["bs"]), _ip(k["bt"]), device, L_total, g_begin)
         self.engine = C.c_void_p()
         self._chk(self.lib.gph_engine_create(C.byref(self.cfg), C.byref(self.engine)), "engine_create")
         self._cb = None

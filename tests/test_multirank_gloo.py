@@ -26,6 +26,16 @@ def allreduce(sums, mins):
         t = torch.from_numpy(mins); dist.all_reduce(t, op=dist.ReduceOp.MIN)
 lib = G.load_library(R.build_hostemu())
 pk = G.Pack.load(%(pack)r)
+if %(presharded)d:
+    # bench.py's weak-scaling path: the rank's pack holds ONLY its own loci (global_L / global_begin)
+    b, e = pk.shard(rank, world)
+    o0, o1 = int(pk.pattern_offsets[b]), int(pk.pattern_offsets[e])
+    full_L = pk.L
+    pk.pattern_offsets = pk.pattern_offsets[b:e + 1] - o0
+    pk.leafcodes, pk.numPhases, pk.counts = pk.leafcodes[o0:o1], pk.numPhases[o0:o1], pk.counts[o0:o1]
+    pk.mutRates = pk.mutRates[b:e]
+    pk.L = pk.numLoci = e - b
+    pk.global_L, pk.global_begin = full_L, b
 s = G.Sampler(pk, lib=lib, rank=rank, world=world, allreduce=allreduce)
 s.set_record_file(%(out)r + ".%%d" %% rank)
 s.initialize()
@@ -38,14 +48,15 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("name,iters", [("m3", 60), ("g1", 12)])
-def test_two_ranks_equal_one_rank(name, iters, tmp_path):
+@pytest.mark.parametrize("name,iters,presharded", [("m3", 60, 0), ("g1", 12, 0), ("m3", 40, 1)])
+def test_two_ranks_equal_one_rank(name, iters, presharded, tmp_path):
     sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
     import run_hostemu as R
     R.build_hostemu()
     out = str(tmp_path / "rec")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % dict(repo=REPO, pack=os.path.join(GOLDEN, name + ".gpk"), out=out, iters=iters))
+    script.write_text(WORKER % dict(repo=REPO, pack=os.path.join(GOLDEN, name + ".gpk"), out=out, iters=iters,
+                                      presharded=presharded))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
     for p in procs:
