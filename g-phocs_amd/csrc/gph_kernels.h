@@ -233,7 +233,7 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune)
     lik_adjust_age(inode, tnew);
     lnLd = -FS(FS_DATALNL);
     { STAMP_BEGIN(1); lnLd += lik_compute(1); STAMP_END(1); }
-    { STAMP_BEGIN(2); dgen = consider_event_move(0, NEV(inode), pop, t, pop, tnew); STAMP_END(2); }
+    { STAMPA_BEGIN(2); dgen = consider_event_move(0, NEV(inode), pop, t, pop, tnew); STAMPA_END(2); }
     lnacc = dgen + lnLd;
     if (gph_failed()) break;
     if (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp_u(lnacc))) {
@@ -313,8 +313,8 @@ GPH_DEV void sweep_spr(const GphDev &D, int g)
     father = FATH(node);
     father_pop_old = NPOP(father);
     sibling = LEFT(father) + RGHT(father) - node;
-    { STAMP_BEGIN(3); trace_lineage<0>(node); STAMP_END(3); }
-    { STAMP_BEGIN(4); res = trace_lineage<1>(node); STAMP_END(4); }
+    { STAMPA_BEGIN(3); trace_lineage<0>(node); STAMPA_END(3); }
+    { STAMPA_BEGIN(4); res = trace_lineage<1>(node); STAMPA_END(4); }
     lnLd = -FS(FS_DATALNL);
     { STAMP_BEGIN(1); lnLd += lik_compute(1); STAMP_END(1); }
     lnacc = lnLd;

@@ -121,6 +121,18 @@ GPH_DEV void ll_swap_remove(LiveList &l, int i) { l.n--; ll_set(l, i, ll_get(l, 
 #define STAMP_BEGIN(k) ((void)0)
 #define STAMP_END(k) ((void)0)
 #endif
+// -DGPH_STAMPS=2: slots 2/3/4 attribute lik_compute's own phases instead of the chain functions
+#if defined(GPH_STAMPS) && GPH_STAMPS == 2 && !defined(GPH_HOSTEMU)
+#define STAMPA_BEGIN(k) ((void)0)
+#define STAMPA_END(k) ((void)0)
+#define STAMPB_BEGIN(k) STAMP_BEGIN(k)
+#define STAMPB_END(k) STAMP_END(k)
+#else
+#define STAMPA_BEGIN(k) STAMP_BEGIN(k)
+#define STAMPA_END(k) STAMP_END(k)
+#define STAMPB_BEGIN(k) ((void)0)
+#define STAMPB_END(k) ((void)0)
+#endif
 GPH_DEV void gph_fail(int code) { if (CNT(CN_ERROR) == 0) setCNT(CN_ERROR, code); }
 GPH_DEV int gph_failed() { return CNT(CN_ERROR) != 0; }
 
@@ -384,6 +396,14 @@ GPH_DEV double rdlane64(double v, int l)
   u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
   return u.d;
 }
+GPH_DEV double bperm64(int byteaddr, double v)
+{
+  union { double d; int32_t i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_ds_bpermute(byteaddr, u.i[0]);
+  u.i[1] = __builtin_amdgcn_ds_bpermute(byteaddr, u.i[1]);
+  return u.d;
+}
 // prune_node() with every tree scalar already in (scalar) registers
 GPH_DEV void prune_node_r(int node, int l, int r, double an, double al, double ar, int cbn, int cbl, int cbr,
                           int P, double mut, gdbl *cb)
@@ -408,6 +428,86 @@ GPH_DEV void prune_node_r(int node, int l, int r, double an, double al, double a
   GPH_WAVE_FENCE();
 }
 
+// ---- lanes = patterns (P <= 64): one lane owns pattern `lane` and its 4 base entries.
+// The 4 conditionals a lane just produced stay in its registers (q0..q3): when the next node
+// processed is the parent (the usual case: a dirty path is a chain), that child is not re-read
+// from memory -- no store->load round trip on the critical path.
+typedef double gph_d2 __attribute__((ext_vector_type(2)));
+typedef GPH_GLB gph_d2 gdbl2;
+
+// factors of one child for the 4 bases of pattern `lane` (computeSubtreeConditionals_new,
+// LocusDataLikelihood.c:1650-1673; same operations in the same order as child_factor())
+GPH_DEVHOT void child_factor4(int child, const gdbl *cnd, bool fwd, double q0, double q1, double q2, double q3,
+                              double pe, double qe, bool act, double &f0, double &f1, double &f2, double &f3)
+{
+  const int lane = GPH_LANE;
+  if (child < g_lay.n) {
+    /* leaf: one-hot (or N).  S = 1 exactly, so S*pe = pe and sa*qe is qe or 0: bit-identical shortcut */
+    const int code = act ? (int)gu8v(g_lay.q_leaf, lane * g_lay.n + child) : 4;
+    const double hit = pe + qe;
+    f0 = code == 4 ? 1.0 : (code == 0 ? hit : pe);
+    f1 = code == 4 ? 1.0 : (code == 1 ? hit : pe);
+    f2 = code == 4 ? 1.0 : (code == 2 ? hit : pe);
+    f3 = code == 4 ? 1.0 : (code == 3 ? hit : pe);
+    return;
+  }
+  double s0 = q0, s1 = q1, s2 = q2, s3 = q3;
+  if (!fwd) {
+    gph_d2 a = {1.0, 1.0}, b = {1.0, 1.0};
+    if (act) {
+      const gdbl2 *c2 = (const gdbl2 *)(cnd + 4 * lane);
+      a = c2[0];
+      b = c2[1];
+    }
+    s0 = a.x; s1 = a.y; s2 = b.x; s3 = b.y;
+  }
+  double S = 0.0;
+  S += s0;
+  S += s1;
+  S += s2;
+  S += s3;
+  const double Sp = S * pe;
+  const bool miss = S >= 4;
+  f0 = miss ? 1.0 : (Sp + s0 * qe);
+  f1 = miss ? 1.0 : (Sp + s1 * qe);
+  f2 = miss ? 1.0 : (Sp + s2 * qe);
+  f3 = miss ? 1.0 : (Sp + s3 * qe);
+}
+
+// recompute node `node`; on entry q* hold node `prev`'s conditionals (prev < 0: nothing), on exit
+// this node's.  `fresh` = nodes written earlier in this evaluation (their stores may be in flight)
+GPH_DEVHOT void prune_node_q(int node, int l, int r, double an, double al, double ar, int cbn, int cbl, int cbr,
+                             int P, double mut, gdbl *cb, int prev, uint64_t fresh,
+                             double &q0, double &q1, double &q2, double &q3)
+{
+  const double pl = edge_prob(mut * (an - al));
+  const double ql = 1 - 4.0 * pl;
+  const double pr = edge_prob(mut * (an - ar));
+  const double qr = 1 - 4.0 * pr;
+  const int nint = g_lay.n - 1, n = g_lay.n, lane = GPH_LANE;
+  const bool act = lane < P;
+  gdbl *pc = cb + ((cbn * nint + (node - n)) * P) * 4;
+  const gdbl *lc = cb + (l >= n ? ((cbl * nint + (l - n)) * P) * 4 : 0);
+  const gdbl *rc = cb + (r >= n ? ((cbr * nint + (r - n)) * P) * 4 : 0);
+  const bool fl = l == prev, fr = r == prev;
+  /* a child recomputed earlier in this evaluation but not held in registers: its stores must
+   * have landed before it is re-read */
+  if ((l >= n && !fl && ((fresh >> l) & 1)) || (r >= n && !fr && ((fresh >> r) & 1))) GPH_WAVE_FENCE();
+  double f0, f1, f2, f3, g0, g1, g2, g3;
+  child_factor4(l, lc, fl, q0, q1, q2, q3, pl, ql, act, f0, f1, f2, f3);
+  child_factor4(r, rc, fr, q0, q1, q2, q3, pr, qr, act, g0, g1, g2, g3);
+  q0 = f0 * g0;
+  q1 = f1 * g1;
+  q2 = f2 * g2;
+  q3 = f3 * g3;
+  if (act) {
+    gdbl2 *o2 = (gdbl2 *)(pc + 4 * lane);
+    gph_d2 a = {q0, q1}, b = {q2, q3};
+    o2[0] = a;
+    o2[1] = b;
+  }
+}
+
 // computeLocusDataLikelihood, LocusDataLikelihood.c:426-483.  Device form: the genealogy
 // (father/left/right/age, one node per lane) and the dirty / current-buffer sets (64-bit
 // masks) are pulled into registers once; "which nodes must be recomputed" is a ballot
@@ -421,6 +521,7 @@ GPH_DEVHOT double lik_compute(int useOld)
   useOld = RFL(useOld);
   const int P = CNT(CN_P);
   if (P == 0) return 0.0;
+  STAMPB_BEGIN(2);
   const bool isnode = lane < N;
   const int le = isnode ? (int)gph_lds.left[lane] : -1;
   const int ri = isnode ? (int)gph_lds.right[lane] : -1;
@@ -449,24 +550,48 @@ GPH_DEVHOT double lik_compute(int useOld)
   const int nord = __builtin_popcountll(todo);
   gdbl *cb = cond_base();
   const double mut = FS(FS_MUTRATE);
+  const bool wide = P > GPH_WAVE;   /* more than one pattern per lane: generic (pattern, base) mapping */
+  double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+  int prev = -1;
+  uint64_t fresh = 0;
+  /* conditionals written by an earlier evaluation of this wave must have landed before they are re-read */
+  GPH_WAVE_FENCE();
+  STAMPB_END(2);
   for (int guard = 0; todo != 0; guard++) {
     bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
     uint64_t rmask = __ballot(rdy);
     if (rmask == 0 || guard > N) { gph_fail(100); return FS(FS_DATALNL); }
-    while (rmask) {
-      const int node = __builtin_ctzll(rmask);
+    if (wide) {
+      while (rmask) {
+        const int node = __builtin_ctzll(rmask);
+        const uint64_t bit = (uint64_t)1 << node;
+        rmask &= rmask - 1;
+        if (useOld && !(dirty & bit)) { dirty |= bit; cbit ^= bit; newly |= bit; }   /* copyNodeConditionals */
+        const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
+        STAMP_BEGIN(7);
+        prune_node_r(node, l, r, rdlane64(ag, node), rdlane64(ag, l), rdlane64(ag, r), (int)((cbit >> node) & 1),
+                     (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, mut, cb);
+        STAMP_END(7);
+        todo &= ~bit;
+      }
+    } else {
+      /* one node per step, the parent of the node just computed first (its child is in registers) */
+      const uint64_t pm = __ballot(isnode && (le == prev || ri == prev)) & rmask;
+      const int node = __builtin_ctzll(pm ? pm : rmask);
       const uint64_t bit = (uint64_t)1 << node;
-      rmask &= rmask - 1;
-      if (useOld && !(dirty & bit)) { dirty |= bit; cbit ^= bit; newly |= bit; }   /* copyNodeConditionals */
+      if (useOld && !(dirty & bit)) { dirty |= bit; cbit ^= bit; newly |= bit; }     /* copyNodeConditionals */
       const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
       STAMP_BEGIN(7);
-      prune_node_r(node, l, r, rdlane64(ag, node), rdlane64(ag, l), rdlane64(ag, r), (int)((cbit >> node) & 1),
-                   (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, mut, cb);
+      prune_node_q(node, l, r, rdlane64(ag, node), rdlane64(ag, l), rdlane64(ag, r), (int)((cbit >> node) & 1),
+                   (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, mut, cb, prev, fresh, q0, q1, q2, q3);
       STAMP_END(7);
       todo &= ~bit;
+      fresh |= bit;
+      prev = node;
     }
   }
   setCNT(CN_NODES, CNT(CN_NODES) + nord);
+  STAMPB_BEGIN(3);
   /* write the dirty / current-buffer sets back, append the newly marked nodes to the list */
   if (isnode) {
     gph_lds.dirty[lane] = (uint8_t)((dirty >> lane) & 1);
@@ -477,25 +602,48 @@ GPH_DEVHOT double lik_compute(int useOld)
     }
   }
   setISC(IS_NCHANGEDC, ISC(IS_NCHANGEDC) + __builtin_popcountll(newly));
-  GPH_WAVE_FENCE();
+  STAMPB_END(3);
+  STAMPB_BEGIN(4);
   /* root reduction, LocusDataLikelihood.c:466-479: per unphased pattern
    * log(sum over phases and bases / (4*phases)) * count, summed in pattern order */
   double lnl = 0.0;
   int U;
   const gdbl *rc = cb + (((int)((cbit >> root) & 1) * (n - 1) + (root - n)) * P) * 4;
-  if (P <= GPH_WAVE) {
+  if (!wide) {
+    /* the root was computed last: its conditionals for pattern `lane` are q0..q3; only the further
+     * phases of an unphased pattern (the following rows) come from memory */
     double term = 0.0;
     const int ph = lane < P ? gu8v(g_lay.q_phases, lane) : 0;
+    double prob = 0.0;
+    prob += q0;
+    prob += q1;
+    prob += q2;
+    prob += q3;
+    /* further phases: the next lanes' registers, fetched lane-to-lane (no store->load round trip),
+     * added in the reference's order (phase by phase, base by base) */
+    for (int k = 1; __ballot(ph > k) != 0; k++) {
+      const int src = ((lane + k) & (GPH_WAVE - 1)) << 2;
+      const double r0 = bperm64(src, q0), r1 = bperm64(src, q1), r2 = bperm64(src, q2), r3 = bperm64(src, q3);
+      if (ph > k) {
+        prob += r0;
+        prob += r1;
+        prob += r2;
+        prob += r3;
+      }
+    }
     if (ph > 0) {
       const int nc = 4 * ph;
-      double prob = 0.0;
-      for (int c = 0; c < nc; c++) prob += rc[lane * 4 + c];
-      term = gph_log(prob / nc) * gi32v(g_lay.q_count, lane);
+      /* phase counts are powers of two upstream (2^hets): the division is an exact exponent shift */
+      double avg;
+      if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
+      else avg = prob / nc;
+      term = gph_log(avg) * gi32v(g_lay.q_count, lane);
     }
     uint64_t pm = __ballot(ph > 0);
     U = __builtin_popcountll(pm);
     while (pm) { lnl += rdlane64(term, __builtin_ctzll(pm)); pm &= pm - 1; }
   } else {
+    GPH_WAVE_FENCE();
     for (int p = lane; p < P; p += GPH_NLANES) {
       int ph = gu8v(g_lay.q_phases, p);
       if (ph > 0) {
@@ -512,6 +660,7 @@ GPH_DEVHOT double lik_compute(int useOld)
   }
   setFS(FS_DATALNL, lnl);
   if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (96.0 * nord * P + 20.0 * N + 8.0 * U + 8.0));
+  STAMPB_END(4);
   return lnl;
 }
 #else
