@@ -308,6 +308,13 @@ GPH_DEV double edge_prob(double len)
   return ((1 - gph_exp_u(-4 * len / 3.0)) / 4.0);
 }
 
+// same, argument differs per lane (table words gathered through the vector L1)
+GPH_DEV double edge_prob_v(double len)
+{
+  if (len < 1e-100) return 0.0;
+  return ((1 - gph_exp(-4 * len / 3.0)) / 4.0);
+}
+
 // The fp64 conditional arrays [2][n-1][P][4] of the locus stay in global memory: they are
 // touched lane-parallel and fully coalesced (4P consecutive doubles per node), the working
 // set of all resident waves fits the L2 / Infinity Cache, and keeping them out of LDS is
@@ -405,12 +412,9 @@ GPH_DEV double bperm64(int byteaddr, double v)
   return u.d;
 }
 // prune_node() with every tree scalar already in (scalar) registers
-GPH_DEV void prune_node_r(int node, int l, int r, double an, double al, double ar, int cbn, int cbl, int cbr,
-                          int P, double mut, gdbl *cb)
+GPH_DEV void prune_node_r(int node, int l, int r, double pl, double pr, int cbn, int cbl, int cbr, int P, gdbl *cb)
 {
-  double pl = edge_prob(mut * (an - al));
   double ql = 1 - 4.0 * pl;
-  double pr = edge_prob(mut * (an - ar));
   double qr = 1 - 4.0 * pr;
   const int nint = g_lay.n - 1;
   gdbl *pc = cb + ((cbn * nint + (node - g_lay.n)) * P) * 4;
@@ -476,13 +480,11 @@ GPH_DEVHOT void child_factor4(int child, const gdbl *cnd, bool fwd, double q0, d
 
 // recompute node `node`; on entry q* hold node `prev`'s conditionals (prev < 0: nothing), on exit
 // this node's.  `fresh` = nodes written earlier in this evaluation (their stores may be in flight)
-GPH_DEVHOT void prune_node_q(int node, int l, int r, double an, double al, double ar, int cbn, int cbl, int cbr,
-                             int P, double mut, gdbl *cb, int prev, uint64_t fresh,
+GPH_DEVHOT void prune_node_q(int node, int l, int r, double pl, double pr, int cbn, int cbl, int cbr,
+                             int P, gdbl *cb, int prev, uint64_t fresh,
                              double &q0, double &q1, double &q2, double &q3)
 {
-  const double pl = edge_prob(mut * (an - al));
   const double ql = 1 - 4.0 * pl;
-  const double pr = edge_prob(mut * (an - ar));
   const double qr = 1 - 4.0 * pr;
   const int nint = g_lay.n - 1, n = g_lay.n, lane = GPH_LANE;
   const bool act = lane < P;
@@ -550,6 +552,13 @@ GPH_DEVHOT double lik_compute(int useOld)
   const int nord = __builtin_popcountll(todo);
   gdbl *cb = cond_base();
   const double mut = FS(FS_MUTRATE);
+  /* edge transition probabilities (computeEdgeConditionalJC, LocusDataLikelihood.c:1831-1848) of every
+   * edge below a node that is recomputed: one lane per child node, all edges in ONE vector exp */
+  double pe = 0.0;
+  {
+    const int fa = isnode ? (int)gph_lds.father[lane] : -1;
+    if (fa >= 0 && ((todo >> fa) & 1)) pe = edge_prob_v(mut * (gph_lds.age[fa] - ag));
+  }
   const bool wide = P > GPH_WAVE;   /* more than one pattern per lane: generic (pattern, base) mapping */
   double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
   int prev = -1;
@@ -569,8 +578,8 @@ GPH_DEVHOT double lik_compute(int useOld)
         if (useOld && !(dirty & bit)) { dirty |= bit; cbit ^= bit; newly |= bit; }   /* copyNodeConditionals */
         const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
         STAMP_BEGIN(7);
-        prune_node_r(node, l, r, rdlane64(ag, node), rdlane64(ag, l), rdlane64(ag, r), (int)((cbit >> node) & 1),
-                     (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, mut, cb);
+        prune_node_r(node, l, r, rdlane64(pe, l), rdlane64(pe, r), (int)((cbit >> node) & 1),
+                     (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, cb);
         STAMP_END(7);
         todo &= ~bit;
       }
@@ -582,8 +591,8 @@ GPH_DEVHOT double lik_compute(int useOld)
       if (useOld && !(dirty & bit)) { dirty |= bit; cbit ^= bit; newly |= bit; }     /* copyNodeConditionals */
       const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
       STAMP_BEGIN(7);
-      prune_node_q(node, l, r, rdlane64(ag, node), rdlane64(ag, l), rdlane64(ag, r), (int)((cbit >> node) & 1),
-                   (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, mut, cb, prev, fresh, q0, q1, q2, q3);
+      prune_node_q(node, l, r, rdlane64(pe, l), rdlane64(pe, r), (int)((cbit >> node) & 1),
+                   (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, cb, prev, fresh, q0, q1, q2, q3);
       STAMP_END(7);
       todo &= ~bit;
       fresh |= bit;
