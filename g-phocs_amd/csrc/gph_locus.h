@@ -1327,8 +1327,8 @@ GPH_DEVHOT int trace_lineage(int node)
   node = RFL(node);
   int i, pop, ev, node_id, b = -1, mig_source, proceed;
   LiveList live = {0, 0};
-  int target, num_targets, nev = 0;
-  double age, t = 0, event_sample, rate, mig_rate, theta, lnld = 0.0;
+  int target, num_targets, nev = 0, rate_ev = -1;
+  double age, t = 0, event_sample, rate = 0.0, mig_rate, theta, lnld = 0.0;
 
   pop = NPOP(node);
   if (node < g_lay.n) {
@@ -1348,9 +1348,17 @@ GPH_DEVHOT int trace_lineage(int node)
     setSPRI(SI_NNEW, 0);
   }
   setDI(inst, DI_NPOPS, g_lay.K);
-  for (i = 0; i < g_lay.K; i++) { setDPOPS(inst, i, i); setDCOAL(inst, i, 0.0); }
   setDI(inst, DI_NBANDS, g_lay.B);
+#ifdef GPH_HOSTEMU
+  for (i = 0; i < g_lay.K; i++) { setDPOPS(inst, i, i); setDCOAL(inst, i, 0.0); }
   for (i = 0; i < g_lay.B; i++) { setDBANDS(inst, i, i); setDMIG(inst, i, 0.0); }
+#else
+  {   /* one lane per population / band */
+    const int lane = GPH_LANE;
+    if (lane < g_lay.K) { gph_lds.s_dpops[inst][lane] = (int16_t)lane; gph_lds.s_dcoal[inst][lane] = 0.0; }
+    if (lane < g_lay.B) { gph_lds.s_dbands[inst][lane] = (int16_t)lane; gph_lds.s_dmig[inst][lane] = 0.0; }
+  }
+#endif
   mig_rate = 0.0;
   for (b = 0; b < g_lay.B; b++) {
     if (g_model.bandTgt[b] == pop && g_model.bandStart[b] < age && g_model.bandEnd[b] > age) {
@@ -1393,6 +1401,7 @@ GPH_DEVHOT int trace_lineage(int node)
       }
     } else {
       rate = mig_rate + 2 * ENLIN(ev) / theta;
+      rate_ev = ev;
       if (UNI(rate <= 0)) t = EVT(ev);
       else t = -(1 / rate) * gph_log_u(l_rndu());
       if (UNI(t >= EVT(ev))) {
@@ -1439,7 +1448,9 @@ GPH_DEVHOT int trace_lineage(int node)
     for (i = 0; i < live.n; i++) setDMIG(inst, ll_get(live, i), DMIG(inst, ll_get(live, i)) + t);
     setDEV(inst, nev, ev);
     nev++;
-    lnld -= (mig_rate + 2 * ENLIN(ev) / theta) * t;
+    /* the same expression as `rate` above unless the walk ended inside the interval (new event) */
+    if (RECONNECT && ev == rate_ev) lnld -= rate * t;
+    else lnld -= (mig_rate + 2 * ENLIN(ev) / theta) * t;
     if (mig_source >= 0) {
       lnld += gph_log_u(g_model.migRate[b]);
       ev = mig_source;
