@@ -126,7 +126,7 @@ GPH_DEV void out_common(const GphDev &D, int g)
 // living-lineage array is packed exactly as the recursion packs it: a cursor
 // advances past each finished population's SURVIVING lineages, so an ancestral
 // population's list is the contiguous run [base(son0), cursor).
-GPH_DEV void random_gtree()
+GPH_DEV void random_gtree(GphRng &rng)
 {
   const int n = g_lay.n;
   int pi, pop, nextId = n, num, node1, node2, choice, a, b, base, cur = 0;
@@ -154,13 +154,13 @@ GPH_DEV void random_gtree()
     T = g_model.popAge[pop];
     if (pop < g_lay.Kc) T = g_model.sampleAge[pop];
     for (; num > 1; num--, nextId++) {
-      t = -(g_model.theta[pop] / (num * (num - 1.))) * gph_log_u(l_rndu());
+      t = -(g_model.theta[pop] / (num * (num - 1.))) * gph_log_u(l_rndu(rng));
       T += t;
       if (pop != g_lay.rootPop && T > g_model.popAge[g_model.popFather[pop]]) break;
-      choice = (int)(num * l_rndu());
+      choice = (int)(num * l_rndu(rng));
       a = gi16(&GphLds::s_targets, base + choice);
       si16(&GphLds::s_targets, base + choice, gi16(&GphLds::s_targets, base + num - 1));
-      choice = (int)((num - 1) * l_rndu());
+      choice = (int)((num - 1) * l_rndu(rng));
       b = gi16(&GphLds::s_targets, base + choice);
       si16(&GphLds::s_targets, base + choice, nextId);
       setRGHT(nextId, a);
@@ -194,7 +194,12 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate)
     setMG(i, MG_BRANCH, -1); setMG(i, MG_BAND, -1); setMG(i, MG_SPOP, -1);
     setMG(i, MG_TPOP, -1); setMG(i, MG_SEV, -1); setMG(i, MG_TEV, -1);
   }
-  random_gtree();
+  {
+    GphRng rng;
+    rng_load(rng);
+    random_gtree(rng);
+    rng_store(rng);
+  }
   construct_event_chain();
   compute_genetree_stats();
   setFS(FS_GENLNL, gtree_lnl());
@@ -208,7 +213,7 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate)
 
 // ---------------------------------------------------------------- genealogy sweeps
 // UpdateGB_InternalNode per-locus body, GPhoCS.c:2299-2425
-GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune)
+GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune, GphRng &rng)
 {
   int pop, inode, i, son, mig, acc = 0;
   double t, tnew, lnacc, lnLd, dgen, tb0, tb1, dData = 0, dLog = 0;
@@ -227,7 +232,7 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune)
       if (mig >= 0) tb0 = gmax2(tb0, MAGE(mig));
       else tb0 = gmax2(tb0, AGE(son));
     }
-    tnew = t + finetune * l_rnd2normal8();
+    tnew = t + finetune * l_rnd2normal8(rng);
     tnew = l_reflect(tnew, tb0, tb1);
     if (UNI(fabs(tnew - t) < 1e-15)) { acc++; continue; }
     lik_adjust_age(inode, tnew);
@@ -236,7 +241,7 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune)
     { STAMPA_BEGIN(2); dgen = consider_event_move(0, NEV(inode), pop, t, pop, tnew); STAMPA_END(2); }
     lnacc = dgen + lnLd;
     if (gph_failed()) break;
-    if (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp_u(lnacc))) {
+    if (UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
       dData += lnLd;
@@ -254,7 +259,7 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune)
 }
 
 // UpdateGB_MigrationNode per-locus body, GPhoCS.c:2453-2587
-GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune)
+GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune, GphRng &rng)
 {
   int mi, mignode, pop_s, pop_t, ev_s, ev_t, below, mig_below, mig_above, father, acc = 0, totmigs = 0;
   double t, tnew, tb0, tb1, dgen, lnacc, dLog = 0;
@@ -278,14 +283,14 @@ GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune)
       if (father < 0) tb1 = gmin2(tb1, GPH_OLDAGE);
       else tb1 = gmin2(tb1, AGE(father));
     }
-    tnew = t + finetune * l_rnd2normal8();
+    tnew = t + finetune * l_rnd2normal8(rng);
     tnew = l_reflect(tnew, tb0, tb1);
     if (UNI(fabs(tnew - t) < 1e-15)) { acc++; continue; }
     dgen = consider_event_move(0, ev_s, pop_s, t, pop_s, tnew);
     dgen += consider_event_move(1, ev_t, pop_t, t, pop_t, tnew);
     lnacc = dgen;
     if (gph_failed()) break;
-    if (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp_u(lnacc))) {
+    if (UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
       dLog += dgen / D.Ltot;
@@ -304,7 +309,7 @@ GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune)
 }
 
 // UpdateGB_MigSPR per-locus body, GPhoCS.c:2610-2944 (no admixture)
-GPH_DEV void sweep_spr(const GphDev &D, int g)
+GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
 {
   int node, res, father, father_pop_old, sibling, b, i, mig, ev, target, pop, acc = 0, fpn, fen;
   double lnLd, lnacc, t_new, dData = 0, dLog = 0;
@@ -313,13 +318,13 @@ GPH_DEV void sweep_spr(const GphDev &D, int g)
     father = FATH(node);
     father_pop_old = NPOP(father);
     sibling = LEFT(father) + RGHT(father) - node;
-    { STAMPA_BEGIN(3); trace_lineage<0>(node); STAMPA_END(3); }
-    { STAMPA_BEGIN(4); res = trace_lineage<1>(node); STAMPA_END(4); }
+    { STAMPA_BEGIN(3); trace_lineage<0>(node, rng); STAMPA_END(3); }
+    { STAMPA_BEGIN(4); res = trace_lineage<1>(node, rng); STAMPA_END(4); }
     lnLd = -FS(FS_DATALNL);
     { STAMP_BEGIN(1); lnLd += lik_compute(1); STAMP_END(1); }
     lnacc = lnLd;
     if (gph_failed()) break;
-    if (res >= 0 && (UNI(lnacc >= 0) || UNI(l_rndu() < gph_exp_u(lnacc)))) {
+    if (res >= 0 && (UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc)))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + (SPRLN(1) - SPRLN(0)));
       dData += lnLd;
@@ -376,11 +381,14 @@ GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double f
 {
   STAMP_BEGIN(0);
   stage_in(D, g, D.pages, 1);
+  GphRng rng;
+  rng_load(rng);
   OUT(g, 0, 0.0); OUT(g, 1, 0.0); OUT(g, 2, 0.0); OUT(g, 3, 0.0); OUT(g, 4, 0.0);
   OUT(g, 5, 0.0); OUT(g, 6, 0.0); OUT(g, 7, 0.0); OUT(g, 12, 0.0);
-  { STAMP_BEGIN(5); if ((flags & 1) && ftCoal > 0.0) sweep_internal(D, g, ftCoal); STAMP_END(5); }
-  if ((flags & 2) && ftMig > 0.0 && !gph_failed()) sweep_mignodes(D, g, ftMig);
-  { STAMP_BEGIN(6); if ((flags & 4) && !gph_failed()) sweep_spr(D, g); STAMP_END(6); }
+  { STAMP_BEGIN(5); if ((flags & 1) && ftCoal > 0.0) sweep_internal(D, g, ftCoal, rng); STAMP_END(5); }
+  if ((flags & 2) && ftMig > 0.0 && !gph_failed()) sweep_mignodes(D, g, ftMig, rng);
+  { STAMP_BEGIN(6); if ((flags & 4) && !gph_failed()) sweep_spr(D, g, rng); STAMP_END(6); }
+  rng_store(rng);
   out_common(D, g);
   STAMP_END(0);
 #if defined(GPH_STAMPS) && !defined(GPH_HOSTEMU)

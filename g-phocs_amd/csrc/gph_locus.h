@@ -138,16 +138,21 @@ GPH_DEV int gph_failed() { return CNT(CN_ERROR) != 0; }
 
 // ---------------------------------------------------------------- RNG
 // rndu, utils.c:498-513: unsigned 32-bit Wichmann-Hill without the sign fix-up
-GPH_DEV double l_rndu()
+// The locus' generator state (RndCtx slot, utils.c:401) lives in registers while a kernel works on
+// the locus: loaded from the page after stage-in, stored back before stage-out.
+struct GphRng { uint32_t x, y, z; };
+GPH_DEV void rng_load(GphRng &g) { g.x = (uint32_t)ISC(IS_RX); g.y = (uint32_t)ISC(IS_RY); g.z = (uint32_t)ISC(IS_RZ); }
+GPH_DEV void rng_store(const GphRng &g) { setISC(IS_RX, (int)g.x); setISC(IS_RY, (int)g.y); setISC(IS_RZ, (int)g.z); }
+GPH_DEV double l_rndu(GphRng &g)
 {
-  uint32_t x = (uint32_t)ISC(IS_RX), y = (uint32_t)ISC(IS_RY), z = (uint32_t)ISC(IS_RZ);
+  uint32_t x = g.x, y = g.y, z = g.z;
   double r;
   x = 171u * (x % 177u) - 2u * (x / 177u);
   y = 172u * (y % 176u) - 35u * (y / 176u);
   z = 170u * (z % 178u) - 63u * (z / 178u);
-  setISC(IS_RX, (int)x);
-  setISC(IS_RY, (int)y);
-  setISC(IS_RZ, (int)z);
+  g.x = x;
+  g.y = y;
+  g.z = z;
 #ifdef GPH_HOSTEMU
   r = x / 30269.0 + y / 30307.0 + z / 30323.0;
 #else
@@ -167,14 +172,14 @@ GPH_DEV double l_rndu()
   return r;
 }
 // rndnormal, utils.c:459-472
-GPH_DEV double l_rndnormal()
+GPH_DEV double l_rndnormal(GphRng &g)
 {
   double u, v, s;
   int guard = 0;
   for (;;) {
     if (++guard > 100000) { gph_fail(89); return 0.0; }
-    u = 2 * l_rndu() - 1;
-    v = 2 * l_rndu() - 1;
+    u = 2 * l_rndu(g) - 1;
+    v = 2 * l_rndu(g) - 1;
     s = u * u + v * v;
     if (UNI(s > 0 && s < 1)) break;
   }
@@ -182,13 +187,13 @@ GPH_DEV double l_rndnormal()
   return u * s;
 }
 // rnd2normal8, utils.c:482-488 (kernel constants utils.c:427-431)
-GPH_DEV double l_rnd2normal8()
+GPH_DEV double l_rnd2normal8(GphRng &g)
 {
   const double m2s2 = 8.;
   double m2N = sqrt(m2s2 / (m2s2 + 1.));
   double s2N = sqrt(1. / (m2s2 + 1.));
-  double z = m2N + l_rndnormal() * s2N;
-  z = UNI(l_rndu() < 0.5) ? z : -z;
+  double z = m2N + l_rndnormal(g) * s2N;
+  z = UNI(l_rndu(g) < 0.5) ? z : -z;
   return z;
 }
 // reflect, utils.c:333-398
@@ -1321,7 +1326,7 @@ GPH_DEV double rubber_band_ripple(int do_or_redo)
 // traceLineage, patch.c:886-1331.  RECONNECT == 0: walk the existing edge above
 // `node`, removing one lineage; RECONNECT == 1: re-sample its path from the prior
 template <int RECONNECT>
-GPH_DEVHOT int trace_lineage(int node)
+GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
 {
   const int inst = RECONNECT;
   node = RFL(node);
@@ -1403,13 +1408,13 @@ GPH_DEVHOT int trace_lineage(int node)
       rate = mig_rate + 2 * ENLIN(ev) / theta;
       rate_ev = ev;
       if (UNI(rate <= 0)) t = EVT(ev);
-      else t = -(1 / rate) * gph_log_u(l_rndu());
+      else t = -(1 / rate) * gph_log_u(l_rndu(rng));
       if (UNI(t >= EVT(ev))) {
         t = EVT(ev);
         age += t;
       } else {
         age += t;
-        event_sample = rate * l_rndu();
+        event_sample = rate * l_rndu(rng);
         if (UNI(event_sample < mig_rate)) {
           int k = SPRI(SI_NNEW);
           if (GPH_MAX_MIGS <= ISC(IS_NUM_MIGS) + k - SPRI(SI_NOLD)) {
