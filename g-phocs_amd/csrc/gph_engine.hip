@@ -154,7 +154,7 @@ struct gph_engine {
   std::vector<uint64_t> h_cond_off;
   std::vector<int32_t> h_P;          // per slot (sorted order)
   std::vector<int32_t> h_orig;       // slot -> original local index
-  struct Bucket { int j0, count; GphLayout lay; };
+  struct Bucket { int j0, count, lds_bytes; };   // a launch group: slots [j0, j0+count), dynamic LDS per wave
   std::vector<Bucket> buckets;
   double *d_mutRate = nullptr;
   double *d_part = nullptr, *d_red = nullptr;
@@ -208,16 +208,11 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   o = 0;
   y.o_scratch = 0;
   y.scratch_bytes = (int)sizeof(GphLds);
-  y.o_seq = o;
-  y.q_leaf = o; o += Pmax * n;
-  y.q_phases = o; o += Pmax;
-  o = align_up(o, 4);
-  y.q_count = o; o += 4 * Pmax;
-  o = align_up(o, 16);
-  y.o_cond = o;     // end of the sequence block
-  y.s_terms = f64(Pmax);
+  // (the block is laid out by the locus' own P: GPH_Q_* in gph_types.h; nothing P-dependent here)
+  y.o_seq = 0;
   y.Pmax = Pmax;
-  y.lds_bytes = align_up(o, 16);
+  y.lds_bytes = GPH_Q_TERMS(Pmax, n) + (Pmax > GPH_WAVE ? 8 * Pmax : 0);
+  (void)f64;
 }
 
 static void build_model_static(gph_engine *e)
@@ -256,8 +251,9 @@ static int h2d(gph_engine *, void *d, const void *h, size_t n) { memcpy(d, h, n)
 static int d2h(gph_engine *, void *h, const void *d, size_t n) { memcpy(h, d, n); return 0; }
 static int upload_tables(gph_engine *e) { g_lay = e->lay; g_model = e->model; return 0; }
 #define LAUNCH(e, which, name, ...) do { g_model = (e)->model; \
-    for (auto &bk_ : (e)->buckets) { g_lay = bk_.lay; (e)->lds.assign(bk_.lay.lds_bytes + 64, 0); gph_sm = (e)->lds.data(); \
-      for (int b_ = 0; b_ < bk_.count; b_++) name(b_, (e)->dev, bk_.j0, __VA_ARGS__); } g_lay = (e)->lay; \
+    g_lay = (e)->lay; \
+    for (auto &bk_ : (e)->buckets) { (e)->lds.assign(bk_.lds_bytes + 8 * (e)->lay.Pmax + 64, 0); /* the host form keeps per-pattern terms for every P */ gph_sm = (e)->lds.data(); \
+      for (int b_ = 0; b_ < bk_.count; b_++) name(b_, (e)->dev, bk_.j0, __VA_ARGS__); } \
     (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
 #else
 static int dev_alloc(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess ? 0 : GPH_EHIP; }
@@ -280,14 +276,15 @@ static int upload_tables(gph_engine *e)
   HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_model), &e->model, sizeof(GphModel), 0, hipMemcpyHostToDevice, e->stream));
   return 0;
 }
-// timed launch: HIP events on the engine's own stream bracket the kernel
-// one launch per P-bucket, each with its own LDS size and layout table
+// timed launch: HIP events on the engine's own stream bracket the kernel.  One dispatch covers every
+// locus with at most one pattern per lane (slots in decreasing P: longest wavefronts first), a second one
+// the rare loci with more (they also need the per-pattern terms array in LDS)
 #define LAUNCH(e, which, name, ...) do { \
     HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_model), &(e)->model, sizeof(GphModel), 0, hipMemcpyHostToDevice, (e)->stream)); \
+    HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lay), &(e)->lay, sizeof(GphLayout), 0, hipMemcpyHostToDevice, (e)->stream)); \
     HIPCHK(hipEventRecord((e)->ev0, (e)->stream)); \
     for (auto &bk_ : (e)->buckets) { \
-      HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lay), &bk_.lay, sizeof(GphLayout), 0, hipMemcpyHostToDevice, (e)->stream)); \
-      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lay.lds_bytes, (e)->stream, (e)->dev, bk_.j0, __VA_ARGS__); \
+      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, (e)->dev, bk_.j0, __VA_ARGS__); \
       HIPCHK(hipGetLastError()); } \
     HIPCHK(hipEventRecord((e)->ev1, (e)->stream)); \
     HIPCHK(hipEventSynchronize((e)->ev1)); \
@@ -418,26 +415,28 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
     return GPH_EARG;
   }
   e->L = L;
-  // slots sorted by P (stable), then cut into buckets at fixed P caps
+  // slots in decreasing P (stable): within a dispatch the longest wavefronts start first; loci with more
+  // than one pattern per lane (P > 64) form their own launch group
   e->h_orig.resize(L);
   for (int64_t g = 0; g < L; g++) e->h_orig[g] = (int32_t)g;
   std::stable_sort(e->h_orig.begin(), e->h_orig.end(), [&](int32_t a, int32_t b) {
-    return (poff[a + 1] - poff[a]) < (poff[b + 1] - poff[b]); });
-  static const int caps[] = {4, 6, 8, 10, 12, 14, 16, 20, 24, 32, 48, 64, 96, 128, 1 << 30};
+    return (poff[a + 1] - poff[a]) > (poff[b + 1] - poff[b]); });
   e->buckets.clear();
   {
-    int64_t j = 0;
-    for (int ci = 0; j < L; ci++) {
-      int64_t j0 = j;
-      int pb = 0;
-      while (j < L && (poff[e->h_orig[j] + 1] - poff[e->h_orig[j]]) <= caps[ci]) { pb = (int)(poff[e->h_orig[j] + 1] - poff[e->h_orig[j]]); j++; }
-      if (j > j0) {
-        gph_engine::Bucket bk;
-        bk.j0 = (int)j0;
-        bk.count = (int)(j - j0);
-        build_layout(bk.lay, n, e->cfg.Kc, e->cfg.K, e->cfg.B, e->cfg.rootPop, pb);
-        e->buckets.push_back(bk);
-      }
+    int64_t nwide = 0;
+    while (nwide < L && (poff[e->h_orig[nwide] + 1] - poff[e->h_orig[nwide]]) > GPH_WAVE) nwide++;
+    if (nwide > 0) {
+      gph_engine::Bucket bk;
+      bk.j0 = 0; bk.count = (int)nwide;
+      bk.lds_bytes = GPH_Q_TERMS(Pmax, n) + 8 * Pmax;
+      e->buckets.push_back(bk);
+    }
+    if (nwide < L) {
+      const int pn = (int)(poff[e->h_orig[nwide] + 1] - poff[e->h_orig[nwide]]);
+      gph_engine::Bucket bk;
+      bk.j0 = (int)nwide; bk.count = (int)(L - nwide);
+      bk.lds_bytes = GPH_Q_BYTES(pn, n);
+      e->buckets.push_back(bk);
     }
   }
   e->h_cond_off.resize(L + 1);
@@ -445,37 +444,31 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   std::vector<uint64_t> seq_off(L + 1);
   std::vector<double> rates(L, 1.0);
   uint64_t off = 0, soff = 0;
-  for (auto &bk : e->buckets) {
-    const int sb = bk.lay.o_cond - bk.lay.o_seq;
-    for (int j = bk.j0; j < bk.j0 + bk.count; j++) {
-      int64_t g = e->h_orig[j];
-      int P = (int)(poff[g + 1] - poff[g]);
-      e->h_P[j] = P;
-      e->h_cond_off[j] = off;
-      off += (uint64_t)2 * (n - 1) * P * 32;
-      seq_off[j] = soff;
-      soff += sb;
-      if (mutRates) rates[j] = mutRates[g];
-    }
+  for (int64_t j = 0; j < L; j++) {
+    int64_t g = e->h_orig[j];
+    int P = (int)(poff[g + 1] - poff[g]);
+    e->h_P[j] = P;
+    e->h_cond_off[j] = off;
+    off += (uint64_t)2 * (n - 1) * P * 32;
+    seq_off[j] = soff;
+    soff += GPH_Q_BYTES(P, n);
+    if (mutRates) rates[j] = mutRates[g];
   }
   e->h_cond_off[L] = off;
   seq_off[L] = soff;
   std::vector<char> seq(soff, 0);
-  for (auto &bk : e->buckets) {
-    const GphLayout &y = bk.lay;
-    for (int j = bk.j0; j < bk.j0 + bk.count; j++) {
-      int64_t g = e->h_orig[j];
-      int P = e->h_P[j];
-      char *blk = seq.data() + seq_off[j];
-      for (int p = 0; p < P; p++) {
-        for (int i = 0; i < n; i++) {
-          uint8_t c = leafcodes[(size_t)(poff[g] + p) * n + i];
-          if (c > 4) return GPH_EARG;
-          blk[(y.q_leaf - y.o_seq) + p * n + i] = (char)c;
-        }
-        blk[(y.q_phases - y.o_seq) + p] = (char)numPhases[poff[g] + p];
-        ((int32_t *)(blk + (y.q_count - y.o_seq)))[p] = counts[poff[g] + p];
+  for (int64_t j = 0; j < L; j++) {
+    int64_t g = e->h_orig[j];
+    int P = e->h_P[j];
+    char *blk = seq.data() + seq_off[j];
+    for (int p = 0; p < P; p++) {
+      for (int i = 0; i < n; i++) {
+        uint8_t c = leafcodes[(size_t)(poff[g] + p) * n + i];
+        if (c > 4) return GPH_EARG;
+        blk[GPH_Q_LEAF + p * n + i] = (char)c;
       }
+      blk[GPH_Q_PHASES(P, n) + p] = (char)numPhases[poff[g] + p];
+      ((int32_t *)(blk + GPH_Q_COUNT(P, n)))[p] = counts[poff[g] + p];
     }
   }
   e->cond_bytes = off;

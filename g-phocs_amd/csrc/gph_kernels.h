@@ -85,7 +85,7 @@ GPH_DEV void scratch_init(const GphDev &D, int g)
 GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withSeq)
 {
   page_in(pages + (size_t)g * g_lay.page_bytes);
-  if (withSeq) copy16_g2l(g_lay.o_seq, D.seq + D.seq_off[g], g_lay.o_cond - g_lay.o_seq);
+  if (withSeq) copy16_g2l(0, D.seq + D.seq_off[g], (int)(D.seq_off[g + 1] - D.seq_off[g]));
   GPH_SYNC();
   scratch_init(D, g);
 }
@@ -182,7 +182,7 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate)
   int i;
   /* blank page */
   for (i = GPH_LANE; i < (int)(sizeof(GphLds) / 4); i += GPH_NLANES) ((GPH_LDS int32_t *)&gph_lds)[i] = 0;
-  copy16_g2l(g_lay.o_seq, D.seq + D.seq_off[g], g_lay.o_cond - g_lay.o_seq);
+  copy16_g2l(0, D.seq + D.seq_off[g], (int)(D.seq_off[g + 1] - D.seq_off[g]));
   GPH_SYNC();
   scratch_init(D, g);
   setISC(IS_RX, 11);

@@ -350,7 +350,7 @@ GPH_DEV double child_factor(int child, const gdbl *cnd, int p, int a, double pe,
 {
   double s0, s1, s2, s3, sa, S, Sp;
   if (child < g_lay.n) {
-    int code = gu8v(g_lay.q_leaf, p * g_lay.n + child);
+    int code = gu8v(GPH_Q_LEAF, p * g_lay.n + child);
     s0 = (code == 4 || code == 0) ? 1.0 : 0.0;
     s1 = (code == 4 || code == 1) ? 1.0 : 0.0;
     s2 = (code == 4 || code == 2) ? 1.0 : 0.0;
@@ -452,7 +452,7 @@ GPH_DEVHOT void child_factor4(int child, const gdbl *cnd, bool fwd, double q0, d
   const int lane = GPH_LANE;
   if (child < g_lay.n) {
     /* leaf: one-hot (or N).  S = 1 exactly, so S*pe = pe and sa*qe is qe or 0: bit-identical shortcut */
-    const int code = act ? (int)gu8v(g_lay.q_leaf, lane * g_lay.n + child) : 4;
+    const int code = act ? (int)gu8v(GPH_Q_LEAF, lane * g_lay.n + child) : 4;
     const double hit = pe + qe;
     f0 = code == 4 ? 1.0 : (code == 0 ? hit : pe);
     f1 = code == 4 ? 1.0 : (code == 1 ? hit : pe);
@@ -528,6 +528,8 @@ GPH_DEVHOT double lik_compute(int useOld)
   useOld = RFL(useOld);
   const int P = CNT(CN_P);
   if (P == 0) return 0.0;
+  const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n);
+  (void)q_terms;
   STAMPB_BEGIN(2);
   const bool isnode = lane < N;
   const int le = isnode ? (int)gph_lds.left[lane] : -1;
@@ -627,7 +629,7 @@ GPH_DEVHOT double lik_compute(int useOld)
     /* the root was computed last: its conditionals for pattern `lane` are q0..q3; only the further
      * phases of an unphased pattern (the following rows) come from memory */
     double term = 0.0;
-    const int ph = lane < P ? gu8v(g_lay.q_phases, lane) : 0;
+    const int ph = lane < P ? gu8v(q_phases, lane) : 0;
     double prob = 0.0;
     prob += q0;
     prob += q1;
@@ -651,7 +653,7 @@ GPH_DEVHOT double lik_compute(int useOld)
       double avg;
       if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
       else avg = prob / nc;
-      term = gph_log(avg) * gi32v(g_lay.q_count, lane);
+      term = gph_log(avg) * gi32v(q_count, lane);
     }
     uint64_t pm = __ballot(ph > 0);
     U = __builtin_popcountll(pm);
@@ -659,18 +661,18 @@ GPH_DEVHOT double lik_compute(int useOld)
   } else {
     GPH_WAVE_FENCE();
     for (int p = lane; p < P; p += GPH_NLANES) {
-      int ph = gu8v(g_lay.q_phases, p);
+      int ph = gu8v(q_phases, p);
       if (ph > 0) {
         int nc = 4 * ph;
         double prob = 0.0;
         for (int c = 0; c < nc; c++) prob += rc[p * 4 + c];
-        sf64(g_lay.s_terms, p, gph_log(prob / nc) * gi32v(g_lay.q_count, p));
+        sf64(q_terms, p, gph_log(prob / nc) * gi32v(q_count, p));
       }
     }
     GPH_SYNC();
     U = 0;
     for (int p = 0; p < P; p++)
-      if (gu8(g_lay.q_phases, p) > 0) { lnl += gf64(g_lay.s_terms, p); U++; }
+      if (gu8(q_phases, p) > 0) { lnl += gf64(q_terms, p); U++; }
   }
   setFS(FS_DATALNL, lnl);
   if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (96.0 * nord * P + 20.0 * N + 8.0 * U + 8.0));
@@ -690,6 +692,7 @@ GPH_DEVHOT double lik_compute(int useOld)
   uint64_t need = 0;
   double lnl;
   if (P == 0) return 0.0;
+  const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n);
   if (!useOld)
     for (node = n; node < N; node++) lik_mark_cond(node);
   setFS(FS_SV_DATALNL, FS(FS_DATALNL));
@@ -735,19 +738,19 @@ GPH_DEVHOT double lik_compute(int useOld)
     const gdbl *rc = cond_base() + cond_off(ISC(IS_ROOT), CBIT(ISC(IS_ROOT)));
     int p;
     for (p = GPH_LANE; p < P; p += GPH_NLANES) {
-      int ph = gu8v(g_lay.q_phases, p);
+      int ph = gu8v(q_phases, p);
       if (ph > 0) {
         int nc = 4 * ph, c;
         double prob = 0.0;
         for (c = 0; c < nc; c++) prob += rc[p * 4 + c];
-        sf64(g_lay.s_terms, p, gph_log(prob / nc) * gi32v(g_lay.q_count, p));
+        sf64(q_terms, p, gph_log(prob / nc) * gi32v(q_count, p));
       }
     }
     GPH_SYNC();
     lnl = 0.0;
     U = 0;
     for (p = 0; p < P; p++) {
-      if (gu8(g_lay.q_phases, p) > 0) { lnl += gf64(g_lay.s_terms, p); U++; }
+      if (gu8(q_phases, p) > 0) { lnl += gf64(q_terms, p); U++; }
     }
   }
   setFS(FS_DATALNL, lnl);

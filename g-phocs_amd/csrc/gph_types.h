@@ -75,6 +75,14 @@ struct GphLayout {
   // seq region (absolute LDS byte offsets): leaf codes u8[P][n], phases u8[P], counts i32[P]
   int32_t q_leaf, q_phases, q_count;
 };
+// Sequence block of one locus (HBM block format == dynamic-LDS image), sized by the locus' OWN number of
+// phased patterns P: leaf codes u8[P][n] | phases u8[P] | (pad to 4) counts i32[P] | (pad to 16);
+// behind it, for loci with more than one pattern per lane only, f64[P] terms of the root reduction
+#define GPH_Q_LEAF 0
+#define GPH_Q_PHASES(P, n) ((P) * (n))
+#define GPH_Q_COUNT(P, n) (((P) * (n) + (P) + 3) & ~3)
+#define GPH_Q_BYTES(P, n) ((GPH_Q_COUNT(P, n) + 4 * (P) + 15) & ~15)
+#define GPH_Q_TERMS(P, n) GPH_Q_BYTES(P, n)
 // delta scalars (s_di[inst])
 enum { DI_ORIG = 0, DI_UPD, DI_DLIN, DI_NEV, DI_NPOPS, DI_NBANDS, DI_COUNT };
 // spr scalars (s_spri), i16 arrays (s_spri16 + 10*k), f64 (s_sprf: new_ages[0..9], dlnLd[10..11])

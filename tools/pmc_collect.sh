@@ -1,0 +1,24 @@
+#!/bin/bash
+# Counter passes for the benchmark workload on the GPU box (run through gpurun from the repo root):
+#   bash tools/pmc_collect.sh <tag>      -> gpurun_out/pmc_<tag>/*.csv + gpurun_out/pmc_<tag>.json
+# Each pass is its own rocprofv3 run with --pmc only (no tracing flags), the program directly after `--`.
+# FETCH_SIZE and WRITE_SIZE get separate passes (MI355X_MICROARCH.md, HBM section).
+set -u
+TAG=${1:-run}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/warm.json" 2> "$OUT/warm.err"   # fills bench_cache/
+pass() { # name counters...
+  local name=$1; shift
+  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" -d "$OUT/$name" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/$name.log" 2>&1)
+  echo "pass $name rc=$?"
+}
+pass insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM
+pass vmem SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES
+pass active SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+python3 tools/pmc_summarize.py "$OUT" > "$ROOT/gpurun_out/pmc_$TAG.json"
+tail -c 1500 "$ROOT/gpurun_out/pmc_$TAG.json"
