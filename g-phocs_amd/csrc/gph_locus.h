@@ -1335,7 +1335,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
   node = RFL(node);
   int i, pop, ev, node_id, b = -1, mig_source, proceed;
   LiveList live = {0, 0};
-  int target, num_targets, nev = 0, rate_ev = -1;
+  int target, num_targets, nev = 0;
   double age, t = 0, event_sample, rate = 0.0, mig_rate, theta, lnld = 0.0;
 
   pop = NPOP(node);
@@ -1377,15 +1377,23 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
   mig_source = -1;
   proceed = 1;
   int guard = 0;
+  /* per step every field of the current interval is read ONCE into registers (the LDS image is only
+   * re-read when the walk steps to another event); the coalescence-statistic delta of the population
+   * being crossed accumulates in a register and is written back when the walk leaves it -- same values,
+   * same order of additions */
+  const int fev_old = RECONNECT ? -1 : SPRI(SI_FEV_OLD);
+  double dcoal = DCOAL(inst, pop);
   while (proceed) {
     if (++guard > 4 * g_lay.E) { gph_fail(96); break; }
     if (ev < 0) {
       if (g_model.popFather[pop] < 0) {
-        if (RECONNECT) { setDI(inst, DI_NEV, nev); setSPRLN(RECONNECT, lnld); return -1; }
+        if (RECONNECT) { setDCOAL(inst, pop, dcoal); setDI(inst, DI_NEV, nev); setSPRLN(RECONNECT, lnld); return -1; }
         gph_fail(6);
         break;
       }
+      setDCOAL(inst, pop, dcoal);
       pop = g_model.popFather[pop];
+      dcoal = DCOAL(inst, pop);
       theta = g_model.theta[pop];
       ev = FIRSTEV(pop);
       mig_rate = 0.0;
@@ -1393,12 +1401,15 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
       age = g_model.popAge[pop];
     }
     node_id = ENODE(ev);
+    int nlin = ENLIN(ev), ty = ETYPE(ev);
+    const double et = EVT(ev);
     if (!RECONNECT) {
-      setENLIN(ev, ENLIN(ev) - 1);
-      t = EVT(ev);
+      nlin -= 1;
+      setENLIN(ev, nlin);
+      t = et;
       age += t;
-      proceed = (ev != SPRI(SI_FEV_OLD));
-      if (ETYPE(ev) == GPH_IN_MIG) {
+      proceed = (ev != fev_old);
+      if (ty == GPH_IN_MIG) {
         if (MG(node_id, MG_BRANCH) == node) {
           int k = SPRI(SI_NOLD);
           b = MG(node_id, MG_BAND);
@@ -1408,12 +1419,11 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
         }
       }
     } else {
-      rate = mig_rate + 2 * ENLIN(ev) / theta;
-      rate_ev = ev;
-      if (UNI(rate <= 0)) t = EVT(ev);
+      rate = mig_rate + 2 * nlin / theta;
+      if (UNI(rate <= 0)) t = et;
       else t = -(1 / rate) * gph_log_u(l_rndu(rng));
-      if (UNI(t >= EVT(ev))) {
-        t = EVT(ev);
+      if (UNI(t >= et)) {
+        t = et;
         age += t;
       } else {
         age += t;
@@ -1422,6 +1432,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
           int k = SPRI(SI_NNEW);
           if (GPH_MAX_MIGS <= ISC(IS_NUM_MIGS) + k - SPRI(SI_NOLD)) {
             setCNT(CN_NOTENOUGH, CNT(CN_NOTENOUGH) + 1);
+            setDCOAL(inst, pop, dcoal);
             setDI(inst, DI_NEV, nev);
             setSPRLN(RECONNECT, lnld);
             return -1;
@@ -1432,37 +1443,41 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
           setSPRA(SA_NEWBAND, k, b);
           if (g_model.bandTgt[b] != pop) { gph_fail(9); break; }
           setSPRAGE(k, age);
-          ev = create_event_before(pop, ev, t);
+          ev = create_event_before(pop, ev, t);   /* the new interval: same lineage count, type DUMMY */
+          ty = GPH_DUMMY;
           setSPRA(SA_NEWIN, k, ev);
           mig_source = create_event(g_model.bandSrc[b], age);
           setSPRA(SA_NEWOUT, k, mig_source);
           if (mig_source < 0) { gph_fail(10); break; }
           setSPRI(SI_NNEW, k + 1);
         } else {
-          num_targets = edges_for_time_pop((age - t) + EVT(ev) / 2, pop, node);
-          if (num_targets != ENLIN(ev)) { gph_fail(11); break; }
+          num_targets = edges_for_time_pop((age - t) + et / 2, pop, node);
+          if (num_targets != nlin) { gph_fail(11); break; }
           i = (int)((event_sample - mig_rate) * theta / 2);
           target = gi16(&GphLds::s_targets, i);
           lik_spr(node, target, age);
           setSPRI(SI_FPOP_NEW, pop);
           setSPRI(SI_TARGET, target);
           ev = create_event_before(pop, ev, t);
+          ty = GPH_DUMMY;
           setSPRI(SI_FEV_NEW, ev);
           proceed = 0;
         }
       }
     }
-    setDCOAL(inst, pop, DCOAL(inst, pop) + 2 * ENLIN(ev) * t);
+    dcoal += 2 * nlin * t;
     for (i = 0; i < live.n; i++) setDMIG(inst, ll_get(live, i), DMIG(inst, ll_get(live, i)) + t);
     setDEV(inst, nev, ev);
     nev++;
-    /* the same expression as `rate` above unless the walk ended inside the interval (new event) */
-    if (RECONNECT && ev == rate_ev) lnld -= rate * t;
-    else lnld -= (mig_rate + 2 * ENLIN(ev) / theta) * t;
+    /* RECONNECT: the interval's rate was just computed (a split interval keeps its lineage count) */
+    if (RECONNECT) lnld -= rate * t;
+    else lnld -= (mig_rate + 2 * nlin / theta) * t;
     if (mig_source >= 0) {
       lnld += gph_log_u(g_model.migRate[b]);
       ev = mig_source;
+      setDCOAL(inst, pop, dcoal);
       pop = g_model.bandSrc[b];
+      dcoal = DCOAL(inst, pop);
       theta = g_model.theta[pop];
       mig_source = -1;
       mig_rate = 0.0;
@@ -1473,10 +1488,10 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
           ll_push(live, b);
         }
       }
-    } else if (ETYPE(ev) == GPH_MIG_BAND_START) {
+    } else if (ty == GPH_MIG_BAND_START) {
       mig_rate += g_model.migRate[node_id];
       ll_push(live, node_id);
-    } else if (ETYPE(ev) == GPH_MIG_BAND_END) {
+    } else if (ty == GPH_MIG_BAND_END) {
       mig_rate -= g_model.migRate[node_id];
       if (live.n == 1) mig_rate = 0.0;
       i = ll_find(live, node_id);
@@ -1484,6 +1499,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
     }
     ev = ENEXT(ev);
   }
+  setDCOAL(inst, pop, dcoal);
   lnld += gph_log_u(2 / theta);
   setDI(inst, DI_NEV, nev);
   setSPRLN(RECONNECT, lnld);
