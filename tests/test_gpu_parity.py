@@ -73,6 +73,34 @@ def test_many_patterns_against_live_oracle(G, oracle_cli, tmp_path):
     compare_states(st1, os_)
 
 
+@pytest.mark.parametrize("config,loci,iters,mut", [(4, 3000, 24, 6.5), (5, 1500, 20, 3.0), (3, 2000, 30, 1.0)])
+def test_scale_parity_against_live_oracle(G, oracle_cli, tmp_path, config, loci, iters, mut):
+    """thousands of loci of the benchmark's synthetic shape (configs[3] and [4], and the 3-population one),
+    through every proposal type, against the oracle run live on the same pack: ~10^5 locus-iterations,
+    so rare paths (migration-event creation, rubber-band conflicts, checkAll resync at samples-per-log)
+    are hit.  Counters exact, accumulators <= 1e-10 relative, final per-locus state field by field."""
+    from gphocs_amd_pkg import synth
+    pk = synth.make_synthetic_pack(G.Pack, config, loci, mut_scale=mut, data_seed=777 + config, mcmc_seed=4242,
+                                   samples_per_log=8)
+    pth = str(tmp_path / "scale.gpk")
+    synth.write_pack(pk, pth)
+    tr, _, st1, cnt = _run(G, pth, iters, tmp_path, "scale")
+    ot, os_ = tmp_path / "o.trace", tmp_path / "o.state"
+    subprocess.run([oracle_cli, "run", pth, str(iters), str(ot), str(os_), str(iters - 1), "0"], check=True,
+                   timeout=1200)
+    worst = compare_records(tr, ot)
+    # state without conditionals on the oracle side: compare the genealogy / chain / statistics fields
+    st_nc = tmp_path / "scale.nc.state"
+    s = G.Sampler(G.Pack.load(pth))
+    s.initialize()
+    for it in range(iters):
+        s.iteration(it)
+    s.dump_state(str(st_nc), False)
+    s.close()
+    compare_states(st_nc, os_)
+    print(f"config {config}: {loci} loci x {iters} iterations, worst accumulator rel diff {worst:.3e}, evals {cnt['evals']}")
+
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, %(repo)r)
