@@ -35,7 +35,7 @@ __constant__ GphModel g_model;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "gphocs_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return GPH_EHIP; } } while (0)
 #endif
 
-// j0 = first slot of the bucket being launched (see GphDev)
+// j0 = first slot of the launch group (see GphDev)
 GPH_KERNEL(k_init, GphDev D, int j0, uint32_t seedz, const double *mutRate) { kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0); }
 GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphDev D, int j0, int flags, double ftCoal, double ftMig) { kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
 GPH_KERNEL(k_tau_eval, GphDev D, int j0, GphTauArgs A) { kb_tau_eval(D, j0 + GPH_BLK, A); }
@@ -501,7 +501,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   e->dev.locus_begin = e->cfg.locus_begin;
   e->loaded = true;
 #ifndef GPH_HOSTEMU
-  // per-locus kernels use up to the largest bucket's dynamic LDS size; allow > 64 KiB
+  // per-locus kernels use up to the wide group's dynamic LDS size; allow > 64 KiB
   const void *ks[] = {(const void *)k_init, (const void *)k_sweep, (const void *)k_tau_eval, (const void *)k_tau_commit,
                       (const void *)k_tau_revert, (const void *)k_mix_eval, (const void *)k_mix_commit,
                       (const void *)k_sync, (const void *)k_check};
