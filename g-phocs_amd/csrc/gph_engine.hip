@@ -191,16 +191,15 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   int o = 0;
   auto f64 = [&](int cnt) { o = align_up(o, 8); int r = o; o += 8 * cnt; return r; };
 #define OFS(f) ((int32_t)offsetof(GphLds, f))
-  y.o_age = OFS(age); y.o_sv_age = OFS(sv_age); y.o_ev_time = OFS(ev_time); y.o_mig_age = OFS(mig_age);
+  y.o_ev = OFS(ev); y.o_age = OFS(age); y.o_sv_age = OFS(sv_age); y.o_mig_age = OFS(mig_age);
   y.o_coal = OFS(coal); y.o_migst = OFS(migst); y.o_rb_age = OFS(rb_age); y.o_fscal = OFS(fscal);
   y.o_iscal = OFS(iscal);
   y.o_father = OFS(father); y.o_left = OFS(left); y.o_right = OFS(right); y.o_npop = OFS(npop); y.o_nev = OFS(nev);
   y.o_sv_father = OFS(sv_father); y.o_sv_left = OFS(sv_left); y.o_sv_right = OFS(sv_right);
   y.o_changed = OFS(changed); y.o_changedc = OFS(changedc);
-  y.o_ev_next = OFS(ev_next); y.o_ev_prev = OFS(ev_prev); y.o_ev_node = OFS(ev_node); y.o_ev_nlin = OFS(ev_nlin);
   y.o_first = OFS(first);
   y.o_mig_i = OFS(mig_i); y.o_living = OFS(living); y.o_ncoal = OFS(ncoal); y.o_nmig = OFS(nmig); y.o_rb_i = OFS(rb_i);
-  y.o_ev_type = OFS(ev_type); y.o_condbit = OFS(condbit); y.o_dirty = OFS(dirty);
+  y.o_condbit = OFS(condbit); y.o_dirty = OFS(dirty);
   y.page_bytes = align_up(OFS(s_dcoal), 16);
 #undef OFS
   // dynamic LDS: sequence block (also the HBM block format) + per-pattern terms of the root
@@ -802,10 +801,9 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
     const int16_t *fa = (const int16_t *)(pg + y.o_father), *le = (const int16_t *)(pg + y.o_left),
                   *ri = (const int16_t *)(pg + y.o_right), *np = (const int16_t *)(pg + y.o_npop),
                   *ne = (const int16_t *)(pg + y.o_nev);
-    const int16_t *enext = (const int16_t *)(pg + y.o_ev_next), *enode = (const int16_t *)(pg + y.o_ev_node),
-                  *enlin = (const int16_t *)(pg + y.o_ev_nlin), *first = (const int16_t *)(pg + y.o_first);
-    const uint8_t *etype = (const uint8_t *)(pg + y.o_ev_type), *cbit = (const uint8_t *)(pg + y.o_condbit);
-    const double *evt = (const double *)(pg + y.o_ev_time);
+    const int16_t *first = (const int16_t *)(pg + y.o_first);
+    const uint8_t *cbit = (const uint8_t *)(pg + y.o_condbit);
+    const GphEv *evr = (const GphEv *)(pg + y.o_ev);
     fprintf(f, "LOCUS %lld root %d dataLnL %a genLnL %a rng %u %u %u\n", (long long)(go + e->cfg.locus_begin), is[IS_ROOT],
             fs[FS_DATALNL], fs[FS_GENLNL], (unsigned)is[IS_RX], (unsigned)is[IS_RY], (unsigned)is[IS_RZ]);
     for (int i = 0; i < y.N; i++)
@@ -813,8 +811,8 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
     for (int pop = 0; pop < y.K; pop++) {
       fprintf(f, "C %d", pop);
       int guard = 0;
-      for (int ev = first[pop]; ev >= 0 && guard++ < y.E; ev = enext[ev])
-        fprintf(f, " %d:%d:%d:%d:%a", ev, etype[ev], enode[ev], enlin[ev], evt[ev]);
+      for (int ev = first[pop]; ev >= 0 && guard++ < y.E; ev = evr[ev].next)
+        fprintf(f, " %d:%d:%d:%d:%a", ev, evr[ev].type, evr[ev].node, evr[ev].nlin, evr[ev].time);
       fprintf(f, "\n");
     }
     fprintf(f, "S");

@@ -622,8 +622,8 @@ GPH_DEV void kb_mix_commit(const GphDev &D, int g, double c, double lnc)
   for (pop = 0; pop < g_lay.K; pop++) setCOALS(pop, COALS(pop) * c);
   for (b = 0; b < g_lay.B; b++) setMIGST(b, MIGST(b) * c);
   for (i = GPH_LANE; i < g_lay.E; i += GPH_NLANES) {
-    double t = gf64(&GphLds::ev_time, i);
-    if (t > 0) sf64(&GphLds::ev_time, i, t * c);
+    double t = gph_lds.ev[i].time;
+    if (t > 0) gph_lds.ev[i].time = t * c;
   }
   GPH_SYNC();
   {

@@ -16,8 +16,8 @@
 #define setAGE(i, v) sf64(&GphLds::age, (i), (v))
 #define SVAGE(i) gf64(&GphLds::sv_age, (i))
 #define setSVAGE(i, v) sf64(&GphLds::sv_age, (i), (v))
-#define EVT(e) gf64(&GphLds::ev_time, (e))
-#define setEVT(e, v) sf64(&GphLds::ev_time, (e), (v))
+#define EVT(e) (gph_lds.ev[e].time)
+#define setEVT(e, v) (gph_lds.ev[e].time = (v))
 #define MAGE(m) gf64(&GphLds::mig_age, (m))
 #define setMAGE(m, v) sf64(&GphLds::mig_age, (m), (v))
 #define COALS(p) gf64(&GphLds::coal, (p))
@@ -43,16 +43,16 @@
 #define SVR(i) gi16(&GphLds::sv_right, (i))
 #define CHG(i) gi16(&GphLds::changed, (i))
 #define CHGC(i) gi16(&GphLds::changedc, (i))
-#define ENEXT(e) gi16(&GphLds::ev_next, (e))
-#define setENEXT(e, v) si16(&GphLds::ev_next, (e), (v))
-#define EPREV(e) gi16(&GphLds::ev_prev, (e))
-#define setEPREV(e, v) si16(&GphLds::ev_prev, (e), (v))
-#define ENODE(e) gi16(&GphLds::ev_node, (e))
-#define setENODE(e, v) si16(&GphLds::ev_node, (e), (v))
-#define ENLIN(e) gi16(&GphLds::ev_nlin, (e))
-#define setENLIN(e, v) si16(&GphLds::ev_nlin, (e), (v))
-#define ETYPE(e) gu8(&GphLds::ev_type, (e))
-#define setETYPE(e, v) su8(&GphLds::ev_type, (e), (v))
+#define ENEXT(e) RFL((int)gph_lds.ev[e].next)
+#define setENEXT(e, v) (gph_lds.ev[e].next = (int16_t)(v))
+#define EPREV(e) RFL((int)gph_lds.ev[e].prev)
+#define setEPREV(e, v) (gph_lds.ev[e].prev = (int16_t)(v))
+#define ENODE(e) RFL((int)gph_lds.ev[e].node)
+#define setENODE(e, v) (gph_lds.ev[e].node = (int16_t)(v))
+#define ENLIN(e) RFL((int)gph_lds.ev[e].nlin)
+#define setENLIN(e, v) (gph_lds.ev[e].nlin = (int8_t)(v))
+#define ETYPE(e) RFL((int)gph_lds.ev[e].type)
+#define setETYPE(e, v) (gph_lds.ev[e].type = (uint8_t)(v))
 #define FIRSTEV(p) gi16(&GphLds::first, (p))
 #define setFIRSTEV(p, v) si16(&GphLds::first, (p), (v))
 #define MG(m, f) gi16(&GphLds::mig_i, (m) * MG_COUNT + (f))

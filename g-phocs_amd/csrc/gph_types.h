@@ -49,16 +49,17 @@ struct GphModel {
 struct GphLayout {
   int32_t n, N, K, Kc, B, E, RB, rootPop;
   // f64
-  int32_t o_age, o_sv_age, o_ev_time, o_mig_age, o_coal, o_migst, o_rb_age, o_fscal;
+  int32_t o_ev;            // event records (GphEv[E])
+  int32_t o_age, o_sv_age, o_mig_age, o_coal, o_migst, o_rb_age, o_fscal;
   // i16
   int32_t o_father, o_left, o_right, o_npop, o_nev, o_sv_father, o_sv_left, o_sv_right;
   int32_t o_changed, o_changedc;
-  int32_t o_ev_next, o_ev_prev, o_ev_node, o_ev_nlin, o_first;
+  int32_t o_first;
   int32_t o_mig_i, o_living, o_ncoal, o_nmig, o_rb_i;
   // i32
   int32_t o_iscal;
   // u8
-  int32_t o_ev_type, o_condbit, o_dirty;
+  int32_t o_condbit, o_dirty;
   int32_t page_bytes;      // multiple of 16
   int32_t scratch_bytes;   // LDS-only per-wave scratch (pending-proposal storage)
   int32_t Pmax;            // max phased patterns of any locus on this device
@@ -124,17 +125,29 @@ enum { OUT_ACCEPT = 0, OUT_DDATA, OUT_DLOG, OUT_EVALS, OUT_EVALNODES, OUT_EVALBY
 #define GPH_CAP_E (2 * GPH_CAP_LEAVES + 4 * GPH_MAX_MIGS + 3 * GPH_CAP_B + GPH_CAP_K + 10)
 #define GPH_CAP_RB (GPH_MAX_MIGS + 2 * GPH_CAP_B)
 
+// One event = one 16-byte record (Event, patch.h:151-165): a chain walk needs next / lineages / type /
+// elapsed time / node of the SAME event at every step, and one ds_read_b128 fetches them all (the
+// wave-uniform access overhead -- address move, wait, readfirstlane -- is paid once per event, not per field).
+struct alignas(16) GphEv {
+  double time;            // elapsed_time
+  int16_t next, prev;     // chain links
+  int16_t node;           // node_id (genealogy node, migration node or band)
+  int8_t nlin;            // num_lineages
+  uint8_t type;           // EventType
+};
+
 struct alignas(16) GphLds {
   // ---- page (mirrors the HBM page arrays, GphLayout o_*)
-  double age[GPH_CAP_N], sv_age[GPH_CAP_N], ev_time[GPH_CAP_E], mig_age[GPH_MAX_MIGS];
+  GphEv ev[GPH_CAP_E];
+  double age[GPH_CAP_N], sv_age[GPH_CAP_N], mig_age[GPH_MAX_MIGS];
   double coal[GPH_CAP_K], migst[GPH_CAP_B], rb_age[GPH_CAP_RB], fscal[FS_COUNT_];
   int32_t iscal[IS_COUNT_];
   int16_t father[GPH_CAP_N], left[GPH_CAP_N], right[GPH_CAP_N], npop[GPH_CAP_N], nev[GPH_CAP_N];
   int16_t sv_father[GPH_CAP_N], sv_left[GPH_CAP_N], sv_right[GPH_CAP_N];
   int16_t changed[2 * GPH_CAP_N], changedc[2 * GPH_CAP_N];
-  int16_t ev_next[GPH_CAP_E], ev_prev[GPH_CAP_E], ev_node[GPH_CAP_E], ev_nlin[GPH_CAP_E], first[GPH_CAP_K];
+  int16_t first[GPH_CAP_K];
   int16_t mig_i[GPH_MAX_MIGS * 6], living[GPH_MAX_MIGS], ncoal[GPH_CAP_K], nmig[GPH_CAP_B], rb_i[3 * GPH_CAP_RB];
-  uint8_t ev_type[GPH_CAP_E], condbit[GPH_CAP_N], dirty[GPH_CAP_N];
+  uint8_t condbit[GPH_CAP_N], dirty[GPH_CAP_N];
   // ---- LDS-only scratch: pending-proposal storage of GENETREE_STATS_DELTA x2 (patch.h:60-72),
   // MIG_SPR_STATS (patch.h:97-105), genetree_stats_check (patch.h:109), pruning work lists
   double s_dcoal[2][GPH_CAP_K], s_dmig[2][GPH_CAP_B], s_sprf[GPH_MAX_MIGS + 2];
