@@ -109,6 +109,30 @@ GPH_DEV void ll_push(LiveList &l, int v) { ll_set(l, l.n, v); l.n++; }
 GPH_DEV int ll_find(const LiveList &l, int v) { int i; for (i = 0; i < l.n; i++) if (ll_get(l, i) == v) break; return i; }
 GPH_DEV void ll_swap_remove(LiveList &l, int i) { l.n--; ll_set(l, i, ll_get(l, l.n)); }
 
+// every field of one event with ONE LDS access (ds_read_b128 of the GphEv record)
+struct GphEvS { double time; int next, prev, node, nlin, type; };
+GPH_DEVHOT GphEvS ld_ev(int ev)
+{
+  GphEvS r;
+#ifdef GPH_HOSTEMU
+  r.time = gph_lds.ev[ev].time; r.next = gph_lds.ev[ev].next; r.prev = gph_lds.ev[ev].prev;
+  r.node = gph_lds.ev[ev].node; r.nlin = gph_lds.ev[ev].nlin; r.type = gph_lds.ev[ev].type;
+#else
+  typedef uint32_t gph_u4 __attribute__((ext_vector_type(4)));
+  const gph_u4 w = *(const GPH_LDS gph_u4 *)&gph_lds.ev[ev];
+  union { double d; uint32_t u[2]; } t;
+  t.u[0] = w.x; t.u[1] = w.y;
+  const int w2 = RFL((int)w.z), w3 = RFL((int)w.w);
+  r.time = t.d;
+  r.next = (int)(int16_t)w2;
+  r.prev = w2 >> 16;
+  r.node = (int)(int16_t)w3;
+  r.nlin = (int)(int8_t)(w3 >> 16);
+  r.type = (int)((uint32_t)w3 >> 24);
+#endif
+  return r;
+}
+
 #define gmin2(a, b) ((a) < (b) ? (a) : (b))
 #define gmax2(a, b) ((a) > (b) ? (a) : (b))
 
@@ -880,8 +904,9 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
 // removeEvent, patch.c:1666-1700
 GPH_DEV void remove_event(int ev)
 {
-  int nx = ENEXT(ev), pv = EPREV(ev);
-  setEVT(nx, EVT(nx) + EVT(ev));
+  const GphEvS R = ld_ev(ev);
+  int nx = R.next, pv = R.prev;
+  setEVT(nx, EVT(nx) + R.time);
   setEPREV(nx, pv);
   if (pv < 0) {
     int guard = 0;
@@ -901,16 +926,18 @@ GPH_DEV void remove_event(int ev)
 // createEventBefore, patch.c:1707-1742
 GPH_DEV int create_event_before(int pop, int ev, double elapsed)
 {
-  int pv = EPREV(ev), nw = ISC(IS_FREE);
-  setISC(IS_FREE, ENEXT(nw));
-  if (ENEXT(nw) < 0) { gph_fail(15); }
+  const GphEvS R = ld_ev(ev);
+  int pv = R.prev, nw = ISC(IS_FREE);
+  const int fnext = ENEXT(nw);
+  setISC(IS_FREE, fnext);
+  if (fnext < 0) { gph_fail(15); }
   setENEXT(nw, ev);
   setEPREV(nw, pv);
-  setENLIN(nw, ENLIN(ev));
+  setENLIN(nw, R.nlin);
   setEVT(nw, elapsed);
   setETYPE(nw, GPH_DUMMY);
   setEPREV(ev, nw);
-  setEVT(ev, EVT(ev) - elapsed);
+  setEVT(ev, R.time - elapsed);
   if (pv < 0) setFIRSTEV(pop, nw);
   else setENEXT(pv, nw);
   return nw;
@@ -924,13 +951,17 @@ GPH_DEVHOT int create_event(int pop, double age)
   if (UNI(dt < 0)) return -1;
   if (pop != g_lay.rootPop && UNI(age > g_model.popAge[g_model.popFather[pop]] + 0.000001)) return -1;
   int guard = 0;
-  for (ev = FIRSTEV(pop); ETYPE(ev) != GPH_END_CHAIN && UNI(EVT(ev) < dt); ev = ENEXT(ev)) {
-    dt -= EVT(ev);
-    if (++guard > g_lay.E || ENEXT(ev) < 0) { gph_fail(92); return -1; }
+  ev = FIRSTEV(pop);
+  GphEvS R = ld_ev(ev);
+  while (R.type != GPH_END_CHAIN && UNI(R.time < dt)) {
+    dt -= R.time;
+    if (++guard > g_lay.E || R.next < 0) { gph_fail(92); return -1; }
+    ev = R.next;
+    R = ld_ev(ev);
   }
-  if (UNI(EVT(ev) < dt)) {
-    if (UNI(EVT(ev) < dt - 0.000001)) { gph_fail(18); return -1; }
-    dt = EVT(ev);
+  if (UNI(R.time < dt)) {
+    if (UNI(R.time < dt - 0.000001)) { gph_fail(18); return -1; }
+    dt = R.time;
   }
   return create_event_before(pop, ev, dt);
 }
@@ -946,14 +977,17 @@ GPH_DEVHOT double recalc_stats(int pop)
   int guard = 0;
   ev = FIRSTEV(pop);
   n = ENLIN(ev);
-  for (; ev >= 0; ev = ENEXT(ev)) {
+  int nxt;
+  for (; ev >= 0; ev = nxt) {
     if (++guard > g_lay.E) { gph_fail(93); return 0.0; }
+    const GphEvS R = ld_ev(ev);
+    nxt = R.next;
     setENLIN(ev, n);
-    id = ENODE(ev);
-    t = EVT(ev);
+    id = R.node;
+    t = R.time;
     cs += n * (n - 1) * t;
     for (b = 0; b < live.n; b++) sf64(&GphLds::s_chkmig, ll_get(live, b), gf64(&GphLds::s_chkmig, ll_get(live, b)) + n * t);
-    switch (ETYPE(ev)) {
+    switch (R.type) {
     case GPH_SAMPLES_START: n += g_model.samplesPerPop[pop]; break;
     case GPH_COAL: nc++; n--; break;
     case GPH_IN_MIG: {
@@ -1104,11 +1138,12 @@ GPH_DEV void coal_stats_delta(int inst, int bottom_event, int bottom_pop, int to
   setDPOPS(inst, 0, pop);
   while (ev >= 0) {
     if (++guard > 2 * g_lay.E) { gph_fail(94); break; }
-    acc += dlin * (dlin - 1 + 2 * ENLIN(ev)) * EVT(ev);
+    const GphEvS R = ld_ev(ev);
+    acc += dlin * (dlin - 1 + 2 * R.nlin) * R.time;
     setDEV(inst, ne, ev);
     ne++;
     if (ev == top_event) break;
-    ev = ENEXT(ev);
+    ev = R.next;
     if (ev < 0) {
       if (g_model.popFather[pop] < 0) { gph_fail(19); break; }
       setDCOAL(inst, np - 1, acc);
@@ -1400,9 +1435,11 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
       if (fabs(age / g_model.popAge[pop] - 1) > 0.01) { gph_fail(8); break; }
       age = g_model.popAge[pop];
     }
-    node_id = ENODE(ev);
-    int nlin = ENLIN(ev), ty = ETYPE(ev);
-    const double et = EVT(ev);
+    const GphEvS R = ld_ev(ev);
+    const int ev0 = ev;
+    node_id = R.node;
+    int nlin = R.nlin, ty = R.type;
+    const double et = R.time;
     if (!RECONNECT) {
       nlin -= 1;
       setENLIN(ev, nlin);
@@ -1497,7 +1534,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
       i = ll_find(live, node_id);
       if (i < live.n) ll_swap_remove(live, i);
     }
-    ev = ENEXT(ev);
+    ev = (ev == ev0) ? R.next : ENEXT(ev);   /* nothing is inserted AFTER the interval within a step */
   }
   setDCOAL(inst, pop, dcoal);
   lnld += gph_log_u(2 / theta);
