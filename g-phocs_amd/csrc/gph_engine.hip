@@ -191,11 +191,10 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   int o = 0;
   auto f64 = [&](int cnt) { o = align_up(o, 8); int r = o; o += 8 * cnt; return r; };
 #define OFS(f) ((int32_t)offsetof(GphLds, f))
-  y.o_ev = OFS(ev); y.o_age = OFS(age); y.o_sv_age = OFS(sv_age); y.o_mig_age = OFS(mig_age);
+  y.o_ev = OFS(ev); y.o_nd = OFS(nd); y.o_sv = OFS(sv); y.o_mig_age = OFS(mig_age);
   y.o_coal = OFS(coal); y.o_migst = OFS(migst); y.o_rb_age = OFS(rb_age); y.o_fscal = OFS(fscal);
   y.o_iscal = OFS(iscal);
-  y.o_father = OFS(father); y.o_left = OFS(left); y.o_right = OFS(right); y.o_npop = OFS(npop); y.o_nev = OFS(nev);
-  y.o_sv_father = OFS(sv_father); y.o_sv_left = OFS(sv_left); y.o_sv_right = OFS(sv_right);
+  y.o_nev = OFS(nev);
   y.o_changed = OFS(changed); y.o_changedc = OFS(changedc);
   y.o_first = OFS(first);
   y.o_mig_i = OFS(mig_i); y.o_living = OFS(living); y.o_ncoal = OFS(ncoal); y.o_nmig = OFS(nmig); y.o_rb_i = OFS(rb_i);
@@ -797,17 +796,15 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
     const char *pg = pages.data() + (size_t)g * y.page_bytes;
     const double *fs = (const double *)(pg + y.o_fscal);
     const int32_t *is = (const int32_t *)(pg + y.o_iscal);
-    const double *age = (const double *)(pg + y.o_age);
-    const int16_t *fa = (const int16_t *)(pg + y.o_father), *le = (const int16_t *)(pg + y.o_left),
-                  *ri = (const int16_t *)(pg + y.o_right), *np = (const int16_t *)(pg + y.o_npop),
-                  *ne = (const int16_t *)(pg + y.o_nev);
+    const GphNode *nd = (const GphNode *)(pg + y.o_nd);
+    const int16_t *ne = (const int16_t *)(pg + y.o_nev);
     const int16_t *first = (const int16_t *)(pg + y.o_first);
     const uint8_t *cbit = (const uint8_t *)(pg + y.o_condbit);
     const GphEv *evr = (const GphEv *)(pg + y.o_ev);
     fprintf(f, "LOCUS %lld root %d dataLnL %a genLnL %a rng %u %u %u\n", (long long)(go + e->cfg.locus_begin), is[IS_ROOT],
             fs[FS_DATALNL], fs[FS_GENLNL], (unsigned)is[IS_RX], (unsigned)is[IS_RY], (unsigned)is[IS_RZ]);
     for (int i = 0; i < y.N; i++)
-      fprintf(f, "N %d %d %d %d %a %d %d\n", i, fa[i], le[i], ri[i], age[i], np[i], i < y.n ? -1 : ne[i]);
+      fprintf(f, "N %d %d %d %d %a %d %d\n", i, nd[i].father, nd[i].left, nd[i].right, nd[i].age, nd[i].npop, i < y.n ? -1 : ne[i]);
     for (int pop = 0; pop < y.K; pop++) {
       fprintf(f, "C %d", pop);
       int guard = 0;

@@ -218,16 +218,17 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune, GphRng &rng
   int pop, inode, i, son, mig, acc = 0;
   double t, tnew, lnacc, lnLd, dgen, tb0, tb1, dData = 0, dLog = 0;
   for (inode = g_lay.n; inode < g_lay.N; inode++) {
-    t = AGE(inode);
-    pop = NPOP(inode);
+    const GphNodeS me = ld_node(inode);
+    t = me.age;
+    pop = me.npop;
     tb0 = g_model.popAge[pop];
     if (pop != g_lay.rootPop) tb1 = g_model.popAge[g_model.popFather[pop]];
     else tb1 = GPH_OLDAGE;
     mig = find_first_mig(inode, -1);
     if (mig >= 0) tb1 = gmin2(tb1, MAGE(mig));
-    else if (inode != ISC(IS_ROOT)) tb1 = gmin2(tb1, AGE(FATH(inode)));
+    else if (inode != ISC(IS_ROOT)) tb1 = gmin2(tb1, AGE(me.father));
     for (i = 0; i < 2; i++) {
-      son = i == 0 ? LEFT(inode) : RGHT(inode);
+      son = i == 0 ? me.left : me.right;
       mig = find_last_mig(son, -1);
       if (mig >= 0) tb0 = gmax2(tb0, MAGE(mig));
       else tb0 = gmax2(tb0, AGE(son));

@@ -12,10 +12,10 @@
 #include "gph_rt.h"
 
 // ---------------------------------------------------------------- accessors
-#define AGE(i) gf64(&GphLds::age, (i))
-#define setAGE(i, v) sf64(&GphLds::age, (i), (v))
-#define SVAGE(i) gf64(&GphLds::sv_age, (i))
-#define setSVAGE(i, v) sf64(&GphLds::sv_age, (i), (v))
+#define AGE(i) (gph_lds.nd[i].age)
+#define setAGE(i, v) (gph_lds.nd[i].age = (v))
+#define SVAGE(i) (gph_lds.sv[i].age)
+#define setSVAGE(i, v) (gph_lds.sv[i].age = (v))
 #define EVT(e) (gph_lds.ev[e].time)
 #define setEVT(e, v) (gph_lds.ev[e].time = (v))
 #define MAGE(m) gf64(&GphLds::mig_age, (m))
@@ -28,19 +28,19 @@
 #define setRBAGE(i, v) sf64(&GphLds::rb_age, (i), (v))
 #define FS(k) gf64(&GphLds::fscal, (k))
 #define setFS(k, v) sf64(&GphLds::fscal, (k), (v))
-#define FATH(i) gi16(&GphLds::father, (i))
-#define setFATH(i, v) si16(&GphLds::father, (i), (v))
-#define LEFT(i) gi16(&GphLds::left, (i))
-#define setLEFT(i, v) si16(&GphLds::left, (i), (v))
-#define RGHT(i) gi16(&GphLds::right, (i))
-#define setRGHT(i, v) si16(&GphLds::right, (i), (v))
-#define NPOP(i) gi16(&GphLds::npop, (i))
-#define setNPOP(i, v) si16(&GphLds::npop, (i), (v))
+#define FATH(i) RFL((int)gph_lds.nd[i].father)
+#define setFATH(i, v) (gph_lds.nd[i].father = (int16_t)(v))
+#define LEFT(i) RFL((int)gph_lds.nd[i].left)
+#define setLEFT(i, v) (gph_lds.nd[i].left = (int16_t)(v))
+#define RGHT(i) RFL((int)gph_lds.nd[i].right)
+#define setRGHT(i, v) (gph_lds.nd[i].right = (int16_t)(v))
+#define NPOP(i) RFL((int)gph_lds.nd[i].npop)
+#define setNPOP(i, v) (gph_lds.nd[i].npop = (int16_t)(v))
 #define NEV(i) gi16(&GphLds::nev, (i))
 #define setNEV(i, v) si16(&GphLds::nev, (i), (v))
-#define SVF(i) gi16(&GphLds::sv_father, (i))
-#define SVL(i) gi16(&GphLds::sv_left, (i))
-#define SVR(i) gi16(&GphLds::sv_right, (i))
+#define SVF(i) RFL((int)gph_lds.sv[i].father)
+#define SVL(i) RFL((int)gph_lds.sv[i].left)
+#define SVR(i) RFL((int)gph_lds.sv[i].right)
 #define CHG(i) gi16(&GphLds::changed, (i))
 #define CHGC(i) gi16(&GphLds::changedc, (i))
 #define ENEXT(e) RFL((int)gph_lds.ev[e].next)
@@ -109,6 +109,28 @@ GPH_DEV void ll_push(LiveList &l, int v) { ll_set(l, l.n, v); l.n++; }
 GPH_DEV int ll_find(const LiveList &l, int v) { int i; for (i = 0; i < l.n; i++) if (ll_get(l, i) == v) break; return i; }
 GPH_DEV void ll_swap_remove(LiveList &l, int i) { l.n--; ll_set(l, i, ll_get(l, l.n)); }
 
+// every field of one genealogy node with ONE LDS access
+struct GphNodeS { double age; int father, left, right, npop; };
+GPH_DEVHOT GphNodeS ld_node(int node)
+{
+  GphNodeS r;
+#ifdef GPH_HOSTEMU
+  r.age = gph_lds.nd[node].age; r.father = gph_lds.nd[node].father; r.left = gph_lds.nd[node].left;
+  r.right = gph_lds.nd[node].right; r.npop = gph_lds.nd[node].npop;
+#else
+  typedef uint32_t gph_u4 __attribute__((ext_vector_type(4)));
+  const gph_u4 w = *(const GPH_LDS gph_u4 *)&gph_lds.nd[node];
+  union { double d; uint32_t u[2]; } t;
+  t.u[0] = w.x; t.u[1] = w.y;
+  const int w2 = RFL((int)w.z), w3 = RFL((int)w.w);
+  r.age = t.d;
+  r.father = (int)(int16_t)w2;
+  r.left = w2 >> 16;
+  r.right = (int)(int16_t)w3;
+  r.npop = w3 >> 16;
+#endif
+  return r;
+}
 // every field of one event with ONE LDS access (ds_read_b128 of the GphEv record)
 struct GphEvS { double time; int next, prev, node, nlin, type; };
 GPH_DEVHOT GphEvS ld_ev(int ev)
@@ -266,10 +288,7 @@ GPH_DEV void lik_save_node(int node, int recalc)
   k = ISC(IS_NCHANGED);
   si16(&GphLds::changed, k, node);
   setISC(IS_NCHANGED, k + 1);
-  setSVAGE(node, AGE(node));
-  si16(&GphLds::sv_father, node, FATH(node));
-  si16(&GphLds::sv_left, node, LEFT(node));
-  si16(&GphLds::sv_right, node, RGHT(node));
+  gph_lds.sv[node] = gph_lds.nd[node];   /* one 16-byte record: age, father, left, right */
 }
 // adjustGenNodeAge, LocusDataLikelihood.c:875-882
 GPH_DEV void lik_adjust_age(int node, double age)
@@ -556,9 +575,10 @@ GPH_DEVHOT double lik_compute(int useOld)
   (void)q_terms;
   STAMPB_BEGIN(2);
   const bool isnode = lane < N;
-  const int le = isnode ? (int)gph_lds.left[lane] : -1;
-  const int ri = isnode ? (int)gph_lds.right[lane] : -1;
-  const double ag = isnode ? gph_lds.age[lane] : 0.0;
+  GphNode me = {0.0, -1, -1, -1, -1};
+  if (isnode) me = gph_lds.nd[lane];    /* the lane's node record: one 16-byte read */
+  const int le = me.left, ri = me.right;
+  const double ag = me.age;
   uint64_t dirty = __ballot(isnode && gph_lds.dirty[lane] != 0);
   uint64_t cbit = __ballot(isnode && gph_lds.condbit[lane] != 0);
   const uint64_t internal = (((uint64_t)1 << N) - 1) & ~(((uint64_t)1 << n) - 1);
@@ -587,8 +607,8 @@ GPH_DEVHOT double lik_compute(int useOld)
    * edge below a node that is recomputed: one lane per child node, all edges in ONE vector exp */
   double pe = 0.0;
   {
-    const int fa = isnode ? (int)gph_lds.father[lane] : -1;
-    if (fa >= 0 && ((todo >> fa) & 1)) pe = edge_prob_v(mut * (gph_lds.age[fa] - ag));
+    const int fa = me.father;
+    if (fa >= 0 && ((todo >> fa) & 1)) pe = edge_prob_v(mut * (gph_lds.nd[fa].age - ag));
   }
   const bool wide = P > GPH_WAVE;   /* more than one pattern per lane: generic (pattern, base) mapping */
   double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
@@ -867,8 +887,8 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
     const int lane = GPH_LANE;
     bool in = false;
     if (lane < g_lay.N && lane != exc) {
-      f = gph_lds.father[lane];
-      in = !(gph_lds.age[lane] > time) && !(f >= 0 && gph_lds.age[f] <= time);
+      f = gph_lds.nd[lane].father;
+      in = !(gph_lds.nd[lane].age > time) && !(f >= 0 && gph_lds.nd[f].age <= time);
       if (in && pop != g_lay.rootPop) {
         /* findLastMig(node = lane, time), patch.c:374-391 */
         int last = -1, nm = ISC(IS_NUM_MIGS);
@@ -877,7 +897,7 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
           if (MG(mig, MG_BRANCH) != lane) continue;
           if ((time < 0 || MAGE(mig) < time) && (last < 0 || MAGE(mig) > MAGE(last))) last = mig;
         }
-        pop1 = (last >= 0) ? (int)gph_lds.mig_i[last * MG_COUNT + MG_SPOP] : (int)gph_lds.npop[lane];
+        pop1 = (last >= 0) ? (int)gph_lds.mig_i[last * MG_COUNT + MG_SPOP] : (int)gph_lds.nd[lane].npop;
         in = ((g_model.isAnc[pop] >> pop1) & 1) != 0;
       }
     }

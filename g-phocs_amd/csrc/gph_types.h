@@ -50,9 +50,10 @@ struct GphLayout {
   int32_t n, N, K, Kc, B, E, RB, rootPop;
   // f64
   int32_t o_ev;            // event records (GphEv[E])
-  int32_t o_age, o_sv_age, o_mig_age, o_coal, o_migst, o_rb_age, o_fscal;
+  int32_t o_nd, o_sv;      // node records (GphNode[N]) and their saved copies
+  int32_t o_mig_age, o_coal, o_migst, o_rb_age, o_fscal;
   // i16
-  int32_t o_father, o_left, o_right, o_npop, o_nev, o_sv_father, o_sv_left, o_sv_right;
+  int32_t o_nev;
   int32_t o_changed, o_changedc;
   int32_t o_first;
   int32_t o_mig_i, o_living, o_ncoal, o_nmig, o_rb_i;
@@ -136,14 +137,22 @@ struct alignas(16) GphEv {
   uint8_t type;           // EventType
 };
 
+// One genealogy node = one 16-byte record (GenericBinaryTree / LikelihoodNode, LocusDataLikelihood.c:40-104);
+// the saved copy (savedVersion) is the same record, so saving a node is one 16-byte LDS copy.
+struct alignas(16) GphNode {
+  double age;
+  int16_t father, left, right;
+  int16_t npop;           // nodePops[gen][node] (unused in the saved copy)
+};
+
 struct alignas(16) GphLds {
   // ---- page (mirrors the HBM page arrays, GphLayout o_*)
   GphEv ev[GPH_CAP_E];
-  double age[GPH_CAP_N], sv_age[GPH_CAP_N], mig_age[GPH_MAX_MIGS];
+  GphNode nd[GPH_CAP_N], sv[GPH_CAP_N];
+  double mig_age[GPH_MAX_MIGS];
   double coal[GPH_CAP_K], migst[GPH_CAP_B], rb_age[GPH_CAP_RB], fscal[FS_COUNT_];
   int32_t iscal[IS_COUNT_];
-  int16_t father[GPH_CAP_N], left[GPH_CAP_N], right[GPH_CAP_N], npop[GPH_CAP_N], nev[GPH_CAP_N];
-  int16_t sv_father[GPH_CAP_N], sv_left[GPH_CAP_N], sv_right[GPH_CAP_N];
+  int16_t nev[GPH_CAP_N];
   int16_t changed[2 * GPH_CAP_N], changedc[2 * GPH_CAP_N];
   int16_t first[GPH_CAP_K];
   int16_t mig_i[GPH_MAX_MIGS * 6], living[GPH_MAX_MIGS], ncoal[GPH_CAP_K], nmig[GPH_CAP_B], rb_i[3 * GPH_CAP_RB];
