@@ -350,12 +350,21 @@ GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
         setNCOAL(fpn, NCOAL(fpn) + 1);
       }
       replace_mig_nodes(node);
+#ifdef GPH_HOSTEMU
       for (i = 0; i < DI(1, DI_NEV); ++i) {
         ev = DEV(1, i);
         setENLIN(ev, ENLIN(ev) + 1);
       }
       for (b = 0; b < g_lay.B; ++b) setMIGST(b, MIGST(b) + (DMIG(1, b) - DMIG(0, b)));
       for (pop = 0; pop < g_lay.K; pop++) setCOALS(pop, COALS(pop) + (DCOAL(1, pop) - DCOAL(0, pop)));
+#else
+      {   /* one lane per list entry / band / population (entries are distinct) */
+        const int lane = GPH_LANE;
+        for (int k = lane; k < DI(1, DI_NEV); k += GPH_NLANES) { const int q = gph_lds.s_dev[1][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + 1); }
+        if (lane < g_lay.B) gph_lds.migst[lane] = gph_lds.migst[lane] + (gph_lds.s_dmig[1][lane] - gph_lds.s_dmig[0][lane]);
+        if (lane < g_lay.K) gph_lds.coal[lane] = gph_lds.coal[lane] + (gph_lds.s_dcoal[1][lane] - gph_lds.s_dcoal[0][lane]);
+      }
+#endif
       lik_reset_saved();
     } else {
       if (res >= 0) remove_event(SPRI(SI_FEV_NEW));
@@ -363,10 +372,14 @@ GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
         remove_event(SPRA(SA_NEWIN, i));
         remove_event(SPRA(SA_NEWOUT, i));
       }
+#ifdef GPH_HOSTEMU
       for (i = 0; i < DI(0, DI_NEV); ++i) {
         ev = DEV(0, i);
         setENLIN(ev, ENLIN(ev) + 1);
       }
+#else
+      for (int k = GPH_LANE; k < DI(0, DI_NEV); k += GPH_NLANES) { const int q = gph_lds.s_dev[0][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + 1); }
+#endif
       lik_revert();
     }
   }

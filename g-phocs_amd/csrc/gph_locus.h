@@ -1234,6 +1234,7 @@ GPH_DEV void delta_clear(int inst)
 GPH_DEV void accept_event_chain_changes(int inst)
 {
   int i, pop, b, ue, oe, dlin = DI(inst, DI_DLIN);
+#ifdef GPH_HOSTEMU
   for (i = 0; i < DI(inst, DI_NPOPS); i++) {
     pop = DPOPS(inst, i);
     setCOALS(pop, COALS(pop) + DCOAL(inst, i));
@@ -1246,6 +1247,19 @@ GPH_DEV void accept_event_chain_changes(int inst)
   i = DI(inst, DI_NEV) - 1;
   if (i >= 0 && DEV(inst, i) == oe) i--;
   for (; i >= 0; i--) setENLIN(DEV(inst, i), ENLIN(DEV(inst, i)) + dlin);
+#else
+  /* the listed populations / bands / events are distinct: one lane per list entry */
+  (void)pop; (void)b;
+  {
+    const int lane = GPH_LANE;
+    if (lane < DI(inst, DI_NPOPS)) { const int q = gph_lds.s_dpops[inst][lane]; gph_lds.coal[q] = gph_lds.coal[q] + gph_lds.s_dcoal[inst][lane]; }
+    if (lane < DI(inst, DI_NBANDS)) { const int q = gph_lds.s_dbands[inst][lane]; gph_lds.migst[q] = gph_lds.migst[q] + gph_lds.s_dmig[inst][lane]; }
+    oe = DI(inst, DI_ORIG);
+    i = DI(inst, DI_NEV) - 1;
+    if (i >= 0 && DEV(inst, i) == oe) i--;
+    for (int k = lane; k <= i; k += GPH_NLANES) { const int q = gph_lds.s_dev[inst][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + dlin); }
+  }
+#endif
   ue = DI(inst, DI_UPD);
   if (ue >= 0) {
     setENODE(ue, ENODE(oe));
