@@ -188,8 +188,6 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   y.RB = GPH_MAX_MIGS + 2 * B;
   // the HBM page IS the page part of the static LDS image (GphLds, capacity-sized arrays):
   // staging is one fully coalesced 16-B/lane copy
-  int o = 0;
-  auto f64 = [&](int cnt) { o = align_up(o, 8); int r = o; o += 8 * cnt; return r; };
 #define OFS(f) ((int32_t)offsetof(GphLds, f))
   y.o_ev = OFS(ev); y.o_nd = OFS(nd); y.o_sv = OFS(sv); y.o_mig_age = OFS(mig_age);
   y.o_coal = OFS(coal); y.o_migst = OFS(migst); y.o_rb_age = OFS(rb_age); y.o_fscal = OFS(fscal);
@@ -201,16 +199,10 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   y.o_condbit = OFS(condbit); y.o_dirty = OFS(dirty);
   y.page_bytes = align_up(OFS(s_dcoal), 16);
 #undef OFS
-  // dynamic LDS: sequence block (also the HBM block format) + per-pattern terms of the root
-  // reduction; the locus image itself is the static GphLds
-  o = 0;
-  y.o_scratch = 0;
-  y.scratch_bytes = (int)sizeof(GphLds);
-  // (the block is laid out by the locus' own P: GPH_Q_* in gph_types.h; nothing P-dependent here)
-  y.o_seq = 0;
+  // dynamic LDS: the locus' sequence block (same bytes as its HBM block, laid out by its own P: GPH_Q_* in
+  // gph_types.h) + per-pattern terms of the root reduction for loci with more than one pattern per lane
   y.Pmax = Pmax;
   y.lds_bytes = GPH_Q_TERMS(Pmax, n) + (Pmax > GPH_WAVE ? 8 * Pmax : 0);
-  (void)f64;
 }
 
 static void build_model_static(gph_engine *e)

@@ -326,6 +326,7 @@ GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
     lnacc = lnLd;
     if (gph_failed()) break;
     if (res >= 0 && (UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc)))) {
+      STAMPC_BEGIN(2);
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + (SPRLN(1) - SPRLN(0)));
       dData += lnLd;
@@ -366,7 +367,9 @@ GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
       }
 #endif
       lik_reset_saved();
+      STAMPC_END(2);
     } else {
+      STAMPC_BEGIN(3);
       if (res >= 0) remove_event(SPRI(SI_FEV_NEW));
       for (i = 0; i < SPRI(SI_NNEW); i++) {
         remove_event(SPRA(SA_NEWIN, i));
@@ -381,6 +384,7 @@ GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
       for (int k = GPH_LANE; k < DI(0, DI_NEV); k += GPH_NLANES) { const int q = gph_lds.s_dev[0][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + 1); }
 #endif
       lik_revert();
+      STAMPC_END(3);
     }
   }
   OUT(g, 2, acc);
@@ -400,7 +404,7 @@ GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double f
   OUT(g, 0, 0.0); OUT(g, 1, 0.0); OUT(g, 2, 0.0); OUT(g, 3, 0.0); OUT(g, 4, 0.0);
   OUT(g, 5, 0.0); OUT(g, 6, 0.0); OUT(g, 7, 0.0); OUT(g, 12, 0.0);
   { STAMP_BEGIN(5); if ((flags & 1) && ftCoal > 0.0) sweep_internal(D, g, ftCoal, rng); STAMP_END(5); }
-  if ((flags & 2) && ftMig > 0.0 && !gph_failed()) sweep_mignodes(D, g, ftMig, rng);
+  { STAMPC_BEGIN(4); if ((flags & 2) && ftMig > 0.0 && !gph_failed()) sweep_mignodes(D, g, ftMig, rng); STAMPC_END(4); }
   { STAMP_BEGIN(6); if ((flags & 4) && !gph_failed()) sweep_spr(D, g, rng); STAMP_END(6); }
   rng_store(rng);
   out_common(D, g);

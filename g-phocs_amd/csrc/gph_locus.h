@@ -167,17 +167,29 @@ GPH_DEVHOT GphEvS ld_ev(int ev)
 #define STAMP_BEGIN(k) ((void)0)
 #define STAMP_END(k) ((void)0)
 #endif
-// -DGPH_STAMPS=2: slots 2/3/4 attribute lik_compute's own phases instead of the chain functions
+// -DGPH_STAMPS=2: slots 2/3/4 attribute lik_compute's own phases instead of the chain functions;
+// -DGPH_STAMPS=3: slots 2/3/4 = SPR accept path, SPR reject path, migration-node sweep
 #if defined(GPH_STAMPS) && GPH_STAMPS == 2 && !defined(GPH_HOSTEMU)
 #define STAMPA_BEGIN(k) ((void)0)
 #define STAMPA_END(k) ((void)0)
 #define STAMPB_BEGIN(k) STAMP_BEGIN(k)
 #define STAMPB_END(k) STAMP_END(k)
+#define STAMPC_BEGIN(k) ((void)0)
+#define STAMPC_END(k) ((void)0)
+#elif defined(GPH_STAMPS) && GPH_STAMPS == 3 && !defined(GPH_HOSTEMU)
+#define STAMPA_BEGIN(k) ((void)0)
+#define STAMPA_END(k) ((void)0)
+#define STAMPB_BEGIN(k) ((void)0)
+#define STAMPB_END(k) ((void)0)
+#define STAMPC_BEGIN(k) STAMP_BEGIN(k)
+#define STAMPC_END(k) STAMP_END(k)
 #else
 #define STAMPA_BEGIN(k) STAMP_BEGIN(k)
 #define STAMPA_END(k) STAMP_END(k)
 #define STAMPB_BEGIN(k) ((void)0)
 #define STAMPB_END(k) ((void)0)
+#define STAMPC_BEGIN(k) ((void)0)
+#define STAMPC_END(k) ((void)0)
 #endif
 GPH_DEV void gph_fail(int code) { if (CNT(CN_ERROR) == 0) setCNT(CN_ERROR, code); }
 GPH_DEV int gph_failed() { return CNT(CN_ERROR) != 0; }

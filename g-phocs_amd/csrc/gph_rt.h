@@ -107,7 +107,7 @@ template <class T, int NN> GPH_DEV double gf64(T (GphLds::*m)[2][NN], int k, int
 template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[2][NN], int k, int i, double v) { (gph_lds.*m)[k][i] = v; }
 template <class T, int NN> GPH_DEV int gi16(T (GphLds::*m)[2][NN], int k, int i) { return RFL((gph_lds.*m)[k][i]); }
 template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[2][NN], int k, int i, int v) { (gph_lds.*m)[k][i] = (T)v; }
-// dynamic-part accessors (byte offset from g_lay.q_* / g_lay.s_terms): lane-varying, pruning only
+// dynamic-part accessors (byte offset GPH_Q_* of the locus' sequence block): lane-varying, pruning only
 GPH_DEV double gf64(int off, int i) { return ((lf64 *)(GPH_SMB + off))[i]; }
 GPH_DEV void sf64(int off, int i, double v) { ((lf64 *)(GPH_SMB + off))[i] = v; }
 GPH_DEV int gi16(int off, int i) { return RFL(((li16 *)(GPH_SMB + off))[i]); }

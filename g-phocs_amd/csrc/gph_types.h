@@ -45,7 +45,8 @@ struct GphModel {
   int32_t cumSamples[GPH_MAXK];
 };
 
-// byte offsets of every array inside a locus page (uniform over loci)
+// dimensions + byte offsets of the page arrays inside GphLds (uniform over loci; used by the small
+// per-locus-thread kernels and the host-side dump, everything else addresses GphLds members directly)
 struct GphLayout {
   int32_t n, N, K, Kc, B, E, RB, rootPop;
   // f64
@@ -61,21 +62,9 @@ struct GphLayout {
   int32_t o_iscal;
   // u8
   int32_t o_condbit, o_dirty;
-  int32_t page_bytes;      // multiple of 16
-  int32_t scratch_bytes;   // LDS-only per-wave scratch (pending-proposal storage)
+  int32_t page_bytes;      // multiple of 16: the page part of GphLds
   int32_t Pmax;            // max phased patterns of any locus on this device
-  int32_t lds_bytes;       // page + scratch + cond + seq, multiple of 16
-  int32_t o_scratch, o_cond, o_seq;  // LDS offsets
-  // LDS-only scratch (absolute LDS byte offsets): pending-proposal storage of
-  // GENETREE_STATS_DELTA x2 (patch.h:60-72), MIG_SPR_STATS (patch.h:97-105),
-  // genetree_stats_check (patch.h:109), pruning work lists
-  int32_t s_dev[2], s_dcoal[2], s_dmig[2], s_dpops[2], s_dbands[2], s_di[2];
-  int32_t s_sprf, s_spri16, s_spri;
-  int32_t s_ord, s_stack, s_terms, s_targets;
-  int32_t s_chkcoal, s_chkmig, s_chknc, s_chknm;
-  int32_t s_cnt, s_cntf;
-  // seq region (absolute LDS byte offsets): leaf codes u8[P][n], phases u8[P], counts i32[P]
-  int32_t q_leaf, q_phases, q_count;
+  int32_t lds_bytes;       // largest dynamic-LDS allocation of a launch (sequence block [+ terms])
 };
 // Sequence block of one locus (HBM block format == dynamic-LDS image), sized by the locus' OWN number of
 // phased patterns P: leaf codes u8[P][n] | phases u8[P] | (pad to 4) counts i32[P] | (pad to 16);

@@ -6,7 +6,7 @@ sys.path.insert(0, REPO)
 import gphocs_amd as G
 import bench
 # built where hipcc is cheap (the build container) into bench_cache/, which travels to the GPU box
-MODE = 2 if "--lik" in sys.argv else 1
+MODE = 2 if "--lik" in sys.argv else 3 if "--spr" in sys.argv else 1
 lib_path = os.path.join(REPO, "bench_cache", f"libgphocs_stamps{MODE}.so")
 os.makedirs(os.path.dirname(lib_path), exist_ok=True)
 srcs = [os.path.join(G.CSRC, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp")]
@@ -28,6 +28,8 @@ lib.gph_engine_genealogy_sweep(s.engine, 7, pack.ftCoalTime, pack.ftMigTime, C.b
 # in the stamps build the sweep result fields carry cycle sums (see kb_sweep)
 names = ["kernel body", "lik_compute", "consider_event_move", "trace_lineage<0>", "trace_lineage<1>",
          "internal sweep", "spr sweep", "prune_node (inside lik_compute)"]
+if MODE == 3:
+    names[2:5] = ["SPR accept path", "SPR reject path", "migration-node sweep"]
 if MODE == 2:
     names[2:5] = ["lik_compute: setup (tree regs, need fix-point, fence)", "lik_compute: write-back of masks",
                   "lik_compute: root reduction (log)"]
