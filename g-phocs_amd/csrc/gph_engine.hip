@@ -398,7 +398,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   if (!e || L <= 0 || !poff || !leafcodes || !numPhases || !counts) return GPH_EARG;
   const int n = e->cfg.n;
   int Pmax = 1;
-  for (int64_t g = 0; g < L; g++) { int P = (int)(poff[g + 1] - poff[g]); if (P > Pmax) Pmax = P; if (P < 1) return GPH_EARG; }
+  for (int64_t g = 0; g < L; g++) { int P = (int)(poff[g + 1] - poff[g]); if (P > Pmax) Pmax = P; if (P < 0) return GPH_EARG; }   /* P == 0: a locus with no informative column (all N) is legal upstream */
   build_layout(e->lay, n, e->cfg.Kc, e->cfg.K, e->cfg.B, e->cfg.rootPop, Pmax);
   if (e->lay.lds_bytes + (int)sizeof(GphLds) > 160 * 1024) {
     fprintf(stderr, "gphocs_hip: a locus with %d phased patterns needs %d bytes of LDS (> 160 KiB)\n", Pmax, e->lay.lds_bytes);

@@ -39,3 +39,8 @@ for name in g1 m3 a7; do timeout 900 $REF main -n 1 $name.ctl >/dev/null 2>&1; d
 python3 make_stress.py
 timeout 600 $REF pack stress.ctl stress.gpk >/dev/null
 ls -la
+# z0: g1 with locus 3 all-N (a locus with zero informative columns is legal upstream: P = 0)
+# (z0.ctl / z0.seq are derived from g1 by hand: sequences of locus3 replaced by N, file names changed)
+timeout 600 $REF pack z0.ctl z0.gpk >/dev/null
+timeout 600 $REF run z0.ctl 0 z0.init.rtrace z0.init.state -1 1 >/dev/null; rm -f z0.init.rtrace
+timeout 600 $REF run z0.ctl 12 z0.rtrace z0.state 11 1 >/dev/null

@@ -1,0 +1,89 @@
+GENERAL-INFO-START
+
+	seq-file            z0.seq
+	trace-file          z0.trace
+	locus-mut-rate          CONST
+	num-loci            24
+	random-seed         12345
+	mcmc-iterations	  30
+	iterations-per-log  10
+	logs-per-line       10
+
+	find-finetunes		FALSE
+	finetune-coal-time	0.01		
+	finetune-mig-time	0.3		
+	finetune-theta		0.04
+	finetune-mig-rate	0.02
+	finetune-tau		0.0000008
+	finetune-mixing		0.003
+
+	tau-theta-print		10000.0
+	tau-theta-alpha		1.0
+	tau-theta-beta		10000.0
+
+	mig-rate-print		0.001
+	mig-rate-alpha		0.002
+	mig-rate-beta		0.0000100000
+
+GENERAL-INFO-END
+
+CURRENT-POPS-START	
+
+	POP-START
+		name		A
+		samples		s0 d
+	POP-END
+
+	POP-START
+		name		B
+		samples		s1 d
+	POP-END
+
+	POP-START
+		name		C
+		samples		s2 d
+	POP-END
+
+	POP-START
+		name		D
+		samples		s3 d
+	POP-END
+
+CURRENT-POPS-END
+
+ANCESTRAL-POPS-START
+
+	POP-START
+		name			AB
+		children		A		B
+		tau-initial	0.000005000
+		tau-beta		20000.0	
+		finetune-tau			0.00000080
+	POP-END
+
+	POP-START
+		name			ABC
+		children		AB		C
+		tau-initial	0.000010000
+		tau-beta		20000.0	
+		finetune-tau			0.00000080
+	POP-END
+
+	POP-START
+		name			root
+		children		ABC		D
+		tau-initial	0.000050000
+		tau-beta		20000.0	
+		finetune-tau			0.00000286
+	POP-END
+
+ANCESTRAL-POPS-END
+
+MIG-BANDS-START	
+	BAND-START		
+       source  D
+       target  B
+       mig-rate-print 0.1
+	BAND-END
+
+MIG-BANDS-END

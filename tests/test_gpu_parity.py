@@ -14,7 +14,7 @@ from parity_util import compare_records, compare_states
 
 pytestmark = pytest.mark.gpu
 
-CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, "a7": 100}
+CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, "a7": 100, "z0": 12}
 
 
 @pytest.fixture(scope="module")
