@@ -504,7 +504,7 @@ int gph_engine_set_model(gph_engine *e, const double *theta, const double *popAg
                          const double *migRate, const double *bandStart, const double *bandEnd)
 {
   if (!e || !theta || !popAge || !sampleAge) return GPH_EARG;
-  for (int p = 0; p < e->cfg.K; p++) { e->model.theta[p] = theta[p]; e->model.popAge[p] = popAge[p]; e->model.sampleAge[p] = sampleAge[p]; }
+  for (int p = 0; p < e->cfg.K; p++) { e->model.theta[p] = theta[p]; e->model.thetaInv[p] = 1.0 / theta[p]; e->model.popAge[p] = popAge[p]; e->model.sampleAge[p] = sampleAge[p]; }
   for (int b = 0; b < e->cfg.B; b++) { e->model.migRate[b] = migRate[b]; e->model.bandStart[b] = bandStart[b]; e->model.bandEnd[b] = bandEnd[b]; }
   e->model_set = true;
   return 0;

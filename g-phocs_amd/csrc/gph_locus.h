@@ -106,7 +106,15 @@ struct LiveList {
 GPH_DEV int ll_get(const LiveList &l, int i) { return (int)((l.bits >> (4 * i)) & 15); }
 GPH_DEV void ll_set(LiveList &l, int i, int v) { l.bits = (l.bits & ~((uint64_t)15 << (4 * i))) | ((uint64_t)v << (4 * i)); }
 GPH_DEV void ll_push(LiveList &l, int v) { ll_set(l, l.n, v); l.n++; }
-GPH_DEV int ll_find(const LiveList &l, int v) { int i; for (i = 0; i < l.n; i++) if (ll_get(l, i) == v) break; return i; }
+// first index i < n whose nibble equals v, else n -- branch-free (zero-nibble test; the lowest hit is exact;
+// checked against the loop on 2e8 random lists, tools/verify_llfind.c)
+GPH_DEV int ll_find(const LiveList &l, int v)
+{
+  const uint64_t x = l.bits ^ (0x1111111111111111ull * (uint64_t)v);
+  uint64_t t = (x - 0x1111111111111111ull) & ~x & 0x8888888888888888ull;
+  if (l.n < 16) t &= (((uint64_t)1 << (4 * l.n)) - 1);
+  return t ? (int)(__builtin_ctzll(t) >> 2) : l.n;
+}
 GPH_DEV void ll_swap_remove(LiveList &l, int i) { l.n--; ll_set(l, i, ll_get(l, l.n)); }
 
 // every field of one genealogy node with ONE LDS access
@@ -193,6 +201,31 @@ GPH_DEVHOT GphEvS ld_ev(int ev)
 #endif
 GPH_DEV void gph_fail(int code) { if (CNT(CN_ERROR) == 0) setCNT(CN_ERROR, code); }
 GPH_DEV int gph_failed() { return CNT(CN_ERROR) != 0; }
+
+// IEEE-exact quotients a / theta[pop] and a / 3 without the ~12-instruction divide expansion: with
+// y = RN(1/b) (computed by a true division, on the host for theta), q0 = a*y, r = fma(-q0, b, a) (exact),
+// q = fma(r, y, q0) is the correctly rounded a/b (Markstein); tools/verify_fma_div*.c compare it with the
+// hardware division on 1.4e9 operands, all-ones significands of b included.  The host form divides.
+GPH_DEV double gph_div_theta(double a, int pop)
+{
+#ifdef GPH_HOSTEMU
+  return a / g_model.theta[pop];
+#else
+  const double b = g_model.theta[pop], y = g_model.thetaInv[pop];
+  const double q0 = a * y;
+  return __builtin_fma(__builtin_fma(-q0, b, a), y, q0);
+#endif
+}
+GPH_DEV double gph_div3(double a)
+{
+#ifdef GPH_HOSTEMU
+  return a / 3.0;
+#else
+  const double y = 1.0 / 3.0;
+  const double q0 = a * y;
+  return __builtin_fma(__builtin_fma(-q0, 3.0, a), y, q0);
+#endif
+}
 
 // ---------------------------------------------------------------- RNG
 // rndu, utils.c:498-513: unsigned 32-bit Wichmann-Hill without the sign fix-up
@@ -372,7 +405,7 @@ GPH_DEV double edge_prob(double len)
 GPH_DEV double edge_prob_v(double len)
 {
   if (len < 1e-100) return 0.0;
-  return ((1 - gph_exp(-4 * len / 3.0)) / 4.0);
+  return ((1 - gph_exp(gph_div3(-4 * len))) / 4.0);
 }
 
 // The fp64 conditional arrays [2][n-1][P][4] of the locus stay in global memory: they are
@@ -1048,7 +1081,7 @@ GPH_DEVHOT double recalc_stats(int pop)
     }
   }
   if (live.n != 0) { gph_fail(27); return 0.0; }
-  delta -= (cs - COALS(pop)) / (g_model.theta[pop]);
+  delta -= gph_div_theta(cs - COALS(pop), pop);
   setCOALS(pop, cs);
   setNCOAL(pop, nc);
   return delta;
@@ -1195,7 +1228,7 @@ GPH_DEV double delta_lnld(int inst)
 {
   int i, np = DI(inst, DI_NPOPS), nb = DI(inst, DI_NBANDS);
   double r = 0;
-  for (i = 0; i < np; i++) r -= DCOAL(inst, i) / g_model.theta[DPOPS(inst, i)];
+  for (i = 0; i < np; i++) r -= gph_div_theta(DCOAL(inst, i), DPOPS(inst, i));
   for (i = 0; i < nb; i++) r -= DMIG(inst, i) * g_model.migRate[DBANDS(inst, i)];
   return r;
 }
@@ -1502,7 +1535,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
         }
       }
     } else {
-      rate = mig_rate + 2 * nlin / theta;
+      rate = mig_rate + gph_div_theta(2 * nlin, pop);
       if (UNI(rate <= 0)) t = et;
       else t = -(1 / rate) * gph_log_u(l_rndu(rng));
       if (UNI(t >= et)) {
@@ -1554,7 +1587,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
     nev++;
     /* RECONNECT: the interval's rate was just computed (a split interval keeps its lineage count) */
     if (RECONNECT) lnld -= rate * t;
-    else lnld -= (mig_rate + 2 * nlin / theta) * t;
+    else lnld -= (mig_rate + gph_div_theta(2 * nlin, pop)) * t;
     if (mig_source >= 0) {
       lnld += gph_log_u(g_model.migRate[b]);
       ev = mig_source;

@@ -37,6 +37,7 @@ enum { GPH_COAL = 0, GPH_IN_MIG, GPH_OUT_MIG, GPH_MIG_BAND_START, GPH_MIG_BAND_E
 // that every access is a scalar (SGPR) load from the kernarg segment.
 struct GphModel {
   double theta[GPH_MAXK], popAge[GPH_MAXK], sampleAge[GPH_MAXK];
+  double thetaInv[GPH_MAXK];           // RN(1/theta), host division: see gph_div_theta()
   double migRate[GPH_MAXB], bandStart[GPH_MAXB], bandEnd[GPH_MAXB];
   uint32_t isAnc[GPH_MAXK];            // bit d of isAnc[a]: a is ancestral to (or is) d
   int16_t popFather[GPH_MAXK], popSon0[GPH_MAXK], popSon1[GPH_MAXK], samplesPerPop[GPH_MAXK];
