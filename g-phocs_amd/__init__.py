@@ -111,7 +111,8 @@ class GphControlInfo(C.Structure):
     _fields_ = [("seqFile", C.c_char_p), ("traceFile", C.c_char_p), ("rateFile", C.c_char_p),
                 ("numLoci", C.c_int32), ("burnin", C.c_int32), ("numSamples", C.c_int32),
                 ("sampleSkip", C.c_int32), ("logsPerLine", C.c_int32), ("mutRateMode", C.c_int32),
-                ("findFinetunes", C.c_int32), ("numSampleSlots", C.c_int32),
+                ("findFinetunes", C.c_int32), ("findFinetunesNumSteps", C.c_int32),
+                ("findFinetunesSamplesPerStep", C.c_int32), ("numSampleSlots", C.c_int32),
                 ("varRatesAlpha", C.c_double), ("ftLocusRate", C.c_double)]
 
 
@@ -129,7 +130,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_engine_num_loci", "gph_engine_hbm_bytes", "gph_debug_math", "gph_engine_class_stats",
     "gph_mcmc_create", "gph_mcmc_destroy", "gph_mcmc_initialize", "gph_mcmc_set_record_file",
     "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
-    "gph_mcmc_param_vals", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
+    "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
     "gph_control_sample_name", "gph_loci_read", "gph_loci_free", "gph_loci_arrays", "gph_run_control_file",
 ]
 
@@ -177,6 +178,9 @@ def _load_library(path):
     lib.gph_engine_get_counters.argtypes = [C.c_void_p, C.POINTER(GphCounters), C.c_int32]
     lib.gph_engine_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
     lib.gph_mcmc_param_vals.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.gph_mcmc_tau_accept_counts.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gph_mcmc_set_finetunes.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                           C.c_void_p]
     lib.gph_control_read.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
     lib.gph_control_free.argtypes = [C.c_void_p]
     lib.gph_control_free.restype = None

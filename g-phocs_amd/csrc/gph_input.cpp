@@ -894,7 +894,8 @@ int gph_control_get(const gph_control *c, gph_config *cfg, gph_mcmc_config *mc, 
     info->seqFile = c->seqFile.c_str(); info->traceFile = c->traceFile.c_str(); info->rateFile = c->rateFile.c_str();
     info->numLoci = c->numLoci; info->burnin = c->burnin; info->numSamples = c->numSamples;
     info->sampleSkip = c->sampleSkip; info->logsPerLine = c->logsPerLine; info->mutRateMode = c->mutRateMode;
-    info->findFinetunes = c->findFinetunes; info->numSampleSlots = (int32_t)c->sampleNames.size();
+    info->findFinetunes = c->findFinetunes; info->findFinetunesNumSteps = c->ffSteps;
+    info->findFinetunesSamplesPerStep = c->ffSamples; info->numSampleSlots = (int32_t)c->sampleNames.size();
     info->varRatesAlpha = c->varRatesAlpha; info->ftLocusRate = c->ftLocusRate;
   }
   return GPH_OK;

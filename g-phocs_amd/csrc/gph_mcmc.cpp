@@ -35,6 +35,7 @@ struct gph_mcmc {
   std::vector<double> tot_coal, tot_ncoal, tot_mig, tot_nmig;
   int64_t rubberband_conflicts;
   int64_t acc[9];               // coalTime, migTime, SPR, theta, migRate, taus(sum), mixing, totalMigNodes, -
+  std::vector<int64_t> accTau;  // per population: accepted UpdateTau / UpdateSampleAge proposals
   FILE *rec;
 };
 
@@ -473,6 +474,7 @@ int gph_mcmc_create(gph_engine *e, const gph_config *cfg, const gph_mcmc_config 
   m->logLikelihood = m->dataLogLikelihood = 0.0;
   m->rubberband_conflicts = 0;
   memset(m->acc, 0, sizeof m->acc);
+  m->accTau.assign(m->K, 0);
   m->rec = nullptr;
   *out = m;
   return 0;
@@ -541,9 +543,9 @@ int gph_mcmc_iteration(gph_mcmc *m, int32_t iteration)
     rec_line(m, iteration, "MIGR", acc);
   }
   if ((rc = update_tau(m, iteration, accArr.data()))) return rc;
-  for (int pop = m->Kc; pop < m->K; pop++) m->acc[5] += accArr[pop];
+  for (int pop = m->Kc; pop < m->K; pop++) { m->acc[5] += accArr[pop]; m->accTau[pop] += accArr[pop]; }
   if ((rc = update_sample_age(m, iteration, accArr.data()))) return rc;
-  for (int pop = 0; pop < m->Kc; pop++) m->acc[5] += accArr[pop];
+  for (int pop = 0; pop < m->Kc; pop++) { m->acc[5] += accArr[pop]; m->accTau[pop] += accArr[pop]; }
   if (m->doMixing) {
     if ((rc = refresh_totals(m))) return rc;
     if ((rc = mixing(m, m->ftMixing, &acc))) return rc;
@@ -630,6 +632,29 @@ int gph_mcmc_param_vals(gph_mcmc *m, double *vals, int32_t n)
 {
   if (!m || !vals) return GPH_EARG;
   for (int i = 0; i < n && i < (int)m->paramVals.size(); i++) vals[i] = m->paramVals[i];
+  return 0;
+}
+
+int gph_mcmc_tau_accept_counts(gph_mcmc *m, int64_t *perPop)
+{
+  if (!m || !perPop) return GPH_EARG;
+  for (int p = 0; p < m->K; p++) perPop[p] = m->accTau[p];
+  return 0;
+}
+
+int gph_mcmc_set_finetunes(gph_mcmc *m, double coalTime, double migTime, double theta, double migRate, double mixing,
+                           const double *taus)
+{
+  if (!m) return GPH_EARG;
+  m->ftCoalTime = coalTime; m->ftMigTime = migTime; m->ftTheta = theta; m->ftMigRate = migRate; m->ftMixing = mixing;
+  if (taus) for (int p = 0; p < m->K; p++) m->ftTaus[p] = taus[p];
+  return 0;
+}
+
+int gph_mcmc_set_log_period(gph_mcmc *m, int32_t iterations)
+{
+  if (!m || iterations <= 0) return GPH_EARG;
+  m->samplesPerLog = iterations;
   return 0;
 }
 

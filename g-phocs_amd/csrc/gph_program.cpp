@@ -10,6 +10,29 @@
 #include <string>
 #include <vector>
 
+namespace {
+// one step of the find-finetunes search for one step size (GPhoCS.c:1896-2180, the same block per proposal
+// type): bisection on [min, max] towards 35 % +- 5 % acceptance
+struct Finetune {
+  double v, lo = 0.0, hi = 10.0;   /* finetuneMins / finetuneMaxes, MAX_FINETUNE = 10 (GPhoCS.h:21-24) */
+  void adjust(double pct)
+  {
+    const double TARGET = 35, RANGE = 5, RES = 0.0000001, MAXF = 10;
+    if (pct > TARGET + RANGE) {
+      lo = v;
+      if (hi - lo < RES) {
+        if (hi >= MAXF) hi = lo = MAXF;
+        else hi *= 2.0;
+      }
+    } else if (pct < TARGET - RANGE) {
+      hi = v;
+      if (hi - lo < RES) lo /= 2.0;
+    }
+    v = 0.5 * (hi + lo);
+  }
+};
+}   // namespace
+
 extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t device, int32_t verbose)
 {
   gph_control *C = nullptr;
@@ -35,7 +58,6 @@ extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t d
   if ((rc = gph_control_read(ctl, ctl2, &C))) return fail(rc, "reading the control file");
   gph_control_get(C, &cfg, &mc, &info);
   printf("Done.\n");
-  if (info.findFinetunes) return fail(GPH_EARG, "find-finetunes TRUE (not supported by the engine driver; give explicit finetunes)");
   if (info.mutRateMode == 1) return fail(GPH_EARG, "locus-mut-rate VAR (UpdateLocusRate is serial over loci upstream and not offloaded)");
   if (mc.seed < 0) mc.seed = abs(2 * (int)time(NULL) + 1);   /* GPhoCS.c:188-191 */
   if (verbose) printf("\nRandom seed set to %d\n", mc.seed);
@@ -78,6 +100,28 @@ extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t d
   std::vector<double> vals(mc.numParameters + 4, 0.0);
   double logL = 0, dataL = 0;
   auto t1 = std::chrono::steady_clock::now();
+  // log periods and the find-finetunes search, GPhoCS.c:1401-1447, 1808-2249
+  int samplesPerLog = mc.samplesPerLog, findingFinetunes = 0;
+  Finetune fCoal{mc.ftCoalTime}, fMig{mc.ftMigTime}, fTheta{mc.ftTheta}, fRate{mc.ftMigRate}, fMix{mc.ftMixing};
+  std::vector<Finetune> fTau(cfg.K);
+  for (int p = 0; p < cfg.K; p++) fTau[p].v = mc.ftTaus[p];
+  auto push_finetunes = [&]() {
+    std::vector<double> taus(cfg.K);
+    for (int p = 0; p < cfg.K; p++) taus[p] = fTau[p].v;
+    return gph_mcmc_set_finetunes(M, fCoal.v, fMig.v, fTheta.v, fRate.v, fMix.v, taus.data());
+  };
+  if (info.findFinetunes) {
+    findingFinetunes = 1;
+    samplesPerLog = info.findFinetunesSamplesPerStep;
+    printf("   ---  Dynamically finding finetune settings for the first %d samples, updating finetunes every %d samples  ---- \n",
+           samplesPerLog * info.findFinetunesNumSteps, samplesPerLog);
+    for (Finetune *f : {&fCoal, &fMig, &fTheta, &fRate, &fMix}) if (f->v < 0) f->v = 1.0;
+    for (int p = 0; p < cfg.K; p++) if (fTau[p].v < 0) fTau[p].v = 1.0;
+    if ((rc = push_finetunes())) return fail(rc, "gph_mcmc_set_finetunes");
+    gph_mcmc_set_log_period(M, samplesPerLog);
+  }
+  int64_t logCount = 1, a0[9] = {0}, a[9];
+  std::vector<int64_t> t0v(cfg.K, 0), tv(cfg.K, 0);
   for (int it = -info.burnin; it < info.numSamples; it++) {
     if ((rc = gph_mcmc_iteration(M, it))) return fail(rc, "gph_mcmc_iteration");
     if (it >= 0 && it % (info.sampleSkip + 1) == 0) {   /* GPhoCS.c:1763-1769 */
@@ -88,15 +132,43 @@ extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t d
       fprintf(trace, "\t%.6f\t%.6f\n", logL, dataL);
       fflush(trace);
     }
-    if ((it + 1) % mc.samplesPerLog == 0) {
-      int64_t a[9];
+    logCount++;
+    if ((it + 1) % samplesPerLog == 0) {
       gph_mcmc_accept_counts(M, a);
+      gph_mcmc_tau_accept_counts(M, tv.data());
       gph_mcmc_get_state(M, &logL, &dataL, nullptr, nullptr, nullptr);
+      // acceptance percentages of the period exactly as upstream computes them (GPhoCS.c:1821-1853): logCount
+      // starts at 1, and the tau counts of a period are added twice (after UpdateTau and again after
+      // UpdateSampleAge, GPhoCS.c:1620-1623, 1646-1649)
+      const double lc = (double)logCount;
+      const double pCoal = (a[0] - a0[0]) * 100.0 / (lc * (double)totalCoals);
+      const double pMig = (a[1] - a0[1]) * 100.0 / ((double)(a[7] - a0[7]) + 0.000001);
+      const double pSpr = (a[2] - a0[2]) * 100.0 / (lc * 2 * (double)totalCoals);
+      const double pTheta = (a[3] - a0[3]) * 100.0 / (lc * cfg.K);
+      const double pRate = (a[4] - a0[4]) * 100.0 / (lc * cfg.B + 0.000001);
+      const double pMix = (a[6] - a0[6]) * 100.0 / lc;
       double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-      printf("%7d   coal %lld  mig %lld  spr %lld  theta %lld  migrate %lld  tau %lld  mix %lld | %.6f | %.1f s\n", it + 1,
-             (long long)a[0], (long long)a[1], (long long)a[2], (long long)a[3], (long long)a[4], (long long)a[5],
-             (long long)a[6], dataL, sec);
+      printf("%7d   %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    ", it + 1, pCoal, pMig, pSpr, pTheta, pRate);
+      for (int p = cfg.Kc; p < cfg.K; p++) printf("%5.1f%%    ", 2 * (tv[p] - t0v[p]) * 100.0 / lc);
+      printf("%5.1f%%    | %.6f | %.1f s\n", pMix, dataL, sec);
       fflush(stdout);
+      if (findingFinetunes) {
+        fCoal.adjust(pCoal); fMig.adjust(pMig); fTheta.adjust(pTheta); fRate.adjust(pRate); fMix.adjust(pMix);
+        for (int p = cfg.Kc; p < cfg.K; p++) fTau[p].adjust(2 * (tv[p] - t0v[p]) * 100.0 / lc);
+        if ((rc = push_finetunes())) return fail(rc, "gph_mcmc_set_finetunes");
+        printf("          %-9.7lf %-9.7lf           %-9.7lf %-9.7lf ", fCoal.v, fMig.v, fTheta.v, fRate.v);
+        for (int p = cfg.Kc; p < cfg.K; p++) printf("%-9.7lf ", fTau[p].v);
+        printf("          %-9.7lf \n", fMix.v);
+      }
+      logCount = 1;
+      memcpy(a0, a, sizeof a0);
+      t0v = tv;
+      if (findingFinetunes && it + 1 >= info.findFinetunesSamplesPerStep * info.findFinetunesNumSteps) {
+        findingFinetunes = 0;
+        samplesPerLog = mc.samplesPerLog;
+        gph_mcmc_set_log_period(M, samplesPerLog);
+        printf("\n-------------------------------------  finetunes  ------------------------------------\n");
+      }
     }
   }
   double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();

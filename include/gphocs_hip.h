@@ -166,6 +166,15 @@ int gph_mcmc_get_state(gph_mcmc *m, double *logLikelihood, double *dataLogLikeli
                        double *popAge, double *migRate);
 int gph_mcmc_dump_state(gph_mcmc *m, const char *path, int32_t withConditionals);
 int gph_mcmc_accept_counts(gph_mcmc *m, int64_t *counts9);
+/* cumulative accepted UpdateTau (ancestral) / UpdateSampleAge (current, estimated age) proposals per population [K] */
+int gph_mcmc_tau_accept_counts(gph_mcmc *m, int64_t *perPop);
+/* new step sizes (the find-finetunes search of performMCMC, GPhoCS.c:1896-2180, changes them between log periods);
+ * taus [K] or NULL = unchanged */
+int gph_mcmc_set_finetunes(gph_mcmc *m, double coalTime, double migTime, double theta, double migRate, double mixing,
+                           const double *taus);
+/* iterations between two checkAll() resynchronisations (= the log period, GPhoCS.c:1811-1821; the find-finetunes
+ * phase uses find-finetunes-samples-per-step instead of iterations-per-log) */
+int gph_mcmc_set_log_period(gph_mcmc *m, int32_t iterations);
 /* recordParamVals (GPhoCS.c:802-849) of the last iteration: thetas, taus, migration rates, sample ages */
 int gph_mcmc_param_vals(gph_mcmc *m, double *vals, int32_t n);
 
@@ -185,7 +194,7 @@ typedef struct {
   int32_t numLoci;          /* num-loci of the control file, -1 = all loci of the sequence file */
   int32_t burnin, numSamples, sampleSkip, logsPerLine;
   int32_t mutRateMode;      /* 0 CONST, 1 VAR, 2 FIXED */
-  int32_t findFinetunes;
+  int32_t findFinetunes, findFinetunesNumSteps, findFinetunesSamplesPerStep;
   int32_t numSampleSlots;   /* haploid leaves per locus (a diploid sample takes two) */
   double varRatesAlpha, ftLocusRate;
 } gph_control_info;

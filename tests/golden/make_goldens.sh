@@ -44,3 +44,6 @@ ls -la
 timeout 600 $REF pack z0.ctl z0.gpk >/dev/null
 timeout 600 $REF run z0.ctl 0 z0.init.rtrace z0.init.state -1 1 >/dev/null; rm -f z0.init.rtrace
 timeout 600 $REF run z0.ctl 12 z0.rtrace z0.state 11 1 >/dev/null
+# f3: the find-finetunes search (GPhoCS.c:1896-2180) -- config 3 with find-finetunes TRUE, 6 steps of 10 samples;
+# only the reference's own trace file is kept (f3.ctl is gen_synth output with the three find-finetunes lines edited in)
+timeout 900 $REF main -n 1 f3.ctl >/dev/null 2>&1

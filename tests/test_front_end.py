@@ -73,9 +73,11 @@ def test_thread_count_does_not_change_the_result(lib):
         assert np.array_equal(getattr(a, f), getattr(b, f))
 
 
-@pytest.mark.parametrize("name", ["g1", "m3", "a7"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3"])
 def test_program_writes_the_reference_trace_file(lib, name, tmp_path):
-    """same control file + sequence file -> the trace file of the real G-PhoCS binary, byte for byte"""
+    """same control file + sequence file -> the trace file of the real G-PhoCS binary, byte for byte
+    (f3: find-finetunes TRUE -- the step-size search of performMCMC, GPhoCS.c:1896-2180, incl. its acceptance
+    bookkeeping quirks, must take the same decisions for the chain to stay on the reference's trajectory)"""
     for ext in (".ctl", ".seq"):
         shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
     with _in_dir(tmp_path):
