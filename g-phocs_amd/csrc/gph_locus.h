@@ -216,6 +216,17 @@ GPH_DEV double gph_div_theta(double a, int pop)
   return __builtin_fma(__builtin_fma(-q0, b, a), y, q0);
 #endif
 }
+// same with the caller holding b = theta[pop] and y = thetaInv[pop] in registers
+GPH_DEV double gph_div_by(double a, double b, double y)
+{
+#ifdef GPH_HOSTEMU
+  (void)y;
+  return a / b;
+#else
+  const double q0 = a * y;
+  return __builtin_fma(__builtin_fma(-q0, b, a), y, q0);
+#endif
+}
 GPH_DEV double gph_div3(double a)
 {
 #ifdef GPH_HOSTEMU
@@ -1462,6 +1473,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
     ev = ENEXT(NEV(node));
   }
   theta = g_model.theta[pop];
+  double thinv = g_model.thetaInv[pop];
   age = AGE(node);
   if (!RECONNECT) {
     setSPRI(SI_NOLD, 0);
@@ -1496,9 +1508,10 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
    * being crossed accumulates in a register and is written back when the walk leaves it -- same values,
    * same order of additions */
   const int fev_old = RECONNECT ? -1 : SPRI(SI_FEV_OLD);
+  const int guard_max = 4 * g_lay.E;
   double dcoal = DCOAL(inst, pop);
   while (proceed) {
-    if (++guard > 4 * g_lay.E) { gph_fail(96); break; }
+    if (++guard > guard_max) { gph_fail(96); break; }
     if (ev < 0) {
       if (g_model.popFather[pop] < 0) {
         if (RECONNECT) { setDCOAL(inst, pop, dcoal); setDI(inst, DI_NEV, nev); setSPRLN(RECONNECT, lnld); return -1; }
@@ -1509,6 +1522,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
       pop = g_model.popFather[pop];
       dcoal = DCOAL(inst, pop);
       theta = g_model.theta[pop];
+      thinv = g_model.thetaInv[pop];
       ev = FIRSTEV(pop);
       mig_rate = 0.0;
       if (fabs(age / g_model.popAge[pop] - 1) > 0.01) { gph_fail(8); break; }
@@ -1535,7 +1549,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
         }
       }
     } else {
-      rate = mig_rate + gph_div_theta(2 * nlin, pop);
+      rate = mig_rate + gph_div_by(2 * nlin, theta, thinv);
       if (UNI(rate <= 0)) t = et;
       else t = -(1 / rate) * gph_log_u(l_rndu(rng));
       if (UNI(t >= et)) {
@@ -1587,7 +1601,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
     nev++;
     /* RECONNECT: the interval's rate was just computed (a split interval keeps its lineage count) */
     if (RECONNECT) lnld -= rate * t;
-    else lnld -= (mig_rate + gph_div_theta(2 * nlin, pop)) * t;
+    else lnld -= (mig_rate + gph_div_by(2 * nlin, theta, thinv)) * t;
     if (mig_source >= 0) {
       lnld += gph_log_u(g_model.migRate[b]);
       ev = mig_source;
@@ -1595,6 +1609,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
       pop = g_model.bandSrc[b];
       dcoal = DCOAL(inst, pop);
       theta = g_model.theta[pop];
+      thinv = g_model.thetaInv[pop];
       mig_source = -1;
       mig_rate = 0.0;
       live.n = 0;
