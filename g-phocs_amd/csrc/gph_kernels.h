@@ -74,7 +74,9 @@ GPH_DEV void scratch_init(const GphDev &D, int g)
   for (k = 0; k < CN_COUNT; k++) setCNT(k, 0);
   setCNT(CN_P, D.P[g]);
   sf64(&GphLds::s_cntf, 0, 0.0);
+#if defined(GPH_STAMPS) || defined(GPH_HOSTEMU)
   for (k = 0; k < 8; k++) gph_lds.s_stamp[k] = 0.0;
+#endif
   set_cond_base(D.cond + D.cond_off[g]);
   delta_clear(0);
   delta_clear(1);

@@ -72,8 +72,8 @@
 #define DIRTY(i) gu8(&GphLds::dirty, (i))
 #define setDIRTY(i, v) su8(&GphLds::dirty, (i), (v))
 // scratch
-#define DEV(inst, i) gi16(&GphLds::s_dev, (inst), (i))
-#define setDEV(inst, i, v) si16(&GphLds::s_dev, (inst), (i), (v))
+#define DEV(inst, i) RFL((int)gph_lds.s_dev[inst][i])
+#define setDEV(inst, i, v) (gph_lds.s_dev[inst][i] = (uint8_t)(v))
 #define DCOAL(inst, i) gf64(&GphLds::s_dcoal, (inst), (i))
 #define setDCOAL(inst, i, v) sf64(&GphLds::s_dcoal, (inst), (i), (v))
 #define DMIG(inst, i) gf64(&GphLds::s_dmig, (inst), (i))

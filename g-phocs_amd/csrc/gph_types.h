@@ -150,12 +150,21 @@ struct alignas(16) GphLds {
   // ---- LDS-only scratch: pending-proposal storage of GENETREE_STATS_DELTA x2 (patch.h:60-72),
   // MIG_SPR_STATS (patch.h:97-105), genetree_stats_check (patch.h:109), pruning work lists
   double s_dcoal[2][GPH_CAP_K], s_dmig[2][GPH_CAP_B], s_sprf[GPH_MAX_MIGS + 2];
-  double s_chkcoal[GPH_CAP_K], s_chkmig[GPH_CAP_B], s_cntf[2], s_stamp[8];
+  double s_chkcoal[GPH_CAP_K], s_chkmig[GPH_CAP_B], s_cntf[2];
+#if defined(GPH_STAMPS) || defined(GPH_HOSTEMU)
+  double s_stamp[8];          // diagnostic cycle sums (tools/stamp_breakdown.py); not in production device builds
+#endif
   int32_t s_di[2][8], s_spri[8], s_cnt[8];
   uint32_t s_condptr[2];
-  int16_t s_dev[2][GPH_CAP_E], s_dpops[2][GPH_CAP_K], s_dbands[2][GPH_CAP_B], s_spri16[4 * GPH_MAX_MIGS];
+  int16_t s_dpops[2][GPH_CAP_K], s_dbands[2][GPH_CAP_B], s_spri16[4 * GPH_MAX_MIGS];
   int16_t s_ord[GPH_CAP_N + 1], s_stack[GPH_CAP_N + 1], s_targets[GPH_CAP_N + 1], s_chknc[GPH_CAP_K], s_chknm[GPH_CAP_B];
+  uint8_t s_dev[2][GPH_CAP_E];   // event lists of the two pending deltas (event ids < 256)
+#ifdef GPH_PAD
+  char s_pad[GPH_PAD];           // LDS-size sensitivity experiments only
+#endif
 };
+
+static_assert(GPH_CAP_E <= 255, "event ids are stored in 8 bits (s_dev)");
 
 // arguments of the tau-evaluate kernel (host part of UpdateTau, GPhoCS.c:3224-3461)
 struct GphTauArgs {
