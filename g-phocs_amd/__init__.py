@@ -131,7 +131,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_mcmc_create", "gph_mcmc_destroy", "gph_mcmc_initialize", "gph_mcmc_set_record_file",
     "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
     "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
-    "gph_control_sample_name", "gph_loci_read", "gph_loci_free", "gph_loci_arrays", "gph_run_control_file",
+    "gph_control_sample_name", "gph_loci_read", "gph_loci_free", "gph_loci_arrays", "gph_run_control_file", "gph_run_control_file_ranked",
 ]
 
 
@@ -195,6 +195,8 @@ def _load_library(path):
     lib.gph_loci_free.restype = None
     lib.gph_loci_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     lib.gph_run_control_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
+    lib.gph_run_control_file_ranked.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                ALLREDUCE_FN, C.c_void_p]
     return lib
 
 

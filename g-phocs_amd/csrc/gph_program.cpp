@@ -2,6 +2,7 @@
 // (GPhoCS.c:84-238, 1232-1330, 1763-1769) over the engine: same control file, same sequence
 // file, same trace file.  Everything per-locus runs on the MI355X engine; there is no CPU path.
 #include "../../include/gphocs_hip.h"
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,8 +34,11 @@ struct Finetune {
 };
 }   // namespace
 
-extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t device, int32_t verbose)
+extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, int32_t device, int32_t verbose,
+                                           int32_t rank, int32_t world, gph_allreduce_fn allreduce, void *user)
 {
+  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !allreduce)) return GPH_EARG;
+  const bool lead = rank == 0;   /* rank 0 talks and writes the trace file; every rank runs the same chain */
   gph_control *C = nullptr;
   gph_loci *LC = nullptr;
   gph_engine *E = nullptr;
@@ -54,13 +58,16 @@ extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t d
     if (C) gph_control_free(C);
     return code;
   };
-  printf("Reading control settings from file %s...\n", ctl);
+  if (lead) printf("Reading control settings from file %s...\n", ctl);
   if ((rc = gph_control_read(ctl, ctl2, &C))) return fail(rc, "reading the control file");
   gph_control_get(C, &cfg, &mc, &info);
-  printf("Done.\n");
+  if (lead) printf("Done.\n");
   if (info.mutRateMode == 1) return fail(GPH_EARG, "locus-mut-rate VAR (UpdateLocusRate is serial over loci upstream and not offloaded)");
-  if (mc.seed < 0) mc.seed = abs(2 * (int)time(NULL) + 1);   /* GPhoCS.c:188-191 */
-  if (verbose) printf("\nRandom seed set to %d\n", mc.seed);
+  if (mc.seed < 0) {
+    if (world > 1) return fail(GPH_EARG, "random-seed must be given in the control file when several ranks run one chain");
+    mc.seed = abs(2 * (int)time(NULL) + 1);   /* GPhoCS.c:188-191 */
+  }
+  if (verbose && lead) printf("\nRandom seed set to %d\n", mc.seed);
 
   auto t0 = std::chrono::steady_clock::now();
   if ((rc = gph_loci_read(C, nullptr, 0, &LC, err, sizeof err))) return fail(rc, "reading the sequence file");
@@ -72,18 +79,23 @@ extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t d
     int64_t up = 0;
     for (int64_t g = 0; g < L; g++) up += unph[g];
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("Read %lld loci over %d samples: %lld patterns (%.2f per locus) -> %lld phased patterns (%.2f per locus) in %.2f s.\n",
+    if (lead) printf("Read %lld loci over %d samples: %lld patterns (%.2f per locus) -> %lld phased patterns (%.2f per locus) in %.2f s.\n",
            (long long)L, n, (long long)up, (double)up / L, (long long)offs[L], (double)offs[L] / L, sec);
   }
+  // loci shard in contiguous blocks of ceil(L / world) (OpenMP static scheduling of the reference, MultiCoreUtils.h:8)
+  const int64_t per = (L + world - 1) / world, lb = std::min<int64_t>(rank * per, L), le = std::min<int64_t>((rank + 1) * per, L);
+  if (le <= lb) return fail(GPH_EARG, "more ranks than loci");
   cfg.L_total = L;
-  cfg.locus_begin = 0;
+  cfg.locus_begin = lb;
   cfg.device = device;
   if ((rc = gph_engine_create(&cfg, &E))) return fail(rc, "gph_engine_create");
-  if ((rc = gph_engine_load_loci(E, L, offs, leaf, ph, cnt, info.mutRateMode == 2 ? rates : nullptr))) return fail(rc, "gph_engine_load_loci");
+  if (world > 1 && (rc = gph_engine_set_allreduce(E, allreduce, user))) return fail(rc, "gph_engine_set_allreduce");
+  /* pattern offsets are absolute indices into the pattern arrays: the shard is a window of the offset array */
+  if ((rc = gph_engine_load_loci(E, le - lb, offs + lb, leaf, ph, cnt, info.mutRateMode == 2 ? rates + lb : nullptr))) return fail(rc, "gph_engine_load_loci");
   if ((rc = gph_mcmc_create(E, &cfg, &mc, &M))) return fail(rc, "gph_mcmc_create");
 
   // trace file header, GPhoCS.c:1273-1311
-  trace = fopen(info.traceFile, "w");
+  trace = fopen(lead ? info.traceFile : "/dev/null", "w");
   if (!trace) { snprintf(err, sizeof err, "Could not open trace file %s", info.traceFile); return fail(GPH_EARG, "opening the trace file"); }
   fprintf(trace, "Sample");
   for (int p = 0; p < cfg.K; p++) fprintf(trace, "\ttheta_%s", gph_control_pop_name(C, p));
@@ -94,7 +106,7 @@ extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t d
     if (mc.updateSampleAge[p] || mc.sampleAge[p] > 0.0) fprintf(trace, "\ttau_%s", gph_control_pop_name(C, p));
   fprintf(trace, "\tData-ld-ln\tFull-ld-ln\n");
 
-  printf("Starting MCMC: %d burnin, %d running, sampled every %d iteration(s).\n", info.burnin, info.numSamples, info.sampleSkip);
+  if (lead) printf("Starting MCMC: %d burnin, %d running, sampled every %d iteration(s).\n", info.burnin, info.numSamples, info.sampleSkip);
   int64_t totalCoals = 0;
   if ((rc = gph_mcmc_initialize(M, &totalCoals))) return fail(rc, "gph_mcmc_initialize");
   std::vector<double> vals(mc.numParameters + 4, 0.0);
@@ -113,7 +125,7 @@ extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t d
   if (info.findFinetunes) {
     findingFinetunes = 1;
     samplesPerLog = info.findFinetunesSamplesPerStep;
-    printf("   ---  Dynamically finding finetune settings for the first %d samples, updating finetunes every %d samples  ---- \n",
+    if (lead) printf("   ---  Dynamically finding finetune settings for the first %d samples, updating finetunes every %d samples  ---- \n",
            samplesPerLog * info.findFinetunesNumSteps, samplesPerLog);
     for (Finetune *f : {&fCoal, &fMig, &fTheta, &fRate, &fMix}) if (f->v < 0) f->v = 1.0;
     for (int p = 0; p < cfg.K; p++) if (fTau[p].v < 0) fTau[p].v = 1.0;
@@ -148,17 +160,17 @@ extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t d
       const double pRate = (a[4] - a0[4]) * 100.0 / (lc * cfg.B + 0.000001);
       const double pMix = (a[6] - a0[6]) * 100.0 / lc;
       double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-      printf("%7d   %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    ", it + 1, pCoal, pMig, pSpr, pTheta, pRate);
-      for (int p = cfg.Kc; p < cfg.K; p++) printf("%5.1f%%    ", 2 * (tv[p] - t0v[p]) * 100.0 / lc);
-      printf("%5.1f%%    | %.6f | %.1f s\n", pMix, dataL, sec);
+      if (lead) printf("%7d   %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    ", it + 1, pCoal, pMig, pSpr, pTheta, pRate);
+      for (int p = cfg.Kc; p < cfg.K; p++) if (lead) printf("%5.1f%%    ", 2 * (tv[p] - t0v[p]) * 100.0 / lc);
+      if (lead) printf("%5.1f%%    | %.6f | %.1f s\n", pMix, dataL, sec);
       fflush(stdout);
       if (findingFinetunes) {
         fCoal.adjust(pCoal); fMig.adjust(pMig); fTheta.adjust(pTheta); fRate.adjust(pRate); fMix.adjust(pMix);
         for (int p = cfg.Kc; p < cfg.K; p++) fTau[p].adjust(2 * (tv[p] - t0v[p]) * 100.0 / lc);
         if ((rc = push_finetunes())) return fail(rc, "gph_mcmc_set_finetunes");
-        printf("          %-9.7lf %-9.7lf           %-9.7lf %-9.7lf ", fCoal.v, fMig.v, fTheta.v, fRate.v);
-        for (int p = cfg.Kc; p < cfg.K; p++) printf("%-9.7lf ", fTau[p].v);
-        printf("          %-9.7lf \n", fMix.v);
+        if (lead) printf("          %-9.7lf %-9.7lf           %-9.7lf %-9.7lf ", fCoal.v, fMig.v, fTheta.v, fRate.v);
+        for (int p = cfg.Kc; p < cfg.K; p++) if (lead) printf("%-9.7lf ", fTau[p].v);
+        if (lead) printf("          %-9.7lf \n", fMix.v);
       }
       logCount = 1;
       memcpy(a0, a, sizeof a0);
@@ -167,16 +179,21 @@ extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t d
         findingFinetunes = 0;
         samplesPerLog = mc.samplesPerLog;
         gph_mcmc_set_log_period(M, samplesPerLog);
-        printf("\n-------------------------------------  finetunes  ------------------------------------\n");
+        if (lead) printf("\n-------------------------------------  finetunes  ------------------------------------\n");
       }
     }
   }
   double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-  printf("MCMC finished. Time used: %.2f s (%.3f iterations/s).\n", sec, (info.burnin + info.numSamples) / (sec > 0 ? sec : 1));
+  if (lead) printf("MCMC finished. Time used: %.2f s (%.3f iterations/s).\n", sec, (info.burnin + info.numSamples) / (sec > 0 ? sec : 1));
   fclose(trace);
   gph_mcmc_destroy(M);
   gph_engine_destroy(E);
   gph_loci_free(LC);
   gph_control_free(C);
   return GPH_OK;
+}
+
+extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t device, int32_t verbose)
+{
+  return gph_run_control_file_ranked(ctl, ctl2, device, verbose, 0, 1, nullptr, nullptr);
 }

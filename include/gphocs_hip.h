@@ -211,6 +211,11 @@ void gph_loci_free(gph_loci *l);
 int gph_loci_arrays(const gph_loci *l, int64_t *L, int32_t *n, const int64_t **pattern_offsets, const uint8_t **leafcodes,
                     const uint8_t **numPhases, const int32_t **counts, const double **mutRates, const int32_t **unphased);
 int gph_run_control_file(const char *ctl_path, const char *secondary_ctl_path_or_null, int32_t device, int32_t verbose);
+/* the same chain over `world` processes, one per GPU: every rank reads the files, holds the contiguous block
+ * rank*ceil(L/world) .. of the loci, runs the same host code on the same general RNG stream and combines the
+ * reduced vectors through `allreduce` (see gph_engine_set_allreduce); rank 0 writes the trace file */
+int gph_run_control_file_ranked(const char *ctl_path, const char *secondary_ctl_path_or_null, int32_t device,
+                                int32_t verbose, int32_t rank, int32_t world, gph_allreduce_fn allreduce, void *user);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@ within 1e-10 relative; the full per-locus state (topology, event chains with ids
 counts, statistics, RNG slots exact; ages/times/conditionals within 1e-9 relative)."""
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -178,3 +179,24 @@ def test_program_trace_file(name, tmp_path):
         # one unit of the last printed digit at most (values agree to 1e-10 relative)
         assert all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
     assert ndiff <= len(want) // 10
+
+
+@pytest.mark.gpu
+def test_program_through_rccl_launcher(tmp_path):
+    """tools/run_multi_gpu.py under torch.distributed.run with the nccl (= RCCL) backend and one rank on this GPU:
+    the all-gather hook with device tensors, gph_run_control_file_ranked, trace file vs the real binary's"""
+    import shutil
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, "a7" + ext), tmp_path)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(REPO, "tools", "run_multi_gpu.py"), "a7.ctl"]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    want = open(os.path.join(GOLDEN, "a7.trace")).read().splitlines()
+    got = open(os.path.join(tmp_path, "a7.trace")).read().splitlines()
+    assert want[0] == got[0] and len(want) == len(got)
+    for w, g in zip(want[1:], got[1:]):
+        if w == g:
+            continue
+        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
+        assert len(wf) == len(gf) and all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)

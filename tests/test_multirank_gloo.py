@@ -70,3 +70,29 @@ def test_two_ranks_equal_one_rank(name, iters, presharded, tmp_path):
     cut = len(mine)
     (tmp_path / "g").write_text("\n".join(golden[:cut]) + "\n")
     compare_records(out + ".0", str(tmp_path / "g"))
+
+
+def test_program_over_two_ranks(tmp_path):
+    """the whole program (control file -> trace file) over two ranks: tools/run_multi_gpu.py with gloo and the
+    host-emulation build; rank 0's trace file against the real binary's (reduction order differs from the
+    single-process run, so values agree to ~1e-13 relative and the printed digits may differ in the last place)"""
+    import shutil
+    sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
+    import run_hostemu as R
+    lib = R.build_hostemu()
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, "m3" + ext), tmp_path)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    cmd = [sys.executable, os.path.join(REPO, "tools", "run_multi_gpu.py"), "m3.ctl", "--backend", "gloo", "--lib", lib]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=tmp_path) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    want = open(os.path.join(GOLDEN, "m3.trace")).read().splitlines()
+    got = open(os.path.join(tmp_path, "m3.trace")).read().splitlines()
+    assert want[0] == got[0] and len(want) == len(got)
+    for w, g in zip(want[1:], got[1:]):
+        if w == g:
+            continue
+        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
+        assert len(wf) == len(gf) and wf[0] == gf[0]
+        assert all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
