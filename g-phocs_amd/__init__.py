@@ -28,13 +28,14 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # sized by compile-time capacities (csrc/gph_types.h), and a tighter image means more resident
 # wavefronts per CU.  `load_library(dims=...)` picks the smallest variant that fits the model.
 VARIANTS = {  # name: (max leaves, max pops, max bands, waves per SIMD of the sweep kernel, file)
-    "s": (16, 9, 4, 6, "libgphocs_hip_s.so"),
+    "s": (16, 9, 4, 6, "libgphocs_hip_s.so"),     # BASELINE configs[0..3]
+    "l": (20, 13, 4, 5, "libgphocs_hip_l.so"),    # BASELINE configs[4] (20 leaves, 13 populations)
     "m": (24, 16, 8, 5, "libgphocs_hip.so"),
 }
 
 
 def variant_for(n, K, B):
-    for name in ("s", "m"):
+    for name in ("s", "l", "m"):
         cl, ck, cb, _, _ = VARIANTS[name]
         if n <= cl and K <= ck and B <= cb:
             return name

@@ -14,7 +14,8 @@
 #include <string>
 
 struct Variant { const char *file; int leaves, pops, bands; };
-static const Variant VARIANTS[] = {{"libgphocs_hip_s.so", 16, 9, 4}, {"libgphocs_hip.so", 24, 16, 8}};
+static const Variant VARIANTS[] = {{"libgphocs_hip_s.so", 16, 9, 4}, {"libgphocs_hip_l.so", 20, 13, 4}, {"libgphocs_hip.so", 24, 16, 8}};
+static const int DEFAULT_VARIANT = 2;   /* the largest capacities: always able to read the control file */
 
 template <class F> static F sym(void *h, const char *name)
 {
@@ -40,7 +41,7 @@ int main(int argc, char **argv)
   self[k] = 0;
   const std::string dir = dirname(self);
   const char *forced = getenv("GPHOCS_HIP_LIB");
-  std::string path = forced ? forced : dir + "/" + VARIANTS[1].file;
+  std::string path = forced ? forced : dir + "/" + VARIANTS[DEFAULT_VARIANT].file;
   void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
   if (!h) { fprintf(stderr, "G-PhoCS-hip: cannot load %s: %s\n", path.c_str(), dlerror()); return 2; }
   if (!forced) {
@@ -52,7 +53,7 @@ int main(int argc, char **argv)
     sym<decltype(&gph_control_free)>(h, "gph_control_free")(c);
     for (const Variant &v : VARIANTS)
       if (n <= v.leaves && K <= v.pops && B <= v.bands) {
-        if (strcmp(v.file, VARIANTS[1].file)) {
+        if (strcmp(v.file, VARIANTS[DEFAULT_VARIANT].file)) {
           std::string p2 = dir + "/" + v.file;
           void *h2 = dlopen(p2.c_str(), RTLD_NOW | RTLD_LOCAL);
           if (h2) h = h2;
