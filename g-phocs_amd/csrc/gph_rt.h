@@ -80,7 +80,10 @@ __device__ inline double gph_rfl64(double x)
   return v.d;
 }
 #define RFLD(x) gph_rfl64(x)
-#define UNI(c) (__builtin_amdgcn_readfirstlane((int)(c)) != 0)
+// a wave-uniform condition computed on the vector ALU (fp64 compares): the compare's lane mask is tested
+// as a scalar (v_cmp -> SGPR pair -> s_cmp_lg_u64 -> s_cbranch_scc) instead of being turned into a 0/1
+// VGPR and read back (v_cndmask + v_readfirstlane + s_bitcmp)
+#define UNI(c) (__builtin_amdgcn_ballot_w64((bool)(c)) != 0)
 #endif
 typedef GPH_LDS double lf64;
 typedef GPH_LDS int16_t li16;
