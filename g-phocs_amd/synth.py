@@ -19,6 +19,9 @@ CONFIGS = {  # diploid samples per current pop, migration bands (src, tgt), anci
     3: dict(pops=[2, 2, 2], bands=[(0, 1), (2, 1)]),
     4: dict(pops=[2, 2, 2, 1, 1], bands=[(0, 1), (1, 0), (3, 2), (4, 3)]),
     5: dict(pops=[2, 2, 2, 1, 1, 1, 1], bands=[(0, 1), (1, 0), (3, 2), (4, 3)], ancient=6),
+    # estimated ("e") sample ages: UpdateSampleAge is live and mixing stays on (tools/gen_synth.py configs 6, 7)
+    6: dict(pops=[2, 2, 2, 1], bands=[(0, 1), (3, 2), (2, 3)], ancient=3, ancient_est=True),
+    7: dict(pops=[2, 1, 2], bands=[(0, 1), (1, 0), (2, 1)], ancient=1, ancient_est=True),
 }
 
 
@@ -30,7 +33,7 @@ def _taus(kc):
     return taus
 
 
-def make_model(pack, config, seed=12345, samples_per_log=100, start_mig=0, do_mixing=None):
+def make_model(pack, config, seed=12345, samples_per_log=100, start_mig=0, do_mixing=None, mig_beta=0.00001):
     """fills the model / prior / finetune fields of `pack` like sample-control-file.ctl:12-27"""
     cfg = CONFIGS[config]
     kc = len(cfg["pops"])
@@ -49,8 +52,10 @@ def make_model(pack, config, seed=12345, samples_per_log=100, start_mig=0, do_mi
         p.popFather[prev] = p.popFather[i + 1] = a
         prev = a
     p.sampleAge = np.zeros(K)
+    p.updateSampleAge = np.zeros(K, np.int32)
     if cfg.get("ancient") is not None:
         p.sampleAge[cfg["ancient"]] = 0.000002
+        p.updateSampleAge[cfg["ancient"]] = int(bool(cfg.get("ancient_est")))
     p.thetaAlpha, p.thetaBeta, p.thetaStart = np.full(K, 1.0), np.full(K, 10000.0), np.full(K, 1e-4)
     taus = _taus(kc)
     p.ageAlpha, p.ageBeta, p.ageStart = np.zeros(K), np.zeros(K), np.zeros(K)
@@ -58,9 +63,10 @@ def make_model(pack, config, seed=12345, samples_per_log=100, start_mig=0, do_mi
         p.ageAlpha[kc + i], p.ageBeta[kc + i], p.ageStart[kc + i] = 1.0, 20000.0, taus[i]
     p.bandSrc = np.array([s for s, _ in cfg["bands"]] or [0], np.int32)
     p.bandTgt = np.array([t for _, t in cfg["bands"]] or [0], np.int32)
-    p.mrAlpha, p.mrBeta = np.full(max(B, 1), 0.002), np.full(max(B, 1), 0.00001)
+    p.mrAlpha, p.mrBeta = np.full(max(B, 1), 0.002), np.full(max(B, 1), mig_beta)
     p.seed, p.burnin, p.numSamplesMcmc, p.sampleSkip, p.startMig = seed, 0, 1000, 0, start_mig
-    p.doMixing = int(cfg.get("ancient") is None) if do_mixing is None else int(do_mixing)
+    # a FIXED non-zero sample age switches mixing off (MCMCcontrol.c:905-907); an estimated one does not
+    p.doMixing = int(cfg.get("ancient") is None or bool(cfg.get("ancient_est"))) if do_mixing is None else int(do_mixing)
     p.samplesPerLog, p.mutRateMode = samples_per_log, 0
     p.ftCoalTime, p.ftMigTime, p.ftTheta, p.ftMigRate, p.ftMixing = 0.01, 0.3, 0.04, 0.02, 0.003
     p.ftTaus = np.full(K, 0.0000008)
@@ -73,11 +79,11 @@ def make_model(pack, config, seed=12345, samples_per_log=100, start_mig=0, do_mi
 
 
 def make_synthetic_pack(Pack, config, L, seqlen=1000, nmask=0.002, mut_scale=1.0, data_seed=None,
-                        mcmc_seed=12345, samples_per_log=100):
+                        mcmc_seed=12345, samples_per_log=100, mig_beta=0.00001):
     cfg = CONFIGS[config]
     rng = np.random.default_rng(20261002 + config if data_seed is None else data_seed)
     p = Pack()
-    taus = make_model(p, config, seed=mcmc_seed, samples_per_log=samples_per_log)
+    taus = make_model(p, config, seed=mcmc_seed, samples_per_log=samples_per_log, mig_beta=mig_beta)
     p.L = p.numLoci = L
     n, kc = p.n, p.Kc
     theta = 1e-4 * mut_scale
@@ -199,7 +205,7 @@ def write_pack(p, path):
         f.write("samplesPerPop " + " ".join(str(int(x)) for x in p.samplesPerPop) + "\n")
         for k in range(p.K):
             f.write(f"pop {k} {p.popName[k]} {p.popFather[k]} {p.popSon0[k]} {p.popSon1[k]} "
-                    f"{float(p.sampleAge[k]).hex()} 0 {float(p.thetaAlpha[k]).hex()} {float(p.thetaBeta[k]).hex()} "
+                    f"{float(p.sampleAge[k]).hex()} {int(getattr(p, 'updateSampleAge', [0] * p.K)[k])} {float(p.thetaAlpha[k]).hex()} {float(p.thetaBeta[k]).hex()} "
                     f"{float(p.thetaStart[k]).hex()} {float(p.ageAlpha[k]).hex()} {float(p.ageBeta[k]).hex()} "
                     f"{float(p.ageStart[k]).hex()}\n")
         for b in range(p.B):

@@ -74,15 +74,18 @@ def test_many_patterns_against_live_oracle(G, oracle_cli, tmp_path):
     compare_states(st1, os_)
 
 
-@pytest.mark.parametrize("config,loci,iters,mut", [(4, 3000, 24, 6.5), (5, 1500, 20, 3.0), (3, 2000, 30, 1.0)])
-def test_scale_parity_against_live_oracle(G, oracle_cli, tmp_path, config, loci, iters, mut):
-    """thousands of loci of the benchmark's synthetic shape (configs[3] and [4], and the 3-population one),
-    through every proposal type, against the oracle run live on the same pack: ~10^5 locus-iterations,
-    so rare paths (migration-event creation, rubber-band conflicts, checkAll resync at samples-per-log)
-    are hit.  Counters exact, accumulators <= 1e-10 relative, final per-locus state field by field."""
+@pytest.mark.parametrize("config,loci,iters,mut,mig_beta", [(4, 3000, 24, 6.5, 1e-5), (5, 1500, 20, 3.0, 1e-5),
+                                                             (3, 2000, 30, 1.0, 1e-5), (6, 1500, 24, 2.0, 4e-8),
+                                                             (7, 1500, 24, 2.0, 4e-8), (4, 1500, 16, 3.0, 4e-8)])
+def test_scale_parity_against_live_oracle(G, oracle_cli, tmp_path, config, loci, iters, mut, mig_beta):
+    """thousands of loci of the benchmark's synthetic shape (configs[3] and [4], the 3-population one, the two
+    estimated-sample-age ones and a high-migration prior: mig-rate-beta 4e-8 puts thousands of migration events
+    into the genealogies), through every proposal type, against the oracle run live on the same pack: ~10^5
+    locus-iterations, so rare paths (migration-event creation and removal, rubber-band conflicts of UpdateTau and
+    UpdateSampleAge, "not enough migration slots", checkAll resync at samples-per-log) are hit.  Counters exact, accumulators <= 1e-10 relative, final per-locus state field by field."""
     from gphocs_amd_pkg import synth
     pk = synth.make_synthetic_pack(G.Pack, config, loci, mut_scale=mut, data_seed=777 + config, mcmc_seed=4242,
-                                   samples_per_log=8)
+                                   samples_per_log=8, mig_beta=mig_beta)
     pth = str(tmp_path / "scale.gpk")
     synth.write_pack(pk, pth)
     tr, _, st1, cnt = _run(G, pth, iters, tmp_path, "scale")
