@@ -163,6 +163,7 @@ struct gph_engine {
   void *allreduce_user = nullptr;
   uint32_t seedz = 0;
   bool loaded = false, seeded = false, model_set = false, initialized = false;
+  bool sync_pending = false;   // synchronizeEvents of the finished iteration rides at the head of the next sweep kernel
   gph_counters counters = {0, 0, 0.0, 0};
   double last_ms[16] = {0};
   // per kernel class: launches, summed HIP-event ms, evaluations, algorithmic bytes
@@ -328,6 +329,18 @@ static int finish_kernel(gph_engine *e)
 static int xreduce(gph_engine *e, double *sums, int nsum, double *mins, int nmin)
 {
   if (e->allreduce) return e->allreduce(e->allreduce_user, sums, nsum, mins, nmin) ? GPH_EHIP : 0;
+  return 0;
+}
+
+// run a deferred synchronizeEvents pass now (anything but the next genealogy sweep is about to touch the pages)
+static int flush_sync(gph_engine *e)
+{
+  if (!e->sync_pending) return 0;
+  e->sync_pending = false;
+  LAUNCH(e, 8, k_sync, 0);
+  int rc = finish_kernel(e);
+  if (rc) return rc;
+  if (RMIN(e, 0) < 1.0) { fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n"); return GPH_EKERNEL; }
   return 0;
 }
 
@@ -535,9 +548,12 @@ int gph_engine_init_genealogies(gph_engine *e, double *sumGen, double *sumData)
 int gph_engine_genealogy_sweep(gph_engine *e, int32_t flags, double ftCoal, double ftMig, gph_sweep_result *out)
 {
   if (!e || !e->initialized || !out) return GPH_ESTATE;
-  LAUNCH(e, 0, k_sweep, (int)flags, ftCoal, ftMig);
+  const int with_sync = e->sync_pending ? 8 : 0;   /* flag 8: synchronizeEvents first, in the same kernel */
+  e->sync_pending = false;
+  LAUNCH(e, 0, k_sweep, (int)flags | with_sync, ftCoal, ftMig);
   int rc = finish_kernel(e);
   if (rc) return rc;
+  if (with_sync && RMIN(e, 15) < 1.0) { fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n"); return GPH_EKERNEL; }
   double s[9] = {RSUM(e, 0), RSUM(e, 1), RSUM(e, 2), RSUM(e, 3), RSUM(e, 4), RSUM(e, 5), RSUM(e, 6), RSUM(e, 7), RSUM(e, 12)};
   rc = xreduce(e, s, 9, nullptr, 0);
   out->accepted_internal = (int64_t)s[0];
@@ -556,6 +572,7 @@ int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result
 {
   if (!e || !e->initialized || !a || !out) return GPH_ESTATE;
   if (a->num_aff > 2 * GPH_MAXB) return GPH_EARG;
+  { int rcs = flush_sync(e); if (rcs) return rcs; }
   GphTauArgs &A = e->tau;
   memset(&A, 0, sizeof A);
   A.ap = a->ap; A.son0 = a->son0; A.son1 = a->son1; A.isRoot = a->isRoot; A.num_aff = a->num_aff; A.mode = a->mode;
@@ -605,6 +622,7 @@ int gph_engine_tau_revert(gph_engine *e, int64_t first_conflict)
 int gph_engine_mixing_evaluate(gph_engine *e, double c, double *dataDelta)
 {
   if (!e || !e->initialized || !dataDelta) return GPH_ESTATE;
+  { int rcs = flush_sync(e); if (rcs) return rcs; }
   LAUNCH(e, 2, k_mix_eval, c);
   int rc = finish_kernel(e);
   if (rc) return rc;
@@ -684,6 +702,15 @@ int gph_engine_get_totals(gph_engine *e, double *cs, double *nc, double *ms, dou
 int gph_engine_synchronize(gph_engine *e, int32_t refresh, double *oldGen, double *newGen)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
+  if (!refresh) {
+    /* nothing is returned without a refresh: the pass is deferred into the next sweep kernel (one page
+     * round trip less per iteration); any other page-touching call runs it first */
+    e->sync_pending = true;
+    if (oldGen) *oldGen = 0.0;
+    if (newGen) *newGen = 0.0;
+    return 0;
+  }
+  { int rcs = flush_sync(e); if (rcs) return rcs; }
   LAUNCH(e, 8, k_sync, (int)refresh);
   int rc = finish_kernel(e);
   if (rc) return rc;
@@ -698,6 +725,7 @@ int gph_engine_synchronize(gph_engine *e, int32_t refresh, double *oldGen, doubl
 int gph_engine_check_all(gph_engine *e, int32_t *ok, double *sumData, double *sumGen)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
+  { int rcs = flush_sync(e); if (rcs) return rcs; }
   LAUNCH(e, 4, k_check, 0);
   int rc = finish_kernel(e);
   if (rc) return rc;
@@ -774,6 +802,7 @@ int gph_engine_hbm_bytes(gph_engine *e, double *bytes)
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int32_t append)
 {
   if (!e || !e->initialized || !path) return GPH_ESTATE;
+  { int rcs = flush_sync(e); if (rcs) return rcs; }
   const GphLayout &y = e->lay;
   std::vector<char> pages(e->pages_bytes), cond(withCond ? e->cond_bytes : 0);
   int rc = d2h(e, pages.data(), e->dev.pages, e->pages_bytes);

@@ -403,6 +403,8 @@ GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double f
   stage_in(D, g, D.pages, 1);
   GphRng rng;
   rng_load(rng);
+  /* flag 8: synchronizeEvents of the previous iteration (patch.c:3548), deferred into this kernel */
+  OUT(g, 15, (flags & 8) ? (double)synchronize_events() : 1.0);
   OUT(g, 0, 0.0); OUT(g, 1, 0.0); OUT(g, 2, 0.0); OUT(g, 3, 0.0); OUT(g, 4, 0.0);
   OUT(g, 5, 0.0); OUT(g, 6, 0.0); OUT(g, 7, 0.0); OUT(g, 12, 0.0);
   { STAMP_BEGIN(5); if ((flags & 1) && ftCoal > 0.0) sweep_internal(D, g, ftCoal, rng); STAMP_END(5); }
