@@ -163,6 +163,7 @@ struct gph_engine {
   void *allreduce_user = nullptr;
   uint32_t seedz = 0;
   bool loaded = false, seeded = false, model_set = false, initialized = false;
+  bool timing_pending = false; // HIP events of the last launch recorded, elapsed time not read yet
   bool sync_pending = false;   // synchronizeEvents of the finished iteration rides at the head of the next sweep kernel
   gph_counters counters = {0, 0, 0.0, 0};
   double last_ms[16] = {0};
@@ -278,9 +279,7 @@ static int upload_tables(gph_engine *e)
       hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, (e)->dev, bk_.j0, __VA_ARGS__); \
       HIPCHK(hipGetLastError()); } \
     HIPCHK(hipEventRecord((e)->ev1, (e)->stream)); \
-    HIPCHK(hipEventSynchronize((e)->ev1)); \
-    float ms_ = 0; HIPCHK(hipEventElapsedTime(&ms_, (e)->ev0, (e)->ev1)); (e)->last_ms[which] = ms_; \
-    (e)->last_which = (which); (e)->cls_launches[which] += 1; (e)->cls_ms[which] += ms_; } while (0)
+    (e)->last_which = (which); (e)->cls_launches[which] += 1; (e)->timing_pending = true; } while (0)   /* elapsed time is read in finish_kernel(), after the result copy has synchronised the stream */
 #endif
 
 // reduce the per-locus outputs (mode 0) or page statistics (mode 1) over local loci
@@ -313,6 +312,15 @@ static int finish_kernel(gph_engine *e)
 {
   int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
   if (rc) return rc;
+#ifndef GPH_HOSTEMU
+  if (e->timing_pending) {   /* the device-to-host copy above synchronised the stream: both events are complete */
+    float ms = 0;
+    e->timing_pending = false;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->last_ms[e->last_which] = ms;
+    e->cls_ms[e->last_which] += ms;
+  }
+#endif
   e->counters.evals += (int64_t)RSUM(e, 8);
   e->counters.eval_nodes += (int64_t)RSUM(e, 9);
   e->counters.eval_bytes += RSUM(e, 10);
