@@ -163,6 +163,7 @@ struct gph_engine {
   void *allreduce_user = nullptr;
   uint32_t seedz = 0;
   bool loaded = false, seeded = false, model_set = false, initialized = false;
+  uint64_t model_version = 1;  // bumped by set_model; the __constant__ copy is re-uploaded only when it is stale
   bool timing_pending = false; // HIP events of the last launch recorded, elapsed time not read yet
   bool sync_pending = false;   // synchronizeEvents of the finished iteration rides at the head of the next sweep kernel
   gph_counters counters = {0, 0, 0.0, 0};
@@ -262,8 +263,13 @@ static int d2h(gph_engine *e, void *h, const void *d, size_t n)
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
 }
+// the __constant__ tables hold the model of whichever engine uploaded last (several engines may share a
+// process); model versions are unique over all engines, so a stale copy is always detected
+static const gph_engine *g_tables_owner = nullptr;
+static uint64_t g_tables_version = 0;
 static int upload_tables(gph_engine *e)
 {
+  g_tables_owner = e; g_tables_version = e->model_version;
   HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lay), &e->lay, sizeof(GphLayout), 0, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_model), &e->model, sizeof(GphModel), 0, hipMemcpyHostToDevice, e->stream));
   return 0;
@@ -272,8 +278,7 @@ static int upload_tables(gph_engine *e)
 // locus with at most one pattern per lane (slots in decreasing P: longest wavefronts first), a second one
 // the rare loci with more (they also need the per-pattern terms array in LDS)
 #define LAUNCH(e, which, name, ...) do { \
-    HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_model), &(e)->model, sizeof(GphModel), 0, hipMemcpyHostToDevice, (e)->stream)); \
-    HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lay), &(e)->lay, sizeof(GphLayout), 0, hipMemcpyHostToDevice, (e)->stream)); \
+    if (g_tables_owner != (e) || g_tables_version != (e)->model_version) { int rcu_ = upload_tables(e); if (rcu_) return rcu_; } \
     HIPCHK(hipEventRecord((e)->ev0, (e)->stream)); \
     for (auto &bk_ : (e)->buckets) { \
       hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, (e)->dev, bk_.j0, __VA_ARGS__); \
@@ -394,6 +399,9 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
 void gph_engine_destroy(gph_engine *e)
 {
   if (!e) return;
+#ifndef GPH_HOSTEMU
+  if (g_tables_owner == e) g_tables_owner = nullptr;
+#endif
   dev_free(e->dev.pages); dev_free(e->dev.shadow); dev_free(e->dev.cond); dev_free((void *)e->dev.cond_off);
   dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
   dev_free(e->d_part); dev_free(e->d_red);
@@ -528,6 +536,7 @@ int gph_engine_set_model(gph_engine *e, const double *theta, const double *popAg
   for (int p = 0; p < e->cfg.K; p++) { e->model.theta[p] = theta[p]; e->model.thetaInv[p] = 1.0 / theta[p]; e->model.popAge[p] = popAge[p]; e->model.sampleAge[p] = sampleAge[p]; }
   for (int b = 0; b < e->cfg.B; b++) { e->model.migRate[b] = migRate[b]; e->model.bandStart[b] = bandStart[b]; e->model.bandEnd[b] = bandEnd[b]; }
   e->model_set = true;
+  { static uint64_t next_version = 2; e->model_version = next_version++; }
   return 0;
 }
 
