@@ -49,6 +49,7 @@ GPH_KERNEL(k_check, GphDev D, int j0, int unused) { (void)unused; kb_check(D, j0
 // ---------------------------------------------------------------- small elementwise / reduction kernels
 #define GPH_RED_BLOCKS 256
 #define GPH_RED_COLS 128   // >= 2K+2B and >= GPH_OUT_SLOTS
+static_assert(2 * GPH_CAP_K + 2 * GPH_CAP_B <= 64 && GPH_OUT_SLOTS <= 64, "the reduction kernels fold at most 64 columns");
 
 #ifndef GPH_HOSTEMU
 // UpdateTheta accepted: genLogLikelihood touch-up, GPhoCS.c:3084-3093 (one thread per locus)
