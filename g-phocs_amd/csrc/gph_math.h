@@ -31,9 +31,15 @@ __device__ __constant__ static const double gph_exp_c_d[8] = GPH_EXP_CONSTS;
 __device__ __constant__ static const uint64_t gph_exp_t_d[256] = GPH_EXP_TAB;
 __device__ __constant__ static const double gph_log_c_d[18] = GPH_LOG_CONSTS;
 __device__ __constant__ static const double gph_log_t_d[256] = GPH_LOG_TAB;
-#define GPH_EXPC gph_exp_c_d
+// The polynomial / reduction constants are READ from constant memory through a pointer the optimiser cannot
+// see through: otherwise every fp64 constant is folded into the instruction stream as two 32-bit scalar moves
+// per use (36 s_mov_b32 per log), and the scalar unit is the scarce issue slot of the chain kernels; as loads
+// the constants of one call arrive in a few wide s_load instructions.
+typedef __attribute__((address_space(4))) const double gph_cdbl;
+__device__ inline gph_cdbl *gph_opaque(gph_cdbl *p) { asm volatile("" : "+s"(p)); return p; }
+#define GPH_EXPC gph_opaque((gph_cdbl *)gph_exp_c_d)
 #define GPH_EXPT gph_exp_t_d
-#define GPH_LOGC gph_log_c_d
+#define GPH_LOGC gph_opaque((gph_cdbl *)gph_log_c_d)
 #define GPH_LOGT gph_log_t_d
 #else
 static const double gph_exp_c_h[8] = GPH_EXP_CONSTS;
@@ -59,8 +65,9 @@ GPH_MATH_FN double gph_asf64(uint64_t u) { union { double d; uint64_t u; } v; v.
 template <bool UNIFORM>
 GPH_MATH_FN double gph_exp_t(double x)
 {
-  const double InvLn2N = GPH_EXPC[0], Shift = GPH_EXPC[1], NegLn2hiN = GPH_EXPC[2], NegLn2loN = GPH_EXPC[3];
-  const double C2 = GPH_EXPC[4], C3 = GPH_EXPC[5], C4 = GPH_EXPC[6], C5 = GPH_EXPC[7];
+  const auto *EC = GPH_EXPC;
+  const double InvLn2N = EC[0], Shift = EC[1], NegLn2hiN = EC[2], NegLn2loN = EC[3];
+  const double C2 = EC[4], C3 = EC[5], C4 = EC[6], C5 = EC[7];
   uint64_t ix = gph_asu64(x);
   uint32_t abstop = (uint32_t)(ix >> 52) & 0x7ff;
   if (abstop - 0x3c9u > 0x3eu) {
@@ -124,15 +131,16 @@ GPH_MATH_FN double gph_exp_u(double x) { return gph_exp_t<true>(x); }
 template <bool UNIFORM>
 GPH_MATH_FN double gph_log_t(double x)
 {
-  const double Ln2hi = GPH_LOGC[0], Ln2lo = GPH_LOGC[1];
-  const double A0 = GPH_LOGC[2], A1 = GPH_LOGC[3], A2 = GPH_LOGC[4], A3 = GPH_LOGC[5], A4 = GPH_LOGC[6];
+  const auto *LC = GPH_LOGC;
+  const double Ln2hi = LC[0], Ln2lo = LC[1];
+  const double A0 = LC[2], A1 = LC[3], A2 = LC[4], A3 = LC[5], A4 = LC[6];
   uint64_t ix = gph_asu64(x);
   uint32_t top = (uint32_t)(ix >> 48);
   if (ix - 0x3fee000000000000ull <= 0x308ffffffffffull) {
     /* x within [1 - 2^-4, 1 + 0x1.09p-4): dedicated polynomial, log(1) == 0 exactly */
-    const double B0 = GPH_LOGC[7], B1 = GPH_LOGC[8], B2 = GPH_LOGC[9], B3 = GPH_LOGC[10], B4 = GPH_LOGC[11],
-                 B5 = GPH_LOGC[12], B6 = GPH_LOGC[13], B7 = GPH_LOGC[14], B8 = GPH_LOGC[15], B9 = GPH_LOGC[16],
-                 B10 = GPH_LOGC[17];
+    const double B0 = LC[7], B1 = LC[8], B2 = LC[9], B3 = LC[10], B4 = LC[11],
+                 B5 = LC[12], B6 = LC[13], B7 = LC[14], B8 = LC[15], B9 = LC[16],
+                 B10 = LC[17];
     if (ix == 0x3ff0000000000000ull) return 0.0;
     double r = x - 1.0;
     double q1 = __builtin_fma(r, B2, B1);
