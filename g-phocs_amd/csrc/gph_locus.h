@@ -240,6 +240,9 @@ GPH_DEV double gph_div3(double a)
 
 // ---------------------------------------------------------------- RNG
 // rndu, utils.c:498-513: unsigned 32-bit Wichmann-Hill without the sign fix-up
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ static const double gph_rng_c_d[8] = {1.0 / 30269.0, 1.0 / 30307.0, 1.0 / 30323.0, 30269.0, 30307.0, 30323.0, 0.0, 0.0};
+#endif
 // The locus' generator state (RndCtx slot, utils.c:401) lives in registers while a kernel works on
 // the locus: loaded from the page after stage-in, stored back before stage-out.
 struct GphRng { uint32_t x, y, z; };
@@ -255,18 +258,20 @@ GPH_DEV double l_rndu(GphRng &g)
   g.x = x;
   g.y = y;
   g.z = z;
-#ifdef GPH_HOSTEMU
+#if defined(GPH_HOSTEMU) || !defined(__HIP_DEVICE_COMPILE__)   /* host form (and the host pass of hipcc) */
   r = x / 30269.0 + y / 30307.0 + z / 30323.0;
 #else
   /* IEEE-exact quotients without the 14-instruction divide expansion: for a 32-bit integer x
    * and d in {30269, 30307, 30323}, q = fma(fma(-q0, d, x), 1/d, q0) with q0 = x * RN(1/d)
    * equals RN(x / d) for ALL 2^32 values of x (exhaustively verified, tools/verify_rng_div.c) */
   {
-    const double rx = 1.0 / 30269.0, ry = 1.0 / 30307.0, rz = 1.0 / 30323.0;
+    /* the six constants come from constant memory in one scalar load (see gph_math.h: GPH_EXPC) */
+    const gph_cdbl *RC = gph_opaque((gph_cdbl *)gph_rng_c_d);
+    const double rx = RC[0], ry = RC[1], rz = RC[2], mx = RC[3], my = RC[4], mz = RC[5];
     double xd = (double)x, yd = (double)y, zd = (double)z, q;
-    q = xd * rx; double qx = __builtin_fma(__builtin_fma(-q, 30269.0, xd), rx, q);
-    q = yd * ry; double qy = __builtin_fma(__builtin_fma(-q, 30307.0, yd), ry, q);
-    q = zd * rz; double qz = __builtin_fma(__builtin_fma(-q, 30323.0, zd), rz, q);
+    q = xd * rx; double qx = __builtin_fma(__builtin_fma(-q, mx, xd), rx, q);
+    q = yd * ry; double qy = __builtin_fma(__builtin_fma(-q, my, yd), ry, q);
+    q = zd * rz; double qz = __builtin_fma(__builtin_fma(-q, mz, zd), rz, q);
     r = qx + qy + qz;
   }
 #endif
