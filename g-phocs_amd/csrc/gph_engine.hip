@@ -23,8 +23,6 @@ GphModel g_model;
 #define GPH_SWEEP_ATTR
 #define GPH_BLK gph_blk
 #else
-__constant__ GphLayout g_lay;
-__constant__ GphModel g_model;
 #define GPH_KERNEL(name, ...) __global__ __launch_bounds__(GPH_WAVE) void name(__VA_ARGS__)
 #define GPH_BLK ((int)blockIdx.x)
 // 5 waves per SIMD (<= 96 VGPRs): the sweep is a latency-bound dependent chain per wave, LDS allows 20 waves/CU
@@ -36,15 +34,15 @@ __constant__ GphModel g_model;
 #endif
 
 // j0 = first slot of the launch group (see GphDev)
-GPH_KERNEL(k_init, GphDev D, int j0, uint32_t seedz, const double *mutRate) { kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0); }
-GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphDev D, int j0, int flags, double ftCoal, double ftMig) { kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
-GPH_KERNEL(k_tau_eval, GphDev D, int j0, GphTauArgs A) { kb_tau_eval(D, j0 + GPH_BLK, A); }
-GPH_KERNEL(k_tau_commit, GphDev D, int j0, GphTauArgs A) { kb_tau_commit(D, j0 + GPH_BLK, A); }
-GPH_KERNEL(k_tau_revert, GphDev D, int j0, long long limit) { kb_tau_revert(D, j0 + GPH_BLK, limit); }
-GPH_KERNEL(k_mix_eval, GphDev D, int j0, double c) { kb_mix_eval(D, j0 + GPH_BLK, c); }
-GPH_KERNEL(k_mix_commit, GphDev D, int j0, double c, double lnc) { kb_mix_commit(D, j0 + GPH_BLK, c, lnc); }
-GPH_KERNEL(k_sync, GphDev D, int j0, int refresh) { kb_sync(D, j0 + GPH_BLK, refresh); }
-GPH_KERNEL(k_check, GphDev D, int j0, int unused) { (void)unused; kb_check(D, j0 + GPH_BLK); }
+GPH_KERNEL(k_init, GphKargs KA, GphDev D, int j0, uint32_t seedz, const double *mutRate) { kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0); }
+GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphKargs KA, GphDev D, int j0, int flags, double ftCoal, double ftMig) { kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
+GPH_KERNEL(k_tau_eval, GphKargs KA, GphDev D, int j0, GphTauArgs A) { kb_tau_eval(D, j0 + GPH_BLK, A); }
+GPH_KERNEL(k_tau_commit, GphKargs KA, GphDev D, int j0, GphTauArgs A) { kb_tau_commit(D, j0 + GPH_BLK, A); }
+GPH_KERNEL(k_tau_revert, GphKargs KA, GphDev D, int j0, long long limit) { kb_tau_revert(D, j0 + GPH_BLK, limit); }
+GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, double c) { kb_mix_eval(D, j0 + GPH_BLK, c); }
+GPH_KERNEL(k_mix_commit, GphKargs KA, GphDev D, int j0, double c, double lnc) { kb_mix_commit(D, j0 + GPH_BLK, c, lnc); }
+GPH_KERNEL(k_sync, GphKargs KA, GphDev D, int j0, int refresh) { kb_sync(D, j0 + GPH_BLK, refresh); }
+GPH_KERNEL(k_check, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; kb_check(D, j0 + GPH_BLK); }
 
 // ---------------------------------------------------------------- small elementwise / reduction kernels
 #define GPH_RED_BLOCKS 256
@@ -53,7 +51,7 @@ static_assert(2 * GPH_CAP_K + 2 * GPH_CAP_B <= 64 && GPH_OUT_SLOTS <= 64, "the r
 
 #ifndef GPH_HOSTEMU
 // UpdateTheta accepted: genLogLikelihood touch-up, GPhoCS.c:3084-3093 (one thread per locus)
-__global__ void k_apply_theta(GphDev D, int pop, double lnc, double inv_diff)
+__global__ void k_apply_theta(GphKargs KA, GphDev D, int pop, double lnc, double inv_diff)
 {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= D.L) return;
@@ -64,7 +62,7 @@ __global__ void k_apply_theta(GphDev D, int pop, double lnc, double inv_diff)
   fs[FS_GENLNL] -= (lnc * nc + inv_diff * cs);
 }
 // UpdateMigRates accepted: GPhoCS.c:3192-3200
-__global__ void k_apply_migrate(GphDev D, int band, double lnc, double rate_diff)
+__global__ void k_apply_migrate(GphKargs KA, GphDev D, int band, double lnc, double rate_diff)
 {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= D.L) return;
@@ -164,7 +162,6 @@ struct gph_engine {
   void *allreduce_user = nullptr;
   uint32_t seedz = 0;
   bool loaded = false, seeded = false, model_set = false, initialized = false;
-  uint64_t model_version = 1;  // bumped by set_model; the __constant__ copy is re-uploaded only when it is stale
   bool timing_pending = false; // HIP events of the last launch recorded, elapsed time not read yet
   bool sync_pending = false;   // synchronizeEvents of the finished iteration rides at the head of the next sweep kernel
   gph_counters counters = {0, 0, 0.0, 0};
@@ -245,9 +242,9 @@ static int h2d(gph_engine *, void *d, const void *h, size_t n) { memcpy(d, h, n)
 static int d2h(gph_engine *, void *h, const void *d, size_t n) { memcpy(h, d, n); return 0; }
 static int upload_tables(gph_engine *e) { g_lay = e->lay; g_model = e->model; return 0; }
 #define LAUNCH(e, which, name, ...) do { g_model = (e)->model; \
-    g_lay = (e)->lay; \
+    g_lay = (e)->lay; GphKargs ka_; ka_.model = (e)->model; ka_.lay = (e)->lay; \
     for (auto &bk_ : (e)->buckets) { (e)->lds.assign(bk_.lds_bytes + 8 * (e)->lay.Pmax + 64, 0); /* the host form keeps per-pattern terms for every P */ gph_sm = (e)->lds.data(); \
-      for (int b_ = 0; b_ < bk_.count; b_++) name(b_, (e)->dev, bk_.j0, __VA_ARGS__); } \
+      for (int b_ = 0; b_ < bk_.count; b_++) name(b_, ka_, (e)->dev, bk_.j0, __VA_ARGS__); } \
     (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
 #else
 static int dev_alloc(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess ? 0 : GPH_EHIP; }
@@ -264,25 +261,16 @@ static int d2h(gph_engine *e, void *h, const void *d, size_t n)
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
 }
-// the __constant__ tables hold the model of whichever engine uploaded last (several engines may share a
-// process); model versions are unique over all engines, so a stale copy is always detected
-static const gph_engine *g_tables_owner = nullptr;
-static uint64_t g_tables_version = 0;
-static int upload_tables(gph_engine *e)
-{
-  g_tables_owner = e; g_tables_version = e->model_version;
-  HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lay), &e->lay, sizeof(GphLayout), 0, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_model), &e->model, sizeof(GphModel), 0, hipMemcpyHostToDevice, e->stream));
-  return 0;
-}
+// model + layout tables are a by-value kernel argument (GphKargs): nothing to upload
+static int upload_tables(gph_engine *) { return 0; }
 // timed launch: HIP events on the engine's own stream bracket the kernel.  One dispatch covers every
 // locus with at most one pattern per lane (slots in decreasing P: longest wavefronts first), a second one
 // the rare loci with more (they also need the per-pattern terms array in LDS)
 #define LAUNCH(e, which, name, ...) do { \
-    if (g_tables_owner != (e) || g_tables_version != (e)->model_version) { int rcu_ = upload_tables(e); if (rcu_) return rcu_; } \
+    GphKargs ka_; ka_.model = (e)->model; ka_.lay = (e)->lay; \
     HIPCHK(hipEventRecord((e)->ev0, (e)->stream)); \
     for (auto &bk_ : (e)->buckets) { \
-      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, (e)->dev, bk_.j0, __VA_ARGS__); \
+      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
       HIPCHK(hipGetLastError()); } \
     HIPCHK(hipEventRecord((e)->ev1, (e)->stream)); \
     (e)->last_which = (which); (e)->cls_launches[which] += 1; (e)->timing_pending = true; } while (0)   /* elapsed time is read in finish_kernel(), after the result copy has synchronised the stream */
@@ -400,9 +388,6 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
 void gph_engine_destroy(gph_engine *e)
 {
   if (!e) return;
-#ifndef GPH_HOSTEMU
-  if (g_tables_owner == e) g_tables_owner = nullptr;
-#endif
   dev_free(e->dev.pages); dev_free(e->dev.shadow); dev_free(e->dev.cond); dev_free((void *)e->dev.cond_off);
   dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
   dev_free(e->d_part); dev_free(e->d_red);
@@ -537,7 +522,6 @@ int gph_engine_set_model(gph_engine *e, const double *theta, const double *popAg
   for (int p = 0; p < e->cfg.K; p++) { e->model.theta[p] = theta[p]; e->model.thetaInv[p] = 1.0 / theta[p]; e->model.popAge[p] = popAge[p]; e->model.sampleAge[p] = sampleAge[p]; }
   for (int b = 0; b < e->cfg.B; b++) { e->model.migRate[b] = migRate[b]; e->model.bandStart[b] = bandStart[b]; e->model.bandEnd[b] = bandEnd[b]; }
   e->model_set = true;
-  { static uint64_t next_version = 2; e->model_version = next_version++; }
   return 0;
 }
 
@@ -674,7 +658,8 @@ int gph_engine_apply_theta(gph_engine *e, int32_t pop, double lnc, double thetao
 #else
   int rc = upload_tables(e);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_apply_theta, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, e->dev, (int)pop, lnc, inv_diff);
+  { GphKargs ka; ka.model = e->model; ka.lay = e->lay;
+    hipLaunchKernelGGL(k_apply_theta, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, ka, e->dev, (int)pop, lnc, inv_diff); }
   HIPCHK(hipGetLastError());
 #endif
   return 0;
@@ -693,7 +678,8 @@ int gph_engine_apply_migrate(gph_engine *e, int32_t band, double lnc, double old
 #else
   int rc = upload_tables(e);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_apply_migrate, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, e->dev, (int)band, lnc, diff);
+  { GphKargs ka; ka.model = e->model; ka.lay = e->lay;
+    hipLaunchKernelGGL(k_apply_migrate, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, ka, e->dev, (int)band, lnc, diff); }
   HIPCHK(hipGetLastError());
 #endif
   return 0;

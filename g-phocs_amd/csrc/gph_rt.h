@@ -55,8 +55,9 @@ extern GphModel g_model;
 #define RFL(x) __builtin_amdgcn_readfirstlane((int)(x))
 extern __shared__ __attribute__((aligned(16))) char gph_sm[];   // dynamic part: sequence block + per-pattern terms
 __shared__ GphLds gph_lds;   // static part: the locus image (gph_types.h); this header is included by one TU only
-extern __constant__ GphLayout g_lay;
-extern __constant__ GphModel g_model;
+typedef __attribute__((address_space(4))) const GphKargs gph_ckargs;
+#define g_model (((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->model)
+#define g_lay (((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->lay)
 #endif
 
 #ifdef GPH_HOSTEMU

@@ -67,6 +67,11 @@ struct GphLayout {
   int32_t Pmax;            // max phased patterns of any locus on this device
   int32_t lds_bytes;       // largest dynamic-LDS allocation of a launch (sequence block [+ terms])
 };
+// model + layout tables travel BY VALUE as the first argument of every kernel: in the kernarg segment every
+// access is one scalar load off the (always live) kernarg pointer -- a __constant__ symbol costs a
+// pc-relative address computation (3 scalar instructions) per access and an upload per change
+struct GphKargs { GphModel model; GphLayout lay; };
+
 // Sequence block of one locus (HBM block format == dynamic-LDS image), sized by the locus' OWN number of
 // phased patterns P: leaf codes u8[P][n] | phases u8[P] | (pad to 4) counts i32[P] | (pad to 16);
 // behind it, for loci with more than one pattern per lane only, f64[P] terms of the root reduction
