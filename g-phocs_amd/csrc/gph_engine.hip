@@ -128,7 +128,7 @@ __global__ void k_reduce_final(int ncols, const double *part, double *red)
 
 #ifndef GPH_HOSTEMU
 // parity probe: the device's exp/log (gph_math.h) and its native sqrt / divide / floor
-__global__ void k_debug_math(const double *x, const double *y, int n, double *o)
+__global__ void k_debug_math(GphKargs KA, const double *x, const double *y, int n, double *o)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -162,6 +162,7 @@ struct gph_engine {
   void *allreduce_user = nullptr;
   uint32_t seedz = 0;
   bool loaded = false, seeded = false, model_set = false, initialized = false;
+  GphKargs ka;                 // first argument of every kernel: model, layout, math constants, table addresses
   bool timing_pending = false; // HIP events of the last launch recorded, elapsed time not read yet
   bool sync_pending = false;   // synchronizeEvents of the finished iteration rides at the head of the next sweep kernel
   gph_counters counters = {0, 0, 0.0, 0};
@@ -242,7 +243,7 @@ static int h2d(gph_engine *, void *d, const void *h, size_t n) { memcpy(d, h, n)
 static int d2h(gph_engine *, void *h, const void *d, size_t n) { memcpy(h, d, n); return 0; }
 static int upload_tables(gph_engine *e) { g_lay = e->lay; g_model = e->model; return 0; }
 #define LAUNCH(e, which, name, ...) do { g_model = (e)->model; \
-    g_lay = (e)->lay; GphKargs ka_; ka_.model = (e)->model; ka_.lay = (e)->lay; \
+    g_lay = (e)->lay; GphKargs &ka_ = (e)->ka; ka_.model = (e)->model; ka_.lay = (e)->lay; \
     for (auto &bk_ : (e)->buckets) { (e)->lds.assign(bk_.lds_bytes + 8 * (e)->lay.Pmax + 64, 0); /* the host form keeps per-pattern terms for every P */ gph_sm = (e)->lds.data(); \
       for (int b_ = 0; b_ < bk_.count; b_++) name(b_, ka_, (e)->dev, bk_.j0, __VA_ARGS__); } \
     (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
@@ -267,7 +268,7 @@ static int upload_tables(gph_engine *) { return 0; }
 // locus with at most one pattern per lane (slots in decreasing P: longest wavefronts first), a second one
 // the rare loci with more (they also need the per-pattern terms array in LDS)
 #define LAUNCH(e, which, name, ...) do { \
-    GphKargs ka_; ka_.model = (e)->model; ka_.lay = (e)->lay; \
+    GphKargs &ka_ = (e)->ka; ka_.model = (e)->model; ka_.lay = (e)->lay; \
     HIPCHK(hipEventRecord((e)->ev0, (e)->stream)); \
     for (auto &bk_ : (e)->buckets) { \
       hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
@@ -346,6 +347,28 @@ static int flush_sync(gph_engine *e)
   return 0;
 }
 
+// exp/log/rndu constants of gph_math.h / gph_locus.h (GphKargs::mathc) and, on the device, the addresses of the two
+// 128-entry libm tables
+static void fill_math_constants(GphKargs &ka)
+{
+  const double ec[8] = GPH_EXP_CONSTS, lc[18] = GPH_LOG_CONSTS;
+  const double rc[6] = {1.0 / 30269.0, 1.0 / 30307.0, 1.0 / 30323.0, 30269.0, 30307.0, 30323.0};
+  memcpy(&ka.mathc[0], ec, sizeof ec);
+  memcpy(&ka.mathc[8], lc, sizeof lc);
+  memcpy(&ka.mathc[26], rc, sizeof rc);
+}
+#ifndef GPH_HOSTEMU
+static int fill_math_tables(GphKargs &ka)
+{
+  void *p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(gph_log_t_d)) != hipSuccess) return 1;
+  ka.log_t = (const double *)p;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(gph_exp_t_d)) != hipSuccess) return 1;
+  ka.exp_t = (const uint64_t *)p;
+  return 0;
+}
+#endif
+
 // ---------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -370,11 +393,18 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
   e->cfg.bandSrc = e->bandSrc.data();
   e->cfg.bandTgt = e->bandTgt.data();
   memset(&e->dev, 0, sizeof e->dev);
+  memset(&e->ka, 0, sizeof e->ka);
+  fill_math_constants(e->ka);
   build_model_static(e);
 #ifndef GPH_HOSTEMU
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) {
     fprintf(stderr, "gphocs_hip: no usable HIP device %d (found %d) -- this library has no CPU path\n", cfg->device, ndev);
+    delete e;
+    return GPH_EHIP;
+  }
+  if (hipSetDevice(cfg->device) != hipSuccess || fill_math_tables(e->ka)) {
+    fprintf(stderr, "gphocs_hip: cannot resolve the device math tables\n");
     delete e;
     return GPH_EHIP;
   }
@@ -658,7 +688,7 @@ int gph_engine_apply_theta(gph_engine *e, int32_t pop, double lnc, double thetao
 #else
   int rc = upload_tables(e);
   if (rc) return rc;
-  { GphKargs ka; ka.model = e->model; ka.lay = e->lay;
+  { GphKargs &ka = e->ka; ka.model = e->model; ka.lay = e->lay;
     hipLaunchKernelGGL(k_apply_theta, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, ka, e->dev, (int)pop, lnc, inv_diff); }
   HIPCHK(hipGetLastError());
 #endif
@@ -678,7 +708,7 @@ int gph_engine_apply_migrate(gph_engine *e, int32_t band, double lnc, double old
 #else
   int rc = upload_tables(e);
   if (rc) return rc;
-  { GphKargs ka; ka.model = e->model; ka.lay = e->lay;
+  { GphKargs &ka = e->ka; ka.model = e->model; ka.lay = e->lay;
     hipLaunchKernelGGL(k_apply_migrate, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, ka, e->dev, (int)band, lnc, diff); }
   HIPCHK(hipGetLastError());
 #endif
@@ -787,7 +817,11 @@ int gph_debug_math(const double *x, const double *y, int32_t n, double *out, int
   HIPCHK(hipMalloc((void **)&dout, sizeof(double) * 5 * n));
   HIPCHK(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dy, y, sizeof(double) * n, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dy, (int)n, dout);
+  GphKargs ka;
+  memset(&ka, 0, sizeof ka);
+  fill_math_constants(ka);
+  if (fill_math_tables(ka)) return GPH_EHIP;
+  hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, ka, dx, dy, (int)n, dout);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, dout, sizeof(double) * 5 * n, hipMemcpyDeviceToHost));
   (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);

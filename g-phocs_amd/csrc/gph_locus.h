@@ -240,9 +240,6 @@ GPH_DEV double gph_div3(double a)
 
 // ---------------------------------------------------------------- RNG
 // rndu, utils.c:498-513: unsigned 32-bit Wichmann-Hill without the sign fix-up
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __constant__ static const double gph_rng_c_d[8] = {1.0 / 30269.0, 1.0 / 30307.0, 1.0 / 30323.0, 30269.0, 30307.0, 30323.0, 0.0, 0.0};
-#endif
 // The locus' generator state (RndCtx slot, utils.c:401) lives in registers while a kernel works on
 // the locus: loaded from the page after stage-in, stored back before stage-out.
 struct GphRng { uint32_t x, y, z; };
@@ -265,8 +262,8 @@ GPH_DEV double l_rndu(GphRng &g)
    * and d in {30269, 30307, 30323}, q = fma(fma(-q0, d, x), 1/d, q0) with q0 = x * RN(1/d)
    * equals RN(x / d) for ALL 2^32 values of x (exhaustively verified, tools/verify_rng_div.c) */
   {
-    /* the six constants come from constant memory in one scalar load (see gph_math.h: GPH_EXPC) */
-    const gph_cdbl *RC = gph_opaque((gph_cdbl *)gph_rng_c_d);
+    /* the six constants come from the kernel-argument segment in one scalar load (see gph_math.h) */
+    const gph_cdbl *RC = GPH_RNGC;
     const double rx = RC[0], ry = RC[1], rz = RC[2], mx = RC[3], my = RC[4], mz = RC[5];
     double xd = (double)x, yd = (double)y, zd = (double)z, q;
     q = xd * rx; double qx = __builtin_fma(__builtin_fma(-q, mx, xd), rx, q);

@@ -15,6 +15,7 @@
 #pragma once
 #include <stdint.h>
 #include "gph_libm_tables.h"
+#include "gph_types.h"
 
 #ifdef __HIPCC__
 #define GPH_MATH_FN __host__ __device__ inline
@@ -26,21 +27,24 @@
 
 // tables live in constant memory: the chain logic indexes them wave-uniformly (scalar
 // loads); the per-pattern log() in the root reduction gathers through the vector L1
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __constant__ static const double gph_exp_c_d[8] = GPH_EXP_CONSTS;
+#ifdef __HIPCC__   /* both passes: the host side takes the tables' device addresses (hipGetSymbolAddress) */
 __device__ __constant__ static const uint64_t gph_exp_t_d[256] = GPH_EXP_TAB;
-__device__ __constant__ static const double gph_log_c_d[18] = GPH_LOG_CONSTS;
 __device__ __constant__ static const double gph_log_t_d[256] = GPH_LOG_TAB;
-// The polynomial / reduction constants are READ from constant memory through a pointer the optimiser cannot
-// see through: otherwise every fp64 constant is folded into the instruction stream as two 32-bit scalar moves
-// per use (36 s_mov_b32 per log), and the scalar unit is the scarce issue slot of the chain kernels; as loads
-// the constants of one call arrive in a few wide s_load instructions.
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// The polynomial / reduction constants and the table base addresses are READ from the kernel-argument segment
+// (GphKargs, first argument of every kernel): a compile-time constant would be folded into the instruction stream as
+// two 32-bit scalar moves per use (36 s_mov_b32 per log) and a __constant__ symbol costs a pc-relative (GOT) address
+// computation per access, while the scalar unit is the scarce issue slot of the chain kernels; off the kernarg
+// pointer the constants of one call arrive in a few wide scalar loads.
 typedef __attribute__((address_space(4))) const double gph_cdbl;
-__device__ inline gph_cdbl *gph_opaque(gph_cdbl *p) { asm volatile("" : "+s"(p)); return p; }
-#define GPH_EXPC gph_opaque((gph_cdbl *)gph_exp_c_d)
-#define GPH_EXPT gph_exp_t_d
-#define GPH_LOGC gph_opaque((gph_cdbl *)gph_log_c_d)
-#define GPH_LOGT gph_log_t_d
+typedef __attribute__((address_space(4))) const uint64_t gph_cu64;
+#define GPH_KA ((__attribute__((address_space(4))) const GphKargs *)__builtin_amdgcn_kernarg_segment_ptr())
+#define GPH_EXPC (&GPH_KA->mathc[0])
+#define GPH_LOGC (&GPH_KA->mathc[8])
+#define GPH_RNGC (&GPH_KA->mathc[26])
+#define GPH_EXPT ((gph_cu64 *)GPH_KA->exp_t)
+#define GPH_LOGT ((gph_cdbl *)GPH_KA->log_t)
 #else
 static const double gph_exp_c_h[8] = GPH_EXP_CONSTS;
 static const uint64_t gph_exp_t_h[256] = GPH_EXP_TAB;

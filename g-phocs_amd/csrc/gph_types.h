@@ -70,7 +70,15 @@ struct GphLayout {
 // model + layout tables travel BY VALUE as the first argument of every kernel: in the kernarg segment every
 // access is one scalar load off the (always live) kernarg pointer -- a __constant__ symbol costs a
 // pc-relative address computation (3 scalar instructions) per access and an upload per change
-struct GphKargs { GphModel model; GphLayout lay; };
+struct GphKargs {
+  GphModel model;
+  GphLayout lay;
+  // exp() / log() / rndu() constants (gph_math.h, gph_libm_tables.h): [0..7] exp, [8..25] log, [26..31] 1/m and m of
+  // the three Wichmann-Hill streams; and the device addresses of the two 128-entry libm tables
+  double mathc[32];
+  const double *log_t;
+  const uint64_t *exp_t;
+};
 
 // Sequence block of one locus (HBM block format == dynamic-LDS image), sized by the locus' OWN number of
 // phased patterns P: leaf codes u8[P][n] | phases u8[P] | (pad to 4) counts i32[P] | (pad to 16);
