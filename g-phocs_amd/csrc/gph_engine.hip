@@ -213,9 +213,9 @@ static void build_model_static(gph_engine *e)
   const gph_config &c = e->cfg;
   memset(&m, 0, sizeof m);
   for (int p = 0; p < c.K; p++) {
-    m.popFather[p] = (int16_t)e->popFather[p];
-    m.popSon0[p] = (int16_t)e->popSon0[p];
-    m.popSon1[p] = (int16_t)e->popSon1[p];
+    m.popFather[p] = e->popFather[p];
+    m.popSon0[p] = e->popSon0[p];
+    m.popSon1[p] = e->popSon1[p];
     uint32_t mask = 0;
     for (int d = 0; d < c.K; d++) {           // isAncestralTo, self-inclusive (MCMCcontrol.c:851,977,1015-1024)
       int x = d;
@@ -224,15 +224,15 @@ static void build_model_static(gph_engine *e)
     m.isAnc[p] = mask;
   }
   int cum = 0;
-  for (int p = 0; p < c.Kc; p++) { m.samplesPerPop[p] = (int16_t)e->samplesPerPop[p]; cum += e->samplesPerPop[p]; m.cumSamples[p] = cum; }
-  for (int b = 0; b < c.B; b++) { m.bandSrc[b] = (int16_t)e->bandSrc[b]; m.bandTgt[b] = (int16_t)e->bandTgt[b]; }
+  for (int p = 0; p < c.Kc; p++) { m.samplesPerPop[p] = e->samplesPerPop[p]; cum += e->samplesPerPop[p]; m.cumSamples[p] = cum; }
+  for (int b = 0; b < c.B; b++) { m.bandSrc[b] = e->bandSrc[b]; m.bandTgt[b] = e->bandTgt[b]; }
   // populationPostOrder(rootPop), patch.c:1936-1951
   std::vector<int> order;
   struct Rec { static void go(gph_engine *e, int pop, std::vector<int> &o) {
     if (pop >= e->cfg.Kc) { go(e, e->popSon0[pop], o); go(e, e->popSon1[pop], o); }
     o.push_back(pop); } };
   Rec::go(e, c.rootPop, order);
-  for (size_t i = 0; i < order.size(); i++) m.postOrder[i] = (int16_t)order[i];
+  for (size_t i = 0; i < order.size(); i++) m.postOrder[i] = order[i];
 }
 
 // ---------------------------------------------------------------- runtime shim
@@ -611,8 +611,8 @@ int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result
   A.tauold = a->tauold; A.taunew = a->taunew; A.taub0 = a->taub0; A.taub1 = a->taub1;
   A.taufactor0 = a->taufactor0; A.taufactor1 = a->taufactor1;
   for (int i = 0; i < a->num_aff; i++) {
-    A.aff_bands[i] = (int16_t)a->aff_bands[i];
-    A.start_or_end[i] = (int16_t)a->start_or_end[i];
+    A.aff_bands[i] = a->aff_bands[i];
+    A.start_or_end[i] = a->start_or_end[i];
     A.new_band_ages[i] = a->new_band_ages[i];
   }
   LAUNCH(e, 1, k_tau_eval, A);

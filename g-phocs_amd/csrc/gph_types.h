@@ -40,9 +40,11 @@ struct GphModel {
   double thetaInv[GPH_MAXK];           // RN(1/theta), host division: see gph_div_theta()
   double migRate[GPH_MAXB], bandStart[GPH_MAXB], bandEnd[GPH_MAXB];
   uint32_t isAnc[GPH_MAXK];            // bit d of isAnc[a]: a is ancestral to (or is) d
-  int16_t popFather[GPH_MAXK], popSon0[GPH_MAXK], popSon1[GPH_MAXK], samplesPerPop[GPH_MAXK];
-  int16_t bandSrc[GPH_MAXB], bandTgt[GPH_MAXB];
-  int16_t postOrder[GPH_MAXK];         // populationPostOrder(rootPop), patch.c:1936
+  // 32-bit entries: a scalar load cannot fetch 16 bits, and a 16-bit table would be read with vector loads
+  // (a VMEM round trip on the chain's critical path for a wave-uniform value)
+  int32_t popFather[GPH_MAXK], popSon0[GPH_MAXK], popSon1[GPH_MAXK], samplesPerPop[GPH_MAXK];
+  int32_t bandSrc[GPH_MAXB], bandTgt[GPH_MAXB];
+  int32_t postOrder[GPH_MAXK];         // populationPostOrder(rootPop), patch.c:1936
   int32_t cumSamples[GPH_MAXK];
 };
 
@@ -183,7 +185,7 @@ static_assert(GPH_CAP_E <= 255, "event ids are stored in 8 bits (s_dev)");
 struct GphTauArgs {
   int32_t ap, son0, son1, isRoot, num_aff, mode;   // mode 1 = UpdateSampleAge (GPhoCS.c:4006)
   double tauold, taunew, taub0, taub1, taufactor0, taufactor1;
-  int16_t aff_bands[GPH_MAXB * 2];
-  int16_t start_or_end[GPH_MAXB * 2];
+  int32_t aff_bands[GPH_MAXB * 2];     // 32-bit: scalar loads (see GphModel)
+  int32_t start_or_end[GPH_MAXB * 2];
   double new_band_ages[GPH_MAXB * 2];
 };
