@@ -43,7 +43,9 @@ extern GphModel g_model;
 #define GPH_DEVHOT __device__ __attribute__((always_inline)) inline
 #endif
 #define GPH_LDS __attribute__((address_space(3)))
-#define GPH_LANE ((int)threadIdx.x)
+// lane id recomputed where it is used (2 VALU) instead of threadIdx.x kept alive in a VGPR through the whole
+// kernel (the register allocator spilled it to scratch: a memory round trip per use); workgroup = one wave
+#define GPH_LANE ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
 #define GPH_NLANES GPH_WAVE
 #define GPH_SYNC() __syncthreads()
 // hand-off between lanes of the SAME wavefront (the only kind there is: one wave per workgroup).
