@@ -218,7 +218,12 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate)
 GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune, GphRng &rng)
 {
   int pop, inode, i, son, mig, acc = 0;
-  double t, tnew, lnacc, lnLd, dgen, tb0, tb1, dData = 0, dLog = 0;
+  double t, tnew, lnacc, lnLd, dgen, tb0, tb1;
+  /* the accumulators and the step size live in LDS scratch, not in registers that stay allocated (and get
+   * spilled) across the whole sweep: they are touched once per proposal */
+  sf64(&GphLds::s_cntf, 2, 0.0);
+  sf64(&GphLds::s_cntf, 3, 0.0);
+  sf64(&GphLds::s_cntf, 7, finetune);
   for (inode = g_lay.n; inode < g_lay.N; inode++) {
     const GphNodeS me = ld_node(inode);
     t = me.age;
@@ -235,7 +240,7 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune, GphRng &rng
       if (mig >= 0) tb0 = gmax2(tb0, MAGE(mig));
       else tb0 = gmax2(tb0, AGE(son));
     }
-    tnew = t + finetune * l_rnd2normal8(rng);
+    tnew = t + gf64(&GphLds::s_cntf, 7) * l_rnd2normal8(rng);
     tnew = l_reflect(tnew, tb0, tb1);
     if (UNI(fabs(tnew - t) < 1e-15)) { acc++; continue; }
     lik_adjust_age(inode, tnew);
@@ -247,8 +252,8 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune, GphRng &rng
     if (UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc))) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
-      dData += lnLd;
-      dLog += (dgen + lnLd) / D.Ltot;
+      sf64(&GphLds::s_cntf, 2, gf64(&GphLds::s_cntf, 2) + lnLd);
+      sf64(&GphLds::s_cntf, 3, gf64(&GphLds::s_cntf, 3) + (dgen + lnLd) / D.Ltot);
       accept_event_chain_changes(0);
       lik_reset_saved();
     } else {
@@ -257,8 +262,8 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune, GphRng &rng
     }
   }
   OUT(g, 0, acc);
-  OUT(g, 3, dData);
-  OUT(g, 4, dLog);
+  OUT(g, 3, gf64(&GphLds::s_cntf, 2));
+  OUT(g, 4, gf64(&GphLds::s_cntf, 3));
 }
 
 // UpdateGB_MigrationNode per-locus body, GPhoCS.c:2453-2587
@@ -315,7 +320,9 @@ GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune, GphRng &rng
 GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
 {
   int node, res, father, father_pop_old, sibling, b, i, mig, ev, target, pop, acc = 0, fpn, fen;
-  double lnLd, lnacc, t_new, dData = 0, dLog = 0;
+  double lnLd, lnacc, t_new;
+  sf64(&GphLds::s_cntf, 5, 0.0);
+  sf64(&GphLds::s_cntf, 6, 0.0);
   for (node = 0; node < g_lay.N; node++) {
     if (node == ISC(IS_ROOT)) continue;
     father = FATH(node);
@@ -331,8 +338,8 @@ GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
       STAMPC_BEGIN(2);
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + (SPRLN(1) - SPRLN(0)));
-      dData += lnLd;
-      dLog += (lnLd - SPRLN(0) + SPRLN(1)) / D.Ltot;
+      sf64(&GphLds::s_cntf, 5, gf64(&GphLds::s_cntf, 5) + lnLd);
+      sf64(&GphLds::s_cntf, 6, gf64(&GphLds::s_cntf, 6) + (lnLd - SPRLN(0) + SPRLN(1)) / D.Ltot);
       target = SPRI(SI_TARGET);
       t_new = AGE(father);
       for (i = 0; i < ISC(IS_NUM_MIGS); i++) {
@@ -390,8 +397,8 @@ GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
     }
   }
   OUT(g, 2, acc);
-  OUT(g, 6, dData);
-  OUT(g, 7, dLog);
+  OUT(g, 6, gf64(&GphLds::s_cntf, 5));
+  OUT(g, 7, gf64(&GphLds::s_cntf, 6));
 }
 
 // fused genealogy sweep: UpdateGB_InternalNode, UpdateGB_MigrationNode, UpdateGB_MigSPR

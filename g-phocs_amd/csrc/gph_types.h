@@ -165,7 +165,7 @@ struct alignas(16) GphLds {
   // ---- LDS-only scratch: pending-proposal storage of GENETREE_STATS_DELTA x2 (patch.h:60-72),
   // MIG_SPR_STATS (patch.h:97-105), genetree_stats_check (patch.h:109), pruning work lists
   double s_dcoal[2][GPH_CAP_K], s_dmig[2][GPH_CAP_B], s_sprf[GPH_MAX_MIGS + 2];
-  double s_chkcoal[GPH_CAP_K], s_chkmig[GPH_CAP_B], s_cntf[2];
+  double s_chkcoal[GPH_CAP_K], s_chkmig[GPH_CAP_B], s_cntf[8];   // s_cntf: 0 algorithmic bytes, 2..6 sweep accumulators, 7 step size
 #if defined(GPH_STAMPS) || defined(GPH_HOSTEMU)
   double s_stamp[8];          // diagnostic cycle sums (tools/stamp_breakdown.py); not in production device builds
 #endif
