@@ -777,7 +777,7 @@ GPH_DEVHOT double lik_compute(int useOld)
       if (gu8(q_phases, p) > 0) { lnl += gf64(q_terms, p); U++; }
   }
   setFS(FS_DATALNL, lnl);
-  if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (96.0 * nord * P + 20.0 * N + 8.0 * U + 8.0));
+  if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (double)(96 * nord * P + 20 * N + 8 * U + 8));
   STAMPB_END(4);
   return lnl;
 }
@@ -856,7 +856,7 @@ GPH_DEVHOT double lik_compute(int useOld)
     }
   }
   setFS(FS_DATALNL, lnl);
-  if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (96.0 * nord * P + 20.0 * N + 8.0 * U + 8.0));
+  if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (double)(96 * nord * P + 20 * N + 8 * U + 8));
   return lnl;
 }
 
