@@ -34,6 +34,9 @@ VARIANTS = {  # name: (max leaves, max pops, max bands, waves per SIMD of the sw
 }
 
 
+LIB_SOURCES = ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp", "gph_readtrace.cpp")
+
+
 def variant_for(n, K, B):
     for name in ("s", "l", "m"):
         cl, ck, cb, _, _ = VARIANTS[name]
@@ -49,7 +52,7 @@ def lib_path(name="m"):
 
 def build(verbose=False):
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU), every variant."""
-    srcs = [os.path.join(CSRC, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in LIB_SOURCES]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
         [os.path.join(REPO, "include", "gphocs_hip.h")]
     for name, (cl, ck, cb, waves, fn) in VARIANTS.items():
@@ -65,6 +68,13 @@ def build(verbose=False):
     exe, main = os.path.join(_HERE, "G-PhoCS-hip"), os.path.join(CSRC, "gph_main.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(main), os.path.getmtime(deps[-1])):
         cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(REPO, "include"), main, "-ldl", "-o", exe]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    # the post-run trace summary tool (readTrace.c), host only
+    exe, main = os.path.join(_HERE, "readTrace"), os.path.join(CSRC, "gph_readtrace.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(main), os.path.getmtime(deps[-1])):
+        cmd = ["g++", "-O2", "-std=c++17", "-DGPH_READTRACE_MAIN", main, "-o", exe]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
@@ -133,6 +143,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
     "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
     "gph_control_sample_name", "gph_loci_read", "gph_loci_free", "gph_loci_arrays", "gph_run_control_file", "gph_run_control_file_ranked",
+    "gph_read_trace",
 ]
 
 

@@ -35,6 +35,7 @@
  */
 #ifndef GPHOCS_HIP_H
 #define GPHOCS_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -216,6 +217,15 @@ int gph_run_control_file(const char *ctl_path, const char *secondary_ctl_path_or
  * reduced vectors through `allreduce` (see gph_engine_set_allreduce); rank 0 writes the trace file */
 int gph_run_control_file_ranked(const char *ctl_path, const char *secondary_ctl_path_or_null, int32_t device,
                                 int32_t verbose, int32_t rank, int32_t world, gph_allreduce_fn allreduce, void *user);
+
+/* ------------------------------------------------------------------------------------
+ * post-run summary of a trace file (host only): block means per column, the output of the reference's
+ * stand-alone `readTrace` tool (src/readTrace.c:41-291: `-b` block size, default the whole file = -1;
+ * `-d` samples to discard).  The text that tool prints goes to out (NUL-terminated, *out_len = its
+ * length; out may be NULL to ask for the length), its error text to err.  Returns 0, the tool's exit
+ * code on error, or 2 when out_cap was too small. */
+int gph_read_trace(const char *trace_file, int block_size, int discard, char *out, size_t out_cap, size_t *out_len,
+                   char *err, size_t err_cap);
 
 #ifdef __cplusplus
 }

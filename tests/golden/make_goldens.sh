@@ -47,3 +47,13 @@ timeout 600 $REF run z0.ctl 12 z0.rtrace z0.state 11 1 >/dev/null
 # f3: the find-finetunes search (GPhoCS.c:1896-2180) -- config 3 with find-finetunes TRUE, 6 steps of 10 samples;
 # only the reference's own trace file is kept (f3.ctl is gen_synth output with the three find-finetunes lines edited in)
 timeout 900 $REF main -n 1 f3.ctl >/dev/null 2>&1
+
+# the reference's readTrace tool on its own trace files (oracle/_ref/readTrace_ref = src/readTrace.c compiled as is);
+# only block layouts without a trailing partial block are kept, and `-d` with the default block: a partial tail
+# after complete blocks prints uninitialised storage upstream (readTrace.c:253-264)
+RT=../../oracle/_ref/readTrace_ref
+$RT g1.trace        > g1.readtrace_all.txt
+$RT g1.trace -b 3   > g1.readtrace_b3.txt
+$RT m3.trace -b 40  > m3.readtrace_b40.txt
+$RT a7.trace -d 20  > a7.readtrace_d20.txt
+$RT f3.trace -b 10 -d 20 > f3.readtrace_b10_d20.txt

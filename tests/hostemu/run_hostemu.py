@@ -15,7 +15,7 @@ HOSTEMU = os.path.join(REPO, "tests", "hostemu", "libgphocs_hostemu.so")
 
 def build_hostemu(sanitize=False):
     csrc = os.path.join(REPO, "g-phocs_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp")]
+    srcs = [os.path.join(csrc, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp", "gph_readtrace.cpp")]
     deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
     if os.path.exists(HOSTEMU) and all(os.path.getmtime(HOSTEMU) >= os.path.getmtime(d) for d in deps):
         return HOSTEMU

@@ -140,3 +140,71 @@ def test_control_file_errors(lib, tmp_path):
     open(p, "w").write(txt.replace("source  A", "source  AB", 1))
     with pytest.raises(ValueError):
         G.Pack.from_control(p, lib=lib)
+
+
+# ---------------------------------------------------------------------------- readTrace
+READTRACE_CASES = [("g1", [], "all"), ("g1", ["-b", "3"], "b3"), ("m3", ["-b", "40"], "b40"),
+                   ("a7", ["-d", "20"], "d20"), ("f3", ["-b", "10", "-d", "20"], "b10_d20")]
+
+
+def _read_trace(lib, path, block=-1, discard=0):
+    import ctypes as C
+    n = C.c_size_t(0)
+    err = C.create_string_buffer(512)
+    lib.gph_read_trace.restype = C.c_int
+    lib.gph_read_trace.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                   C.c_char_p, C.c_size_t]
+    rc = lib.gph_read_trace(path.encode(), block, discard, None, 0, C.byref(n), err, 512)
+    if rc != 0:
+        return rc, "", err.value.decode()
+    buf = C.create_string_buffer(n.value + 1)
+    rc = lib.gph_read_trace(path.encode(), block, discard, buf, n.value + 1, C.byref(n), err, 512)
+    return rc, buf.value.decode(), err.value.decode()
+
+
+@pytest.mark.parametrize("name,args,tag", READTRACE_CASES)
+def test_read_trace_prints_what_the_reference_tool_prints(lib, name, args, tag):
+    """gph_read_trace / the readTrace executable against the text the reference's own readTrace (src/readTrace.c,
+    compiled unmodified into oracle/_ref/readTrace_ref) printed for its own trace files."""
+    import subprocess
+    want = open(os.path.join(GOLDEN, f"{name}.readtrace_{tag}.txt")).read()
+    block = int(args[args.index("-b") + 1]) if "-b" in args else -1
+    discard = int(args[args.index("-d") + 1]) if "-d" in args else 0
+    rc, got, err = _read_trace(lib, os.path.join(GOLDEN, name + ".trace"), block, discard)
+    assert rc == 0 and err == ""
+    assert got == want
+    # the executable: same text on stdout
+    exe = os.path.join(REPO, "tests", "hostemu", "readTrace_test")
+    src = os.path.join(G.CSRC, "gph_readtrace.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-DGPH_READTRACE_MAIN", src, "-o", exe], check=True)
+    out = subprocess.run([exe, os.path.join(GOLDEN, name + ".trace")] + args, capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout == want
+
+
+def test_read_trace_partial_tail_and_errors(lib, tmp_path):
+    """A trailing partial block is averaged over its own length (readTrace.c:253-264; upstream then prints
+    uninitialised storage for it unless the column widens, here the means are printed); error paths."""
+    path = os.path.join(GOLDEN, "g1.trace")
+    rows = [l.split() for l in open(path).read().strip().split("\n")]
+    data = np.array([[np.float32(x) for x in r[1:]] for r in rows[1:]], dtype=np.float64)   # %f into a float
+    rc, got, _ = _read_trace(lib, path, block=4, discard=1)
+    assert rc == 0
+    lines = got.split("\n")
+    assert lines[0].split() == rows[0][1:]
+    body = data[1:]
+    nblk = (len(body) + 3) // 4
+    assert len(lines) == 1 + nblk + 2          # title, blocks, the closing empty line
+    for b in range(nblk):
+        blk = body[4 * b:4 * b + 4]
+        want = ["%.6f" % v for v in blk.sum(axis=0) / len(blk)]
+        assert lines[1 + b].split() == want
+    rc, _, err = _read_trace(lib, path, discard=100)
+    assert rc == 1 and err == "100 lines specified to discard, but trace file contains only 30 lines.\n"
+    rc, _, err = _read_trace(lib, os.path.join(tmp_path, "nope.trace"))
+    assert rc == 1 and "Could not find trace file" in err
+    # a last line without its newline is not a sample (readTrace.c:217-218), but it was counted (:121-131)
+    p = os.path.join(tmp_path, "t.trace")
+    open(p, "w").write("Sample\ta\tb\n0\t1.0\t2.0\n1\t3.0\t5.0\n2\t100.0\t100.0")
+    rc, got, _ = _read_trace(lib, p)
+    assert rc == 0 and got.split("\n")[1].split() == ["2.000000", "3.500000"]

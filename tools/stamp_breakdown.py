@@ -9,7 +9,7 @@ import bench
 MODE = 2 if "--lik" in sys.argv else 3 if "--spr" in sys.argv else 1
 lib_path = os.path.join(REPO, "bench_cache", f"libgphocs_stamps{MODE}.so")
 os.makedirs(os.path.dirname(lib_path), exist_ok=True)
-srcs = [os.path.join(G.CSRC, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp")]
+srcs = [os.path.join(G.CSRC, f) for f in G.LIB_SOURCES]
 deps = [os.path.join(G.CSRC, f) for f in os.listdir(G.CSRC)]
 if not os.path.exists(lib_path) or any(os.path.getmtime(d) > os.path.getmtime(lib_path) for d in deps):
     subprocess.run(["hipcc"] + G.HIPCC_FLAGS + [f"-DGPH_STAMPS={MODE}", "-DGPH_CAP_LEAVES=16", "-DGPH_CAP_K=9", "-DGPH_CAP_B=4",
