@@ -46,6 +46,7 @@ typedef struct {
   /* mcmc settings */
   int seed, burnin, numSamples, sampleSkip, startMig, doMixing, samplesPerLog, mutRateMode;
   double ftCoalTime, ftMigTime, ftTheta, ftMigRate, ftMixing, ftTaus[GO_MAXK];
+  double varRatesAlpha, ftLocusRate;   /* locus-mut-rate VAR <alpha>, finetune-locus-rate (mutRateMode 1) */
   int numParameters;
   double printFactors[3 * GO_MAXK + GO_MAXB];
 } go_model;
@@ -120,6 +121,7 @@ typedef struct {
   unsigned int gx, gy, gz;
   /* accumulators (GPhoCS.h:35-50, patch.h:186) */
   double logLikelihood, dataLogLikelihood;
+  double rateVar;              /* dataState.rateVar, GPhoCS.h:45 */
   double tot_coal_stats[GO_MAXK], tot_mig_stats[GO_MAXB];
   int tot_num_coals[GO_MAXK], tot_num_migs[GO_MAXB];
   int rubberband_mig_conflicts, not_enough_migs;
@@ -159,6 +161,7 @@ int go_update_theta(go_state *s, double finetune);
 int go_update_mig_rates(go_state *s, double finetune);
 void go_update_tau(go_state *s, const double *finetunes, int *accepted);
 void go_update_sample_age(go_state *s, const double *finetunes, int *accepted);
+int go_update_locus_rate(go_state *s, double finetune);
 int go_mixing(go_state *s, double finetune);
 int go_synchronize_events(go_state *s, go_locus *q);
 int go_check_all(go_state *s);

@@ -125,6 +125,13 @@ go_state *go_load_pack(const char *path)
     for (i = 0; i < 5; i++) { if (fscanf(f, "%s", buf) != 1) goto bad; *ft[i] = strtod(buf, NULL); }
     for (pop = 0; pop < m->K; pop++) { if (fscanf(f, "%s", buf) != 1) goto bad; m->ftTaus[pop] = strtod(buf, NULL); }
   }
+  m->varRatesAlpha = 1.0;
+  m->ftLocusRate = -1.0;
+  if (m->mutRateMode == 1) {   /* only packs of VAR-rate control files carry this line */
+    if (fscanf(f, " %127s", key) != 1 || strcmp(key, "locusrate")) goto bad;
+    if (fscanf(f, "%s", buf) != 1) goto bad; m->varRatesAlpha = strtod(buf, NULL);
+    if (fscanf(f, "%s", buf) != 1) goto bad; m->ftLocusRate = strtod(buf, NULL);
+  }
   if (fscanf(f, " printFactors %d", &m->numParameters) != 1) goto bad;
   for (i = 0; i < m->numParameters; i++) { if (fscanf(f, "%s", buf) != 1) goto bad; m->printFactors[i] = strtod(buf, NULL); }
   /* isAncestralTo (self-inclusive), MCMCcontrol.c:851, 977, 1015-1024 */
@@ -181,6 +188,7 @@ void go_dump_state(go_state *s, FILE *f, int withCond)
   for (b = 0; b < m->B; b++) fprintf(f, " %a %a %a", m->migRate[b], m->bandStart[b], m->bandEnd[b]);
   fprintf(f, "\n");
   fprintf(f, "GLOBAL %a %a %u %u %u\n", s->logLikelihood, s->dataLogLikelihood, s->gx, s->gy, s->gz);
+  if (m->mutRateMode == 1) fprintf(f, "RATEVAR %a\n", s->rateVar);
   fprintf(f, "TOTALS");
   for (pop = 0; pop < m->K; pop++) fprintf(f, " %a %d", s->tot_coal_stats[pop], s->tot_num_coals[pop]);
   for (b = 0; b < m->B; b++) fprintf(f, " %a %d", s->tot_mig_stats[b], s->tot_num_migs[b]);
@@ -189,6 +197,7 @@ void go_dump_state(go_state *s, FILE *f, int withCond)
     go_locus *q = &s->loc[g];
     fprintf(f, "LOCUS %d root %d dataLnL %a genLnL %a rng %u %u %u\n", g, q->root, q->dataLnL, q->genLnL,
             q->rx, q->ry, q->rz);
+    if (m->mutRateMode == 1) fprintf(f, "R %a\n", q->mutRate);
     for (i = 0; i < N; i++)
       fprintf(f, "N %d %d %d %d %a %d %d\n", i, q->father[i], q->left[i], q->right[i], q->age[i],
               q->nodePop[i], i < m->n ? -1 : q->nodeEvent[i]);

@@ -119,13 +119,35 @@ static void compute_total_stats(go_state *s)
   }
 }
 
-/* initializeMCMC, GPhoCS.c:1122-1225 (CONST / FIXED mutation rates) */
+/* initializeMCMC, GPhoCS.c:1122-1225 */
 int go_initialize_mcmc(go_state *s)
 {
   go_model *m = &s->m;
   int g, pop, totalCoals = 0, cum[GO_MAXK], nextId;
   int *living = (int *)malloc(sizeof(int) * m->n);
   sample_pop_parameters(s);
+  /* locus-specific mutation rates, GPhoCS.c:1137-1178: CONST = 1, FIXED = as loaded (readRateFile),
+   * VAR = 0.8 + 0.4 u from the locus's own stream, normalised to mean 1 */
+  s->rateVar = 0.0;
+  if (m->mutRateMode == 1) {
+    double total = 0.0, r;
+    for (g = 0; g < s->L; g++) {
+      r = 0.8 + 0.4 * LRND(&s->loc[g]);
+      total += r;
+      s->loc[g].mutRate = r;
+    }
+    total /= s->L;
+    for (g = 0; g < s->L; g++) {
+      r = s->loc[g].mutRate / total;
+      s->loc[g].mutRate = r;
+      s->rateVar += (r - 1) * (r - 1);
+    }
+    s->rateVar /= s->L;
+  } else if (m->mutRateMode == 2) {
+    /* readRateFile, GPhoCS.c:565-572 */
+    for (g = 0; g < s->L; g++) s->rateVar += (s->loc[g].mutRate - 1.0) * (s->loc[g].mutRate - 1.0);
+    s->rateVar /= s->L;
+  }
   s->logLikelihood = 0.0;
   s->dataLogLikelihood = 0.0;
   cum[0] = m->samplesPerPop[0];
@@ -826,6 +848,50 @@ void go_update_sample_age(go_state *s, const double *finetunes, int *accepted)
 }
 
 /* mixing, GPhoCS.c:4688-4912 */
+/* UpdateLocusRate, GPhoCS.c:4598-4680: for every locus but the reference one (genRateRef = 0,
+ * :1177) shift its rate and the reference locus's rate in opposite directions (mean rate stays 1),
+ * full recomputation of both data likelihoods, Dirichlet(alpha) prior ratio.  Serial over loci by
+ * construction: the reference locus's rate carries every earlier decision. */
+int go_update_locus_rate(go_state *s, double finetune)
+{
+  go_model *m = &s->m;
+  int accepted = 0, g;
+  const int ref = 0;
+  go_locus *qr = &s->loc[ref];
+  double lnacc, lnLd, rold, rnew, rrefold, rrefnew;
+  if (finetune <= 0.0) return 0;
+  for (g = 0; g < s->L; g++) {
+    go_locus *q = &s->loc[g];
+    if (g == ref) continue;
+    rrefold = qr->mutRate;
+    rold = q->mutRate;
+    rnew = rold + finetune * go_rnd2normal8(&q->rx, &q->ry, &q->rz);
+    rnew = go_reflect(rnew, 0, rold + rrefold);
+    q->mutRate = rnew;
+    rrefnew = rrefold + rold - rnew;
+    qr->mutRate = rrefnew;
+    lnacc = (m->varRatesAlpha - 1) * log((rnew * rrefnew) / (rold * rrefold));
+    lnLd = -(q->dataLnL + qr->dataLnL);
+    lnLd += go_lik_compute(s, q, 0);
+    lnLd += go_lik_compute(s, qr, 0);
+    lnacc += lnLd;
+    if (lnacc >= 0 || LRND(q) < exp(lnacc)) {
+      accepted++;
+      s->dataLogLikelihood += lnLd;
+      s->logLikelihood += lnLd / s->L;
+      go_lik_reset_saved(s, q);
+      go_lik_reset_saved(s, qr);
+      s->rateVar += (rnew * rnew + rrefnew * rrefnew - rold * rold - rrefold * rrefold) / s->L;
+    } else {
+      q->mutRate = rold;
+      qr->mutRate = rrefold;
+      go_lik_revert(s, q);
+      go_lik_revert(s, qr);
+    }
+  }
+  return accepted;
+}
+
 int go_mixing(go_state *s, double finetune)
 {
   go_model *m = &s->m;
@@ -1037,6 +1103,7 @@ static void record_param_vals(go_state *s)
   for (b = 0; b < m->B; b++) s->paramVals[ind++] = m->migRate[b];
   for (pop = 0; pop < m->Kc; pop++)
     if (m->updateSampleAge[pop] || m->sampleAge[pop] > 0.0) s->paramVals[ind++] = m->sampleAge[pop];
+  if (m->mutRateMode == 1) s->paramVals[ind++] = sqrt(s->rateVar);
 }
 
 static void rec(go_state *s, FILE *tf, int it, const char *what, int acc)
@@ -1045,7 +1112,7 @@ static void rec(go_state *s, FILE *tf, int it, const char *what, int acc)
 }
 
 /* one iteration of performMCMC, GPhoCS.c:1476-1821 (genetreeSamples == 1, no
- * find-finetunes, no admixture, no UpdateLocusRate) */
+ * find-finetunes, no admixture) */
 int go_iteration(go_state *s, int iteration, FILE *tf)
 {
   go_model *m = &s->m;
@@ -1056,6 +1123,10 @@ int go_iteration(go_state *s, int iteration, FILE *tf)
   rec(s, tf, iteration, "MIGN", acc);
   acc = go_update_mig_spr(s);
   rec(s, tf, iteration, "SPR", acc);
+  if (m->mutRateMode == 1) {
+    acc = go_update_locus_rate(s, m->ftLocusRate);
+    rec(s, tf, iteration, "LRATE", acc);
+  }
   acc = go_update_theta(s, m->ftTheta);
   rec(s, tf, iteration, "THETA", acc);
   if (iteration > m->startMig) {

@@ -103,6 +103,8 @@ static void write_model(FILE *f)
           mcmcSetup.finetunes.migRate, mcmcSetup.finetunes.mixing);
   for (pop = 0; pop < pt->numPops; pop++) fprintf(f, " %a", mcmcSetup.finetunes.taus[pop]);
   fprintf(f, "\n");
+  if (mcmcSetup.mutRateMode == 1)
+    fprintf(f, "locusrate %a %a\n", mcmcSetup.varRatesAlpha, mcmcSetup.finetunes.locusRate);
   fprintf(f, "printFactors %d", mcmcSetup.numParameters);
   for (pop = 0; pop < mcmcSetup.numParameters; pop++) fprintf(f, " %a", mcmcSetup.printFactors[pop]);
   fprintf(f, "\n");
@@ -159,6 +161,7 @@ static void dump_state(FILE *f, int withCond)
   fprintf(f, "GLOBAL %a %a %u %u %u\n", dataState.logLikelihood, dataState.dataLogLikelihood,
           RndCtx.rndu_x[RndCtx.nOfSlots - 1], RndCtx.rndu_y[RndCtx.nOfSlots - 1],
           RndCtx.rndu_z[RndCtx.nOfSlots - 1]);
+  if (mcmcSetup.mutRateMode == 1) fprintf(f, "RATEVAR %a\n", dataState.rateVar);
   fprintf(f, "TOTALS");
   for (pop = 0; pop < pt->numPops; pop++)
     fprintf(f, " %a %d", genetree_stats_total.coal_stats[pop], genetree_stats_total.num_coals[pop]);
@@ -170,6 +173,7 @@ static void dump_state(FILE *f, int withCond)
     fprintf(f, "LOCUS %d root %d dataLnL %a genLnL %a rng %u %u %u\n", g, ld->root,
             ld->dataLogLikelihood, locus_data[g].genLogLikelihood,
             RndCtx.rndu_x[g], RndCtx.rndu_y[g], RndCtx.rndu_z[g]);
+    if (mcmcSetup.mutRateMode == 1) fprintf(f, "R %a\n", ld->mutationRate);
     for (i = 0; i < N; i++) {
       fprintf(f, "N %d %d %d %d %a %d %d\n", i, ld->nodeArray[i]->father,
               ld->nodeArray[i]->leftSon, ld->nodeArray[i]->rightSon,

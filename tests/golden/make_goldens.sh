@@ -33,8 +33,12 @@ gen s3 3 12 300 40 20 --start-mig 10 --mig-beta 0.0000001 --no-mixing
 # estimated sample ages ("age x e"): UpdateSampleAge (GPhoCS.c:4006) is live
 gen a6 6 12 300 80 20 --mig-beta 0.00000004
 gen a7 7 12 300 100 25 --mig-beta 0.00000004
+# variable locus rates ("locus-mut-rate VAR a"): UpdateLocusRate (GPhoCS.c:4598) is live; v9 has a large step
+# (reflections at both ends of (0, rold + rref)) and alpha != 1 (the Dirichlet prior term)
+gen v8 3 16 300 60 20 --mig-beta 0.00000004 --var-rates 1.0 0.3
+gen v9 2 14 300 60 20 --var-rates 1.7 1.1
 # the reference's own trace files (its main(), unmodified): what G-PhoCS-hip must reproduce
-for name in g1 m3 a7; do timeout 900 $REF main -n 1 $name.ctl >/dev/null 2>&1; done
+for name in g1 m3 a7 v8; do timeout 900 $REF main -n 1 $name.ctl >/dev/null 2>&1; done
 # front-end stress input (IUPAC codes, haploids, missing/unknown samples, all-N columns)
 python3 make_stress.py
 timeout 600 $REF pack stress.ctl stress.gpk >/dev/null

@@ -59,14 +59,14 @@ def build_tree(cfg):
 
 
 def write_ctl(path, cfg, seqfile, tracefile, loci, seed, iters, samples_per_log, no_mixing=False,
-              start_mig=0, mig_beta=0.00001):
+              start_mig=0, mig_beta=0.00001, var_rates=None):
     cur, anc, taus = build_tree(cfg)
     kc = len(cur)
     out = []
     out.append("GENERAL-INFO-START\n")
     out.append(f"\tseq-file            {seqfile}")
     out.append(f"\ttrace-file          {tracefile}")
-    out.append("\tlocus-mut-rate          CONST")
+    out.append("\tlocus-mut-rate          " + ("CONST" if var_rates is None else f"VAR {var_rates[0]}"))
     out.append(f"\tnum-loci            {loci}")
     out.append(f"\trandom-seed         {seed}")
     out.append(f"\tmcmc-iterations\t  {iters}")
@@ -84,6 +84,8 @@ def write_ctl(path, cfg, seqfile, tracefile, loci, seed, iters, samples_per_log,
     out.append("\tfinetune-mig-rate\t0.02")
     out.append("\tfinetune-tau\t\t0.0000008")
     out.append("\tfinetune-mixing\t\t0.003")
+    if var_rates is not None:
+        out.append(f"\tfinetune-locus-rate\t{var_rates[1]}")
     out.append("")
     out.append("\ttau-theta-print\t\t10000.0")
     out.append("\ttau-theta-alpha\t\t1.0")
@@ -227,6 +229,8 @@ def main():
                     help="mig-rate-beta (prior mean = 0.002/beta); small beta = many migration events")
     ap.add_argument("--mut-scale", type=float, default=1.0,
                     help="scale branch lengths when dropping mutations (more patterns)")
+    ap.add_argument("--var-rates", type=float, nargs=2, default=None, metavar=("ALPHA", "FINETUNE"),
+                    help="locus-mut-rate VAR <ALPHA> with finetune-locus-rate <FINETUNE> (UpdateLocusRate is live)")
     ap.add_argument("--out", required=True, help="output prefix: <out>.ctl, <out>.seq")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -236,7 +240,8 @@ def main():
     theta = 1e-4
     seqfile = os.path.basename(a.out) + ".seq"
     write_ctl(a.out + ".ctl", cfg, seqfile, os.path.basename(a.out) + ".trace", L, a.mcmc_seed,
-              a.iters, a.per_log, no_mixing=a.no_mixing, start_mig=a.start_mig, mig_beta=a.mig_beta)
+              a.iters, a.per_log, no_mixing=a.no_mixing, start_mig=a.start_mig, mig_beta=a.mig_beta,
+              var_rates=a.var_rates)
     nd = sum(cfg["pops"])
     with open(a.out + ".seq", "w") as f:
         f.write(f"{L}\n\n")
