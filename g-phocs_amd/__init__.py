@@ -115,7 +115,8 @@ class GphMcmcConfig(C.Structure):
                 ("ftTaus", C.POINTER(C.c_double)),
                 ("seed", C.c_int32), ("startMig", C.c_int32), ("doMixing", C.c_int32),
                 ("samplesPerLog", C.c_int32), ("numParameters", C.c_int32),
-                ("printFactors", C.POINTER(C.c_double))]
+                ("printFactors", C.POINTER(C.c_double)),
+                ("mutRateMode", C.c_int32), ("varRatesAlpha", C.c_double), ("ftLocusRate", C.c_double)]
 
 
 class GphControlInfo(C.Structure):
@@ -143,7 +144,8 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
     "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
     "gph_control_sample_name", "gph_loci_read", "gph_loci_free", "gph_loci_arrays", "gph_run_control_file", "gph_run_control_file_ranked",
-    "gph_read_trace",
+    "gph_read_trace", "gph_engine_locus_rate_update", "gph_engine_set_locus_rates", "gph_mcmc_set_locus_rate_finetune",
+    "gph_mcmc_locus_rate_state",
 ]
 
 
@@ -271,7 +273,12 @@ class Pack:
         assert nxt() == "finetunes"
         p.ftCoalTime, p.ftMigTime, p.ftTheta, p.ftMigRate, p.ftMixing = fl(), fl(), fl(), fl(), fl()
         p.ftTaus = np.array([fl() for _ in range(K)])
-        assert nxt() == "printFactors"
+        key = nxt()
+        p.varRatesAlpha, p.ftLocusRate = 1.0, -1.0
+        if key == "locusrate":            # packs of `locus-mut-rate VAR` control files only
+            p.varRatesAlpha, p.ftLocusRate = fl(), fl()
+            key = nxt()
+        assert key == "printFactors"
         p.numParameters = int(nxt())
         p.printFactors = np.array([fl() for _ in range(p.numParameters)])
         offs, leaf, phases, counts, rates = [0], [], [], [], []
@@ -328,6 +335,7 @@ class Pack:
             p.seed, p.startMig, p.doMixing, p.samplesPerLog = mc.seed, mc.startMig, mc.doMixing, mc.samplesPerLog
             p.burnin, p.numSamplesMcmc, p.sampleSkip, p.mutRateMode = (info.burnin, info.numSamples, info.sampleSkip,
                                                                        info.mutRateMode)
+            p.varRatesAlpha, p.ftLocusRate = info.varRatesAlpha, info.ftLocusRate
             p.numParameters = mc.numParameters
             p.printFactors = arr(mc.printFactors, p.numParameters, np.float64)
             p.traceFile, p.seqFile = info.traceFile.decode(), info.seqFile.decode()
@@ -433,7 +441,9 @@ class Sampler:
                                   _dp(k["ma"]), _dp(k["mb"]),
                                   p.ftCoalTime, p.ftMigTime, p.ftTheta, p.ftMigRate, p.ftMixing,
                                   _dp(k["ft"]), p.seed, p.startMig, p.doMixing, p.samplesPerLog,
-                                  p.numParameters, _dp(k["pf_"]))
+                                  p.numParameters, _dp(k["pf_"]),
+                                  int(getattr(p, "mutRateMode", 0)) if int(getattr(p, "mutRateMode", 0)) == 1 else 0,
+                                  float(getattr(p, "varRatesAlpha", 1.0)), float(getattr(p, "ftLocusRate", -1.0)))
         self.mcmc = C.c_void_p()
         self._chk(self.lib.gph_mcmc_create(self.engine, C.byref(self.cfg), C.byref(self.mcfg),
                                            C.byref(self.mcmc)), "mcmc_create")

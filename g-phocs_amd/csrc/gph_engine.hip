@@ -34,7 +34,7 @@ GphModel g_model;
 #endif
 
 // j0 = first slot of the launch group (see GphDev)
-GPH_KERNEL(k_init, GphKargs KA, GphDev D, int j0, uint32_t seedz, const double *mutRate) { kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0); }
+GPH_KERNEL(k_init, GphKargs KA, GphDev D, int j0, uint32_t seedz, const double *mutRate, int preDraws) { kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0, preDraws); }
 GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphKargs KA, GphDev D, int j0, int flags, double ftCoal, double ftMig) { kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
 GPH_KERNEL(k_tau_eval, GphKargs KA, GphDev D, int j0, GphTauArgs A) { kb_tau_eval(D, j0 + GPH_BLK, A); }
 GPH_KERNEL(k_tau_commit, GphKargs KA, GphDev D, int j0, GphTauArgs A) { kb_tau_commit(D, j0 + GPH_BLK, A); }
@@ -43,6 +43,8 @@ GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, double c) { kb_mix_eval(D,
 GPH_KERNEL(k_mix_commit, GphKargs KA, GphDev D, int j0, double c, double lnc) { kb_mix_commit(D, j0 + GPH_BLK, c, lnc); }
 GPH_KERNEL(k_sync, GphKargs KA, GphDev D, int j0, int refresh) { kb_sync(D, j0 + GPH_BLK, refresh); }
 GPH_KERNEL(k_check, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; kb_check(D, j0 + GPH_BLK); }
+GPH_KERNEL(k_lrate_scan, GphKargs KA, GphDev D, int j0, GphLrArgs A) { (void)j0; kb_lrate_scan(D, A); }
+GPH_KERNEL(k_lrate_apply, GphKargs KA, GphDev D, int j0, const GphLrRec *rec) { kb_lrate_apply(D, j0 + GPH_BLK, rec); }
 
 // ---------------------------------------------------------------- small elementwise / reduction kernels
 #define GPH_RED_BLOCKS 256
@@ -156,6 +158,14 @@ struct gph_engine {
   struct Bucket { int j0, count, lds_bytes; };   // a launch group: slots [j0, j0+count), dynamic LDS per wave
   std::vector<Bucket> buckets;
   double *d_mutRate = nullptr;
+  int init_predraws = 0;             // rndu() draws every locus spent before its genealogy is sampled (VAR start-up: 1)
+  bool var_rates = false;            // locus rates are part of the state (dumped as "R" lines)
+  // UpdateLocusRate: per-slot records, input-order -> slot map, result scalars, scratch for pattern-rich loci
+  GphLrRec *d_lrec = nullptr;
+  int32_t *d_slot_of = nullptr;
+  double *d_lr_result = nullptr, *d_lr_gscr = nullptr;
+  GphLrArgs lr;
+  int lr_lds_bytes = 0;
   double *d_part = nullptr, *d_red = nullptr;
   double h_red[3 * GPH_RED_COLS];
   gph_allreduce_fn allreduce = nullptr;
@@ -275,6 +285,23 @@ static int upload_tables(gph_engine *) { return 0; }
       HIPCHK(hipGetLastError()); } \
     HIPCHK(hipEventRecord((e)->ev1, (e)->stream)); \
     (e)->last_which = (which); (e)->cls_launches[which] += 1; (e)->timing_pending = true; } while (0)   /* elapsed time is read in finish_kernel(), after the result copy has synchronised the stream */
+#endif
+
+// one single-wave workgroup with its own dynamic-LDS size (the serial scan of UpdateLocusRate)
+#ifdef GPH_HOSTEMU
+#define LAUNCH1(e, which, name, ldsbytes, ...) do { g_model = (e)->model; \
+    g_lay = (e)->lay; GphKargs &ka_ = (e)->ka; ka_.model = (e)->model; ka_.lay = (e)->lay; \
+    (e)->lds.assign((size_t)(ldsbytes) + 64, 0); gph_sm = (e)->lds.data(); \
+    name(0, ka_, (e)->dev, 0, __VA_ARGS__); \
+    (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
+#else
+#define LAUNCH1(e, which, name, ldsbytes, ...) do { \
+    GphKargs &ka_ = (e)->ka; ka_.model = (e)->model; ka_.lay = (e)->lay; \
+    HIPCHK(hipEventRecord((e)->ev0, (e)->stream)); \
+    hipLaunchKernelGGL(name, dim3(1), dim3(GPH_WAVE), (ldsbytes), (e)->stream, ka_, (e)->dev, 0, __VA_ARGS__); \
+    HIPCHK(hipGetLastError()); \
+    HIPCHK(hipEventRecord((e)->ev1, (e)->stream)); \
+    (e)->last_which = (which); (e)->cls_launches[which] += 1; (e)->timing_pending = true; } while (0)
 #endif
 
 // reduce the per-locus outputs (mode 0) or page statistics (mode 1) over local loci
@@ -420,6 +447,7 @@ void gph_engine_destroy(gph_engine *e)
   if (!e) return;
   dev_free(e->dev.pages); dev_free(e->dev.shadow); dev_free(e->dev.cond); dev_free((void *)e->dev.cond_off);
   dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
+  dev_free(e->d_lrec); dev_free(e->d_slot_of); dev_free(e->d_lr_result); dev_free(e->d_lr_gscr);
   dev_free(e->d_part); dev_free(e->d_red);
 #ifndef GPH_HOSTEMU
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -539,7 +567,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   // per-locus kernels use up to the wide group's dynamic LDS size; allow > 64 KiB
   const void *ks[] = {(const void *)k_init, (const void *)k_sweep, (const void *)k_tau_eval, (const void *)k_tau_commit,
                       (const void *)k_tau_revert, (const void *)k_mix_eval, (const void *)k_mix_commit,
-                      (const void *)k_sync, (const void *)k_check};
+                      (const void *)k_sync, (const void *)k_check, (const void *)k_lrate_apply};
   for (auto k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, e->lay.lds_bytes));
 #endif
   return 0;
@@ -566,7 +594,7 @@ int gph_engine_seed(gph_engine *e, uint32_t seed)
 int gph_engine_init_genealogies(gph_engine *e, double *sumGen, double *sumData)
 {
   if (!e || !e->loaded || !e->seeded || !e->model_set) return GPH_ESTATE;
-  LAUNCH(e, 3, k_init, e->seedz, (const double *)e->d_mutRate);
+  LAUNCH(e, 3, k_init, e->seedz, (const double *)e->d_mutRate, e->init_predraws);
   int rc = finish_kernel(e);
   if (rc) return rc;
   double s[2] = {RSUM(e, 0), RSUM(e, 1)};
@@ -836,6 +864,84 @@ int gph_engine_hbm_bytes(gph_engine *e, double *bytes)
   return 0;
 }
 
+// starting locus rates in input order (VAR start-up or any caller-supplied rates); `draws` = rndu() draws every
+// locus's stream has spent producing them.  Before gph_engine_init_genealogies.
+int gph_engine_set_locus_rates(gph_engine *e, const double *rates, int32_t draws, int32_t variable)
+{
+  if (!e || !e->loaded || e->initialized || !rates || draws < 0) return GPH_ESTATE;
+  std::vector<double> r(e->L);
+  for (int64_t j = 0; j < e->L; j++) r[j] = rates[e->h_orig[j]];
+  if (!e->d_mutRate && dev_alloc((void **)&e->d_mutRate, sizeof(double) * e->L)) return GPH_EHIP;
+  if (h2d(e, e->d_mutRate, r.data(), sizeof(double) * e->L)) return GPH_EHIP;
+  e->init_predraws = draws;
+  e->var_rates = variable != 0;
+  return 0;
+}
+
+// UpdateLocusRate (GPhoCS.c:4598-4680): a serial scan by one wavefront + a parallel write-back (gph_kernels.h)
+int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, gph_locus_rate_result *io)
+{
+  if (!e || !e->initialized || !io) return GPH_ESTATE;
+  io->accepted = 0;
+  if (finetune <= 0.0) return 0;                       /* GPhoCS.c:4606 */
+  if (e->allreduce || e->cfg.locus_begin != 0 || e->cfg.L_total != e->L) {
+    fprintf(stderr, "gphocs_hip: UpdateLocusRate couples every locus to locus 0 serially; it runs on one GPU only\n");
+    return GPH_EARG;
+  }
+  { int rcs = flush_sync(e); if (rcs) return rcs; }
+  const int n = e->cfg.n, N = 2 * n - 1, Pmax = e->lay.Pmax;
+  if (!e->d_lrec) {
+    int rc = 0;
+    std::vector<int32_t> slot_of(e->L);
+    for (int64_t j = 0; j < e->L; j++) slot_of[e->h_orig[j]] = (int32_t)j;
+    // dynamic LDS of the scan: guest sequence block | reference sequence block | guest nodes | reference nodes | scratch
+    const int seqb = align_up(GPH_Q_TERMS(Pmax, n) + (Pmax > GPH_WAVE ? 8 * Pmax : 0), 16), ndb = N * (int)sizeof(GphNode);
+    const int fixed = 2 * seqb + 2 * ndb;
+    const int budget = 96 * 1024 - (int)sizeof(GphLds);
+    int Pscr = (budget - fixed) / ((n - 1) * 32);
+    if (const char *ov = getenv("GPH_LR_PSCR")) Pscr = atoi(ov) < Pscr ? atoi(ov) : Pscr;   /* tests: force the global-scratch path */
+    if (Pscr > Pmax) Pscr = Pmax;
+    if (Pscr < 0) Pscr = 0;
+    memset(&e->lr, 0, sizeof e->lr);
+    e->lr.o_rseq = seqb; e->lr.o_gnd = 2 * seqb; e->lr.o_rnd = 2 * seqb + ndb; e->lr.o_scr = fixed; e->lr.Pscr = Pscr;
+    e->lr_lds_bytes = fixed + (n - 1) * Pscr * 32;
+    rc |= dev_alloc((void **)&e->d_lrec, sizeof(GphLrRec) * e->L);
+    rc |= dev_alloc((void **)&e->d_slot_of, sizeof(int32_t) * e->L);
+    rc |= dev_alloc((void **)&e->d_lr_result, sizeof(double) * 8);
+    rc |= dev_alloc((void **)&e->d_lr_gscr, Pmax > Pscr ? sizeof(double) * 4 * (size_t)(n - 1) * Pmax : 16);
+    if (rc) return GPH_EHIP;
+    if (h2d(e, e->d_slot_of, slot_of.data(), sizeof(int32_t) * e->L)) return GPH_EHIP;
+    e->lr.result = e->d_lr_result; e->lr.rec = e->d_lrec; e->lr.slot_of = e->d_slot_of; e->lr.gscr = e->d_lr_gscr;
+#ifndef GPH_HOSTEMU
+    HIPCHK(hipFuncSetAttribute((const void *)k_lrate_scan, hipFuncAttributeMaxDynamicSharedMemorySize, e->lr_lds_bytes));
+#endif
+  }
+  e->lr.finetune = finetune; e->lr.alpha = alpha;
+  e->lr.dataLnL = io->dataLogLikelihood; e->lr.logL = io->logLikelihood; e->lr.rateVar = io->rateVar;
+  LAUNCH1(e, 9, k_lrate_scan, e->lr_lds_bytes, e->lr);
+  double res[8];
+  int rc = d2h(e, res, e->d_lr_result, sizeof res);
+  if (rc) return rc;
+#ifndef GPH_HOSTEMU
+  if (e->timing_pending) {
+    float ms = 0;
+    e->timing_pending = false;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->last_ms[9] = ms;
+    e->cls_ms[9] += ms;
+  }
+#endif
+  if (res[4] != 0.0) { fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by the locus-rate scan\n", (int)res[4]); return GPH_EKERNEL; }
+  LAUNCH(e, 10, k_lrate_apply, (const GphLrRec *)e->d_lrec);
+  rc = finish_kernel(e);
+  if (rc) return rc;
+  io->accepted = (int64_t)res[0];
+  io->dataLogLikelihood = res[1];
+  io->logLikelihood = res[2];
+  io->rateVar = res[3];
+  return 0;
+}
+
 // canonical text dump (same format as oracle/gphocs_oracle_io.c go_dump_state's per-locus part)
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int32_t append)
 {
@@ -862,6 +968,7 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
     const GphEv *evr = (const GphEv *)(pg + y.o_ev);
     fprintf(f, "LOCUS %lld root %d dataLnL %a genLnL %a rng %u %u %u\n", (long long)(go + e->cfg.locus_begin), is[IS_ROOT],
             fs[FS_DATALNL], fs[FS_GENLNL], (unsigned)is[IS_RX], (unsigned)is[IS_RY], (unsigned)is[IS_RZ]);
+    if (e->var_rates) fprintf(f, "R %a\n", fs[FS_MUTRATE]);
     for (int i = 0; i < y.N; i++)
       fprintf(f, "N %d %d %d %d %a %d %d\n", i, nd[i].father, nd[i].left, nd[i].right, nd[i].age, nd[i].npop, i < y.n ? -1 : ne[i]);
     for (int pop = 0; pop < y.K; pop++) {

@@ -888,6 +888,7 @@ int gph_control_get(const gph_control *c, gph_config *cfg, gph_mcmc_config *mc, 
     mc->seed = c->randomSeed; mc->startMig = c->startMig; mc->doMixing = c->doMixing;
     mc->samplesPerLog = c->samplesPerLog; mc->numParameters = c->numParameters;
     mc->printFactors = c->printFactors.data();
+    mc->mutRateMode = c->mutRateMode; mc->varRatesAlpha = c->varRatesAlpha; mc->ftLocusRate = c->ftLocusRate;
   }
   if (info) {
     memset(info, 0, sizeof *info);

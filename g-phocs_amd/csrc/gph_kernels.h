@@ -179,7 +179,9 @@ GPH_DEV void random_gtree(GphRng &rng)
 }
 
 // initializeMCMC per-locus body, GPhoCS.c:1197-1214
-GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate)
+// preDraws: rndu() draws the locus's stream has already spent before the genealogy is sampled (the VAR-rate
+// start-up draws one per locus, GPhoCS.c:1163)
+GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate, int preDraws)
 {
   int i;
   /* blank page */
@@ -199,6 +201,7 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate)
   {
     GphRng rng;
     rng_load(rng);
+    for (i = 0; i < preDraws; i++) (void)l_rndu(rng);
     random_gtree(rng);
     rng_store(rng);
   }
@@ -664,6 +667,131 @@ GPH_DEV void kb_mix_commit(const GphDev &D, int g, double c, double lnc)
   }
   out_common(D, g);
   stage_out(D, g, D.pages, 0);
+}
+
+// ---------------------------------------------------------------- locus rates
+// UpdateLocusRate, GPhoCS.c:4598-4680.  The proposal is serial over loci by construction: every locus g trades
+// rate with the reference locus (genRateRef = 0), so the decision at g needs the reference locus's rate and
+// likelihood after every earlier decision.  Two kernels:
+//   kb_lrate_scan   ONE wavefront walks the loci in input order.  Per locus: draw the step from the locus's own
+//                   stream, evaluate the locus at its new rate and the reference locus at its new rate with the
+//                   stateless evaluator (lik_private: node records + sequence block staged in LDS, conditionals
+//                   in LDS scratch), decide, carry the running rate / likelihood of the reference locus and the
+//                   three accumulators (dataLogLikelihood, logLikelihood, rateVar: same additions in the same
+//                   order as the reference loop).  Writes one record per locus; touches no locus state.
+//   kb_lrate_apply  one wavefront per locus, all loci in parallel: RNG state written back; an accepted locus is
+//                   recomputed in place at its new rate (computeLocusDataLikelihood(0) + resetSaved, what the
+//                   reference did when it accepted) and must reproduce the scanned value bit for bit.  The
+//                   reference locus ends at its last accepted rate; its buffer parity is the number of accepted
+//                   proposals mod 2 (every accepted proposal flipped all its nodes once).
+struct GphLrRec { double rate, lnl; uint32_t rx, ry, rz; int32_t flag; };   // flag: accepted (reference locus: accept count)
+struct GphLrArgs {
+  double finetune, alpha, dataLnL, logL, rateVar;
+  int32_t o_gnd, o_rnd, o_rseq, o_scr, Pscr, unused;   // dynamic-LDS byte offsets; loci with P <= Pscr use LDS scratch
+  double *result;            // [0] accepted [1] dataLogLikelihood [2] logLikelihood [3] rateVar [4] error code
+  GphLrRec *rec;             // one per slot
+  const int32_t *slot_of;    // input-order index -> slot
+  double *gscr;              // [n-1][Pmax][4] scratch for loci with P > Pscr
+};
+
+GPH_DEV void lr_load(const GphDev &D, int j, int o_nd, int o_seq, int &P, int &root, double &rate, double &lnl, GphRng &rng)
+{
+  const char *pg = D.pages + (size_t)j * g_lay.page_bytes;
+#ifdef GPH_HOSTEMU
+  memcpy(gph_sm + o_nd, pg + g_lay.o_nd, (size_t)g_lay.N * sizeof(GphNode));
+#else
+  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
+  typedef GPH_LDS gu32x4 luint4;
+  if (GPH_LANE < g_lay.N) ((luint4 *)(GPH_SMB + o_nd))[GPH_LANE] = ((const gu32x4 *)(pg + g_lay.o_nd))[GPH_LANE];
+#endif
+  copy16_g2l(o_seq, D.seq + D.seq_off[j], (int)(D.seq_off[j + 1] - D.seq_off[j]));
+  const double *fs = (const double *)(pg + g_lay.o_fscal);
+  const int32_t *is = (const int32_t *)(pg + g_lay.o_iscal);
+  rate = RFLD(fs[FS_MUTRATE]);
+  lnl = RFLD(fs[FS_DATALNL]);
+  root = RFL(is[IS_ROOT]);
+  rng.x = (uint32_t)RFL(is[IS_RX]); rng.y = (uint32_t)RFL(is[IS_RY]); rng.z = (uint32_t)RFL(is[IS_RZ]);
+  P = RFL(D.P[j]);
+  GPH_SYNC();
+}
+
+GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
+{
+  int k, Pr, rootr, P, root, accepted = 0;
+  double rref, likref, rold, likold;
+  GphRng rng, rngr;
+  for (k = 0; k < CN_COUNT; k++) setCNT(k, 0);
+  const int jr = RFL(A.slot_of[0]);
+  lr_load(D, jr, A.o_rnd, A.o_rseq, Pr, rootr, rref, likref, rngr);
+  double dataLnL = A.dataLnL, logL = A.logL, rateVar = A.rateVar;
+  const double Ld = (double)D.Ltot;
+  gdbl *gs = (gdbl *)A.gscr;
+  for (int go = 1; go < D.L; go++) {
+    const int j = RFL(A.slot_of[go]);
+    GPH_SYNC();
+    lr_load(D, j, A.o_gnd, 0, P, root, rold, likold, rng);
+    double rnew = rold + A.finetune * l_rnd2normal8(rng);
+    rnew = l_reflect(rnew, 0, rold + rref);
+    const double rrefnew = rref + rold - rnew;
+    double lnacc = (A.alpha - 1) * gph_log((rnew * rrefnew) / (rold * rref));
+    double lnLd = -(likold + likref);
+    const double lg = lik_private(A.o_gnd, 0, P, root, rnew, A.o_scr, P > A.Pscr ? gs : (gdbl *)0);
+    lnLd += lg;
+    const double lr = lik_private(A.o_rnd, A.o_rseq, Pr, rootr, rrefnew, A.o_scr, Pr > A.Pscr ? gs : (gdbl *)0);
+    lnLd += lr;
+    lnacc += lnLd;
+    bool acc = UNI(lnacc >= 0);
+    if (!acc) acc = UNI(l_rndu(rng) < gph_exp(lnacc));
+    if (acc) {
+      accepted++;
+      dataLnL += lnLd;
+      logL += lnLd / Ld;
+      rateVar += (rnew * rnew + rrefnew * rrefnew - rold * rold - rref * rref) / Ld;
+      rref = rrefnew;
+      likref = lr;
+    }
+    if (GPH_LANE == 0) {
+      GphLrRec r;
+      r.rate = acc ? rnew : rold; r.lnl = acc ? lg : likold;
+      r.rx = rng.x; r.ry = rng.y; r.rz = rng.z; r.flag = acc ? 1 : 0;
+      A.rec[j] = r;
+    }
+    if (gph_failed()) break;
+  }
+  if (GPH_LANE == 0) {
+    GphLrRec r;
+    r.rate = rref; r.lnl = likref; r.rx = rngr.x; r.ry = rngr.y; r.rz = rngr.z; r.flag = accepted;
+    A.rec[jr] = r;
+    A.result[0] = accepted; A.result[1] = dataLnL; A.result[2] = logL; A.result[3] = rateVar; A.result[4] = CNT(CN_ERROR);
+  }
+}
+
+GPH_DEV void kb_lrate_apply(const GphDev &D, int g, const GphLrRec *rec)
+{
+  const GphLrRec r = rec[g];
+  const bool isref = (D.orig[g] + D.locus_begin) == 0;
+  const int flag = RFL(r.flag);
+  if (flag == 0) {
+    /* rejected (or an untouched reference locus): only the stream moved on */
+    if (GPH_LANE == 0) {
+      int32_t *is = (int32_t *)(D.pages + (size_t)g * g_lay.page_bytes + g_lay.o_iscal);
+      double *o = D.out + (size_t)g * GPH_OUT_SLOTS;
+      is[IS_RX] = (int32_t)r.rx; is[IS_RY] = (int32_t)r.ry; is[IS_RZ] = (int32_t)r.rz;
+      o[8] = 0; o[9] = 0; o[10] = 0; o[11] = 0; o[13] = 0;
+    }
+    return;
+  }
+  stage_in(D, g, D.pages, 1);
+  setISC(IS_RX, (int)r.rx); setISC(IS_RY, (int)r.ry); setISC(IS_RZ, (int)r.rz);
+  setFS(FS_MUTRATE, RFLD(r.rate));
+  const int reps = isref ? 2 - (flag & 1) : 1;
+  for (int k = 0; k < reps; k++) {
+    lik_compute(0);
+    lik_reset_saved();
+  }
+  if (!UNI(FS(FS_DATALNL) == RFLD(r.lnl))) gph_fail(120);   /* the scan and the in-place evaluation must agree bit for bit */
+  out_common(D, g);
+  stage_out(D, g, D.pages, 1);
 }
 
 // ---------------------------------------------------------------- end-of-iteration

@@ -447,11 +447,12 @@ GPH_DEV int cond_off(int node, int bit)
 
 // one child's factor for (pattern p, base a): computeSubtreeConditionals_new,
 // LocusDataLikelihood.c:1650-1673.  A leaf child is a base code (one-hot / N).
-GPH_DEV double child_factor(int child, const gdbl *cnd, int p, int a, double pe, double qe)
+template <class CP>
+GPH_DEV double child_factor(int child, CP cnd, int p, int a, double pe, double qe, int q_leaf = GPH_Q_LEAF)
 {
   double s0, s1, s2, s3, sa, S, Sp;
   if (child < g_lay.n) {
-    int code = gu8v(GPH_Q_LEAF, p * g_lay.n + child);
+    int code = gu8v(q_leaf, p * g_lay.n + child);
     s0 = (code == 4 || code == 0) ? 1.0 : 0.0;
     s1 = (code == 4 || code == 1) ? 1.0 : 0.0;
     s2 = (code == 4 || code == 2) ? 1.0 : 0.0;
@@ -517,27 +518,31 @@ GPH_DEV double bperm64(int byteaddr, double v)
   u.i[1] = __builtin_amdgcn_ds_bpermute(byteaddr, u.i[1]);
   return u.d;
 }
+#endif
 // prune_node() with every tree scalar already in (scalar) registers
-GPH_DEV void prune_node_r(int node, int l, int r, double pl, double pr, int cbn, int cbl, int cbr, int P, gdbl *cb)
+template <class DP>
+GPH_DEV void prune_node_r(int node, int l, int r, double pl, double pr, int cbn, int cbl, int cbr, int P, DP cb,
+                          int q_leaf = GPH_Q_LEAF)
 {
   double ql = 1 - 4.0 * pl;
   double qr = 1 - 4.0 * pr;
   const int nint = g_lay.n - 1;
-  gdbl *pc = cb + ((cbn * nint + (node - g_lay.n)) * P) * 4;
-  const gdbl *lc = cb + (l >= g_lay.n ? ((cbl * nint + (l - g_lay.n)) * P) * 4 : 0);
-  const gdbl *rc = cb + (r >= g_lay.n ? ((cbr * nint + (r - g_lay.n)) * P) * 4 : 0);
+  DP pc = cb + ((cbn * nint + (node - g_lay.n)) * P) * 4;
+  DP lc = cb + (l >= g_lay.n ? ((cbl * nint + (l - g_lay.n)) * P) * 4 : 0);
+  DP rc = cb + (r >= g_lay.n ? ((cbr * nint + (r - g_lay.n)) * P) * 4 : 0);
   for (int idx = GPH_LANE; idx < 4 * P; idx += GPH_NLANES) {
     int p = idx >> 2, a = idx & 3;
     double v = 1.0, f;
-    f = child_factor(l, lc, p, a, pl, ql);
+    f = child_factor(l, lc, p, a, pl, ql, q_leaf);
     v *= f;
-    f = child_factor(r, rc, p, a, pr, qr);
+    f = child_factor(r, rc, p, a, pr, qr, q_leaf);
     v *= f;
     pc[idx] = v;
   }
   GPH_WAVE_FENCE();
 }
 
+#ifndef GPH_HOSTEMU
 // ---- lanes = patterns (P <= 64): one lane owns pattern `lane` and its 4 base entries.
 // The 4 conditionals a lane just produced stay in its registers (q0..q3): when the next node
 // processed is the parent (the usual case: a dirty path is a chain), that child is not re-read
@@ -547,13 +552,15 @@ typedef GPH_GLB gph_d2 gdbl2;
 
 // factors of one child for the 4 bases of pattern `lane` (computeSubtreeConditionals_new,
 // LocusDataLikelihood.c:1650-1673; same operations in the same order as child_factor())
-GPH_DEVHOT void child_factor4(int child, const gdbl *cnd, bool fwd, double q0, double q1, double q2, double q3,
-                              double pe, double qe, bool act, double &f0, double &f1, double &f2, double &f3)
+template <class CP, class CP2>
+GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1, double q2, double q3,
+                              double pe, double qe, bool act, double &f0, double &f1, double &f2, double &f3,
+                              int q_leaf)
 {
   const int lane = GPH_LANE;
   if (child < g_lay.n) {
     /* leaf: one-hot (or N).  S = 1 exactly, so S*pe = pe and sa*qe is qe or 0: bit-identical shortcut */
-    const int code = act ? (int)gu8v(GPH_Q_LEAF, lane * g_lay.n + child) : 4;
+    const int code = act ? (int)gu8v(q_leaf, lane * g_lay.n + child) : 4;
     const double hit = pe + qe;
     f0 = code == 4 ? 1.0 : (code == 0 ? hit : pe);
     f1 = code == 4 ? 1.0 : (code == 1 ? hit : pe);
@@ -565,7 +572,7 @@ GPH_DEVHOT void child_factor4(int child, const gdbl *cnd, bool fwd, double q0, d
   if (!fwd) {
     gph_d2 a = {1.0, 1.0}, b = {1.0, 1.0};
     if (act) {
-      const gdbl2 *c2 = (const gdbl2 *)(cnd + 4 * lane);
+      CP2 c2 = (CP2)(cnd + 4 * lane);
       a = c2[0];
       b = c2[1];
     }
@@ -586,30 +593,31 @@ GPH_DEVHOT void child_factor4(int child, const gdbl *cnd, bool fwd, double q0, d
 
 // recompute node `node`; on entry q* hold node `prev`'s conditionals (prev < 0: nothing), on exit
 // this node's.  `fresh` = nodes written earlier in this evaluation (their stores may be in flight)
+template <class DP, class DP2>
 GPH_DEVHOT void prune_node_q(int node, int l, int r, double pl, double pr, int cbn, int cbl, int cbr,
-                             int P, gdbl *cb, int prev, uint64_t fresh,
-                             double &q0, double &q1, double &q2, double &q3)
+                             int P, DP cb, int prev, uint64_t fresh,
+                             double &q0, double &q1, double &q2, double &q3, int q_leaf = GPH_Q_LEAF)
 {
   const double ql = 1 - 4.0 * pl;
   const double qr = 1 - 4.0 * pr;
   const int nint = g_lay.n - 1, n = g_lay.n, lane = GPH_LANE;
   const bool act = lane < P;
-  gdbl *pc = cb + ((cbn * nint + (node - n)) * P) * 4;
-  const gdbl *lc = cb + (l >= n ? ((cbl * nint + (l - n)) * P) * 4 : 0);
-  const gdbl *rc = cb + (r >= n ? ((cbr * nint + (r - n)) * P) * 4 : 0);
+  DP pc = cb + ((cbn * nint + (node - n)) * P) * 4;
+  DP lc = cb + (l >= n ? ((cbl * nint + (l - n)) * P) * 4 : 0);
+  DP rc = cb + (r >= n ? ((cbr * nint + (r - n)) * P) * 4 : 0);
   const bool fl = l == prev, fr = r == prev;
   /* a child recomputed earlier in this evaluation but not held in registers: its stores must
    * have landed before it is re-read */
   if ((l >= n && !fl && ((fresh >> l) & 1)) || (r >= n && !fr && ((fresh >> r) & 1))) GPH_WAVE_FENCE();
   double f0, f1, f2, f3, g0, g1, g2, g3;
-  child_factor4(l, lc, fl, q0, q1, q2, q3, pl, ql, act, f0, f1, f2, f3);
-  child_factor4(r, rc, fr, q0, q1, q2, q3, pr, qr, act, g0, g1, g2, g3);
+  child_factor4<DP, DP2>(l, lc, fl, q0, q1, q2, q3, pl, ql, act, f0, f1, f2, f3, q_leaf);
+  child_factor4<DP, DP2>(r, rc, fr, q0, q1, q2, q3, pr, qr, act, g0, g1, g2, g3, q_leaf);
   q0 = f0 * g0;
   q1 = f1 * g1;
   q2 = f2 * g2;
   q3 = f3 * g3;
   if (act) {
-    gdbl2 *o2 = (gdbl2 *)(pc + 4 * lane);
+    DP2 o2 = (DP2)(pc + 4 * lane);
     gph_d2 a = {q0, q1}, b = {q2, q3};
     o2[0] = a;
     o2[1] = b;
@@ -687,8 +695,8 @@ GPH_DEVHOT double lik_compute(int useOld)
         if (useOld && !(dirty & bit)) { dirty |= bit; cbit ^= bit; newly |= bit; }   /* copyNodeConditionals */
         const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
         STAMP_BEGIN(7);
-        prune_node_r(node, l, r, rdlane64(pe, l), rdlane64(pe, r), (int)((cbit >> node) & 1),
-                     (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, cb);
+        prune_node_r<gdbl *>(node, l, r, rdlane64(pe, l), rdlane64(pe, r), (int)((cbit >> node) & 1),
+                             (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, cb);
         STAMP_END(7);
         todo &= ~bit;
       }
@@ -700,8 +708,8 @@ GPH_DEVHOT double lik_compute(int useOld)
       if (useOld && !(dirty & bit)) { dirty |= bit; cbit ^= bit; newly |= bit; }     /* copyNodeConditionals */
       const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
       STAMP_BEGIN(7);
-      prune_node_q(node, l, r, rdlane64(pe, l), rdlane64(pe, r), (int)((cbit >> node) & 1),
-                   (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, cb, prev, fresh, q0, q1, q2, q3);
+      prune_node_q<gdbl *, gdbl2 *>(node, l, r, rdlane64(pe, l), rdlane64(pe, r), (int)((cbit >> node) & 1),
+                                    (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, cb, prev, fresh, q0, q1, q2, q3);
       STAMP_END(7);
       todo &= ~bit;
       fresh |= bit;
@@ -860,6 +868,154 @@ GPH_DEVHOT double lik_compute(int useOld)
   return lnl;
 }
 
+#endif
+
+// ---------------------------------------------------------------- stateless full evaluation
+// The value computeLocusDataLikelihood(useOld = 0) (LocusDataLikelihood.c:426-483) returns for a locus at
+// mutation rate `rate`, WITHOUT touching the locus: its node records (GphNode[N]) sit at byte offset o_nd and
+// its sequence block at o_seq of the dynamic LDS, the conditionals go to a single-buffer scratch array
+// [n-1][P][4] (dynamic LDS at o_scr, or global memory when gscr != NULL).  Same arithmetic, same order of
+// operations as lik_compute(0): the serial scan of UpdateLocusRate (kb_lrate_scan) uses it to decide, the
+// accepted loci are then recomputed in place by lik_compute(0) and must reproduce the value bit for bit.
+#ifndef GPH_HOSTEMU
+typedef GPH_LDS gph_d2 ld2;
+template <class DP, class DP2>
+GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rate, DP scr)
+{
+  const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
+  const int q_leaf = o_seq + GPH_Q_LEAF, q_phases = o_seq + GPH_Q_PHASES(P, n), q_count = o_seq + GPH_Q_COUNT(P, n),
+            q_terms = o_seq + GPH_Q_TERMS(P, n);
+  const bool isnode = lane < N;
+  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
+  union { gu32x4 v; GphNode n; } nu;
+  GphNode me = {0.0, -1, -1, -1, -1};
+  if (isnode) { nu.v = ((GPH_LDS gu32x4 *)(GPH_SMB + o_nd))[lane]; me = nu.n; }   /* the lane's node record: one 16-byte read */
+  const int le = me.left, ri = me.right;
+  const double ag = me.age;
+  const uint64_t internal = (((uint64_t)1 << N) - 1) & ~(((uint64_t)1 << n) - 1);
+  uint64_t todo = internal, fresh = 0;
+  double pe = 0.0;
+  {
+    const int fa = me.father;
+    if (isnode && fa >= 0) pe = edge_prob_v(rate * (((lf64 *)(GPH_SMB + o_nd))[2 * fa] - ag));   /* GphNode::age of the father */
+  }
+  const bool wide = P > GPH_WAVE;
+  double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+  int prev = -1;
+  GPH_WAVE_FENCE();
+  for (int guard = 0; todo != 0; guard++) {
+    bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
+    uint64_t rmask = __ballot(rdy);
+    if (rmask == 0 || guard > N) { gph_fail(100); return 0.0; }
+    if (wide) {
+      while (rmask) {
+        const int node = __builtin_ctzll(rmask);
+        rmask &= rmask - 1;
+        const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
+        prune_node_r<DP>(node, l, r, rdlane64(pe, l), rdlane64(pe, r), 0, 0, 0, P, scr, q_leaf);
+        todo &= ~((uint64_t)1 << node);
+      }
+    } else {
+      const uint64_t pm = __ballot(isnode && (le == prev || ri == prev)) & rmask;
+      const int node = __builtin_ctzll(pm ? pm : rmask);
+      const uint64_t bit = (uint64_t)1 << node;
+      const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
+      prune_node_q<DP, DP2>(node, l, r, rdlane64(pe, l), rdlane64(pe, r), 0, 0, 0, P, scr, prev, fresh, q0, q1, q2, q3, q_leaf);
+      todo &= ~bit;
+      fresh |= bit;
+      prev = node;
+    }
+  }
+  /* root reduction, LocusDataLikelihood.c:466-479 (see lik_compute) */
+  double lnl = 0.0;
+  DP rc = scr + ((root - n) * P) * 4;
+  if (!wide) {
+    double term = 0.0;
+    const int ph = lane < P ? gu8v(q_phases, lane) : 0;
+    double prob = 0.0;
+    prob += q0;
+    prob += q1;
+    prob += q2;
+    prob += q3;
+    for (int k = 1; __ballot(ph > k) != 0; k++) {
+      const int src = ((lane + k) & (GPH_WAVE - 1)) << 2;
+      const double r0 = bperm64(src, q0), r1 = bperm64(src, q1), r2 = bperm64(src, q2), r3 = bperm64(src, q3);
+      if (ph > k) {
+        prob += r0;
+        prob += r1;
+        prob += r2;
+        prob += r3;
+      }
+    }
+    if (ph > 0) {
+      const int nc = 4 * ph;
+      double avg;
+      if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
+      else avg = prob / nc;
+      term = gph_log(avg) * gi32v(q_count, lane);
+    }
+    uint64_t pm = __ballot(ph > 0);
+    while (pm) { lnl += rdlane64(term, __builtin_ctzll(pm)); pm &= pm - 1; }
+  } else {
+    GPH_WAVE_FENCE();
+    for (int p = lane; p < P; p += GPH_NLANES) {
+      int ph = gu8v(q_phases, p);
+      if (ph > 0) {
+        int nc = 4 * ph;
+        double prob = 0.0;
+        for (int c = 0; c < nc; c++) prob += rc[p * 4 + c];
+        sf64(q_terms, p, gph_log(prob / nc) * gi32v(q_count, p));
+      }
+    }
+    GPH_SYNC();
+    for (int p = 0; p < P; p++)
+      if (gu8(q_phases, p) > 0) lnl += gf64(q_terms, p);
+  }
+  return lnl;
+}
+GPH_DEVHOT double lik_private(int o_nd, int o_seq, int P, int root, double rate, int o_scr, gdbl *gscr)
+{
+  P = RFL(P); root = RFL(root); rate = RFLD(rate);
+  if (P == 0) return 0.0;
+  if (gscr) return lik_private_t<gdbl *, gdbl2 *>(o_nd, o_seq, P, root, rate, gscr);
+  return lik_private_t<lf64 *, ld2 *>(o_nd, o_seq, P, root, rate, (lf64 *)(GPH_SMB + o_scr));
+}
+#else
+GPH_DEV double lik_private(int o_nd, int o_seq, int P, int root, double rate, int o_scr, gdbl *gscr)
+{
+  const int n = g_lay.n, N = g_lay.N;
+  if (P == 0) return 0.0;
+  const int q_leaf = o_seq + GPH_Q_LEAF, q_phases = o_seq + GPH_Q_PHASES(P, n), q_count = o_seq + GPH_Q_COUNT(P, n);
+  const GphNode *nds = (const GphNode *)(gph_sm + o_nd);
+  double *scr = gscr ? gscr : (double *)(gph_sm + o_scr);
+  int ord[GPH_CAP_N], st[GPH_CAP_N], nord = 0, sp = 0, i, p;
+  st[sp++] = root;
+  while (sp > 0) {
+    int node = st[--sp];
+    if (nord >= N) { gph_fail(100); return 0.0; }
+    ord[nord++] = node;
+    if (nds[node].left >= n) st[sp++] = nds[node].left;
+    if (nds[node].right >= n) st[sp++] = nds[node].right;
+  }
+  for (i = nord - 1; i >= 0; i--) {
+    const int node = ord[i], l = nds[node].left, r = nds[node].right;
+    const double pl = edge_prob(rate * (nds[node].age - nds[l].age));
+    const double pr = edge_prob(rate * (nds[node].age - nds[r].age));
+    prune_node_r<double *>(node, l, r, pl, pr, 0, 0, 0, P, scr, q_leaf);
+  }
+  double lnl = 0.0;
+  const double *rc = scr + ((root - n) * P) * 4;
+  for (p = 0; p < P; p++) {
+    int ph = gu8v(q_phases, p);
+    if (ph > 0) {
+      int nc = 4 * ph, c;
+      double prob = 0.0;
+      for (c = 0; c < nc; c++) prob += rc[p * 4 + c];
+      lnl += gph_log(prob / nc) * gi32v(q_count, p);
+    }
+  }
+  return lnl;
+}
 #endif
 
 // scaleAllNodeAges, LocusDataLikelihood.c:895-917

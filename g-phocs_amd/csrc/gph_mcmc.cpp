@@ -29,6 +29,9 @@ struct gph_mcmc {
   std::vector<double> thetaAlpha, thetaBeta, thetaStart, ageAlpha, ageBeta, ageStart, mrAlpha, mrBeta, ftTaus;
   std::vector<double> printFactors, paramVals;
   double ftCoalTime, ftMigTime, ftTheta, ftMigRate, ftMixing;
+  int mutRateMode;              // 0 CONST, 1 VAR (UpdateLocusRate is live), 2 FIXED
+  double varRatesAlpha, ftLocusRate, rateVar;
+  int64_t accLocusRate;
   int seed, startMig, doMixing, samplesPerLog, numParameters;
   uint32_t gx, gy, gz;          // general RNG slot
   double logLikelihood, dataLogLikelihood;
@@ -436,6 +439,7 @@ static void record_param_vals(gph_mcmc *m)
   for (int b = 0; b < m->B; b++) m->paramVals[ind++] = m->migRate[b];
   for (int pop = 0; pop < m->Kc; pop++)
     if (m->updateSampleAge[pop] || m->sampleAge[pop] > 0.0) m->paramVals[ind++] = m->sampleAge[pop];
+  if (m->mutRateMode == 1) m->paramVals[ind++] = sqrt(m->rateVar);   /* GPhoCS.c:842-847 */
 }
 
 extern "C" {
@@ -466,6 +470,8 @@ int gph_mcmc_create(gph_engine *e, const gph_config *cfg, const gph_mcmc_config 
   m->ftTaus.assign(mc->ftTaus, mc->ftTaus + m->K);
   m->ftCoalTime = mc->ftCoalTime; m->ftMigTime = mc->ftMigTime; m->ftTheta = mc->ftTheta;
   m->ftMigRate = mc->ftMigRate; m->ftMixing = mc->ftMixing;
+  m->mutRateMode = mc->mutRateMode; m->varRatesAlpha = mc->varRatesAlpha; m->ftLocusRate = mc->ftLocusRate;
+  m->rateVar = 0.0; m->accLocusRate = 0;
   m->seed = mc->seed; m->startMig = mc->startMig; m->doMixing = mc->doMixing; m->samplesPerLog = mc->samplesPerLog;
   m->numParameters = mc->numParameters;
   m->printFactors.assign(mc->printFactors, mc->printFactors + mc->numParameters);
@@ -502,6 +508,27 @@ int gph_mcmc_initialize(gph_mcmc *m, int64_t *totalCoals)
   double sumGen = 0, sumData = 0;
   if (!m) return GPH_EARG;
   sample_pop_parameters(m);
+  if (m->mutRateMode == 1) {
+    /* locus rates 0.8 + 0.4 u from each locus's own stream, normalised to mean 1 (GPhoCS.c:1157-1178).  Every
+     * locus stream starts in the same state (utils.c:421-426), so every locus draws the same u: the host
+     * replays the sums of the reference loop and hands the engine the rates and the one spent draw. */
+    uint32_t x = 11, y = 23, z = 170u * ((uint32_t)m->seed % 178u) + 137u;
+    x = 171u * (x % 177u) - 2u * (x / 177u);
+    y = 172u * (y % 176u) - 35u * (y / 176u);
+    z = 170u * (z % 178u) - 63u * (z / 178u);
+    double u = x / 30269.0 + y / 30307.0 + z / 30323.0;
+    u = (u - (int)u);
+    const double r0 = 0.8 + 0.4 * u;
+    double total = 0.0;
+    for (int64_t g = 0; g < m->Ltot; g++) total += r0;
+    total /= m->Ltot;
+    const double r = r0 / total;
+    m->rateVar = 0.0;
+    for (int64_t g = 0; g < m->Ltot; g++) m->rateVar += (r - 1) * (r - 1);
+    m->rateVar /= m->Ltot;
+    std::vector<double> rates((size_t)gph_engine_num_loci(m->e), r);
+    if ((rc = gph_engine_set_locus_rates(m->e, rates.data(), 1, 1))) return rc;
+  }
   if ((rc = push_model(m))) return rc;
   if ((rc = gph_engine_seed(m->e, (uint32_t)m->seed))) return rc;
   if ((rc = gph_engine_init_genealogies(m->e, &sumGen, &sumData))) return rc;
@@ -533,6 +560,15 @@ int gph_mcmc_iteration(gph_mcmc *m, int32_t iteration)
   m->logLikelihood += S.dLog_spr;
   m->acc[2] += S.accepted_spr;
   rec_line(m, iteration, "SPR", (long)S.accepted_spr);
+  if (m->mutRateMode == 1) {
+    // UpdateLocusRate, GPhoCS.c:1554-1563, 4598-4680
+    gph_locus_rate_result R;
+    R.accepted = 0; R.dataLogLikelihood = m->dataLogLikelihood; R.logLikelihood = m->logLikelihood; R.rateVar = m->rateVar;
+    if ((rc = gph_engine_locus_rate_update(m->e, m->ftLocusRate, m->varRatesAlpha, &R))) return rc;
+    m->dataLogLikelihood = R.dataLogLikelihood; m->logLikelihood = R.logLikelihood; m->rateVar = R.rateVar;
+    m->accLocusRate += R.accepted;
+    rec_line(m, iteration, "LRATE", (long)R.accepted);
+  }
   if ((rc = refresh_totals(m))) return rc;
   if ((rc = update_theta(m, m->ftTheta, &acc))) return rc;
   m->acc[3] += acc;
@@ -616,6 +652,7 @@ int gph_mcmc_dump_state(gph_mcmc *m, const char *path, int32_t withCond)
   for (int b = 0; b < m->B; b++) fprintf(f, " %a %a %a", m->migRate[b], m->bandStart[b], m->bandEnd[b]);
   fprintf(f, "\n");
   fprintf(f, "GLOBAL %a %a %u %u %u\n", m->logLikelihood, m->dataLogLikelihood, m->gx, m->gy, m->gz);
+  if (m->mutRateMode == 1) fprintf(f, "RATEVAR %a\n", m->rateVar);
   fprintf(f, "TOTALS");
   for (int p = 0; p < m->K; p++) fprintf(f, " %a %d", m->tot_coal[p], (int)m->tot_ncoal[p]);
   for (int b = 0; b < m->B; b++) fprintf(f, " %a %d", m->tot_mig[b], (int)m->tot_nmig[b]);
@@ -648,6 +685,21 @@ int gph_mcmc_set_finetunes(gph_mcmc *m, double coalTime, double migTime, double 
   if (!m) return GPH_EARG;
   m->ftCoalTime = coalTime; m->ftMigTime = migTime; m->ftTheta = theta; m->ftMigRate = migRate; m->ftMixing = mixing;
   if (taus) for (int p = 0; p < m->K; p++) m->ftTaus[p] = taus[p];
+  return 0;
+}
+
+int gph_mcmc_set_locus_rate_finetune(gph_mcmc *m, double locusRate)
+{
+  if (!m) return GPH_EARG;
+  m->ftLocusRate = locusRate;
+  return 0;
+}
+
+int gph_mcmc_locus_rate_state(gph_mcmc *m, int64_t *accepted, double *rateVar)
+{
+  if (!m) return GPH_EARG;
+  if (accepted) *accepted = m->accLocusRate;
+  if (rateVar) *rateVar = m->rateVar;
   return 0;
 }
 

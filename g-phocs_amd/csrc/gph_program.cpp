@@ -62,7 +62,8 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
   if ((rc = gph_control_read(ctl, ctl2, &C))) return fail(rc, "reading the control file");
   gph_control_get(C, &cfg, &mc, &info);
   if (lead) printf("Done.\n");
-  if (info.mutRateMode == 1) return fail(GPH_EARG, "locus-mut-rate VAR (UpdateLocusRate is serial over loci upstream and not offloaded)");
+  if (info.mutRateMode == 1 && world > 1)
+    return fail(GPH_EARG, "locus-mut-rate VAR with several ranks (UpdateLocusRate couples every locus to locus 0 serially: one GPU only)");
   if (mc.seed < 0) {
     if (world > 1) return fail(GPH_EARG, "random-seed must be given in the control file when several ranks run one chain");
     mc.seed = abs(2 * (int)time(NULL) + 1);   /* GPhoCS.c:188-191 */
@@ -104,6 +105,7 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
     fprintf(trace, "\tm_%s->%s", gph_control_pop_name(C, cfg.bandSrc[b]), gph_control_pop_name(C, cfg.bandTgt[b]));
   for (int p = 0; p < cfg.Kc; p++)
     if (mc.updateSampleAge[p] || mc.sampleAge[p] > 0.0) fprintf(trace, "\ttau_%s", gph_control_pop_name(C, p));
+  if (info.mutRateMode == 1) fprintf(trace, "\tVariance-Mut");   /* GPhoCS.c:1311-1312 */
   fprintf(trace, "\tData-ld-ln\tFull-ld-ln\n");
 
   if (lead) printf("Starting MCMC: %d burnin, %d running, sampled every %d iteration(s).\n", info.burnin, info.numSamples, info.sampleSkip);
@@ -114,12 +116,13 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
   auto t1 = std::chrono::steady_clock::now();
   // log periods and the find-finetunes search, GPhoCS.c:1401-1447, 1808-2249
   int samplesPerLog = mc.samplesPerLog, findingFinetunes = 0;
-  Finetune fCoal{mc.ftCoalTime}, fMig{mc.ftMigTime}, fTheta{mc.ftTheta}, fRate{mc.ftMigRate}, fMix{mc.ftMixing};
+  Finetune fCoal{mc.ftCoalTime}, fMig{mc.ftMigTime}, fTheta{mc.ftTheta}, fRate{mc.ftMigRate}, fMix{mc.ftMixing}, fLocus{mc.ftLocusRate};
   std::vector<Finetune> fTau(cfg.K);
   for (int p = 0; p < cfg.K; p++) fTau[p].v = mc.ftTaus[p];
   auto push_finetunes = [&]() {
     std::vector<double> taus(cfg.K);
     for (int p = 0; p < cfg.K; p++) taus[p] = fTau[p].v;
+    gph_mcmc_set_locus_rate_finetune(M, fLocus.v);
     return gph_mcmc_set_finetunes(M, fCoal.v, fMig.v, fTheta.v, fRate.v, fMix.v, taus.data());
   };
   if (info.findFinetunes) {
@@ -127,12 +130,12 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
     samplesPerLog = info.findFinetunesSamplesPerStep;
     if (lead) printf("   ---  Dynamically finding finetune settings for the first %d samples, updating finetunes every %d samples  ---- \n",
            samplesPerLog * info.findFinetunesNumSteps, samplesPerLog);
-    for (Finetune *f : {&fCoal, &fMig, &fTheta, &fRate, &fMix}) if (f->v < 0) f->v = 1.0;
+    for (Finetune *f : {&fCoal, &fMig, &fTheta, &fRate, &fMix, &fLocus}) if (f->v < 0) f->v = 1.0;
     for (int p = 0; p < cfg.K; p++) if (fTau[p].v < 0) fTau[p].v = 1.0;
     if ((rc = push_finetunes())) return fail(rc, "gph_mcmc_set_finetunes");
     gph_mcmc_set_log_period(M, samplesPerLog);
   }
-  int64_t logCount = 1, a0[9] = {0}, a[9];
+  int64_t logCount = 1, a0[9] = {0}, a[9], aLocus0 = 0, aLocus = 0;
   std::vector<int64_t> t0v(cfg.K, 0), tv(cfg.K, 0);
   for (int it = -info.burnin; it < info.numSamples; it++) {
     if ((rc = gph_mcmc_iteration(M, it))) return fail(rc, "gph_mcmc_iteration");
@@ -159,6 +162,8 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
       const double pTheta = (a[3] - a0[3]) * 100.0 / (lc * cfg.K);
       const double pRate = (a[4] - a0[4]) * 100.0 / (lc * cfg.B + 0.000001);
       const double pMix = (a[6] - a0[6]) * 100.0 / lc;
+      gph_mcmc_locus_rate_state(M, &aLocus, nullptr);
+      const double pLocus = (aLocus - aLocus0) * 100.0 / (lc * (double)(info.numLoci - 1));   /* GPhoCS.c:1842-1845 */
       double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
       if (lead) printf("%7d   %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    ", it + 1, pCoal, pMig, pSpr, pTheta, pRate);
       for (int p = cfg.Kc; p < cfg.K; p++) if (lead) printf("%5.1f%%    ", 2 * (tv[p] - t0v[p]) * 100.0 / lc);
@@ -166,14 +171,16 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
       fflush(stdout);
       if (findingFinetunes) {
         fCoal.adjust(pCoal); fMig.adjust(pMig); fTheta.adjust(pTheta); fRate.adjust(pRate); fMix.adjust(pMix);
+        fLocus.adjust(pLocus);
         for (int p = cfg.Kc; p < cfg.K; p++) fTau[p].adjust(2 * (tv[p] - t0v[p]) * 100.0 / lc);
         if ((rc = push_finetunes())) return fail(rc, "gph_mcmc_set_finetunes");
         if (lead) printf("          %-9.7lf %-9.7lf           %-9.7lf %-9.7lf ", fCoal.v, fMig.v, fTheta.v, fRate.v);
         for (int p = cfg.Kc; p < cfg.K; p++) if (lead) printf("%-9.7lf ", fTau[p].v);
-        if (lead) printf("          %-9.7lf \n", fMix.v);
+        if (lead) printf("          %-9.7lf %-9.7lf \n", fLocus.v, fMix.v);
       }
       logCount = 1;
       memcpy(a0, a, sizeof a0);
+      aLocus0 = aLocus;
       t0v = tv;
       if (findingFinetunes && it + 1 >= info.findFinetunesSamplesPerStep * info.findFinetunesNumSteps) {
         findingFinetunes = 0;

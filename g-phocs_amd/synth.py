@@ -33,6 +33,14 @@ def _taus(kc):
     return taus
 
 
+def make_var_rates(p, alpha, finetune):
+    """switch a synthetic pack to `locus-mut-rate VAR alpha` (UpdateLocusRate live): one more recorded parameter"""
+    p.mutRateMode, p.varRatesAlpha, p.ftLocusRate = 1, float(alpha), float(finetune)
+    p.numParameters += 1
+    p.printFactors = np.concatenate([p.printFactors, [1.0]])
+    return p
+
+
 def make_model(pack, config, seed=12345, samples_per_log=100, start_mig=0, do_mixing=None, mig_beta=0.00001):
     """fills the model / prior / finetune fields of `pack` like sample-control-file.ctl:12-27"""
     cfg = CONFIGS[config]
@@ -214,6 +222,8 @@ def write_pack(p, path):
                 f"{p.samplesPerLog} {p.mutRateMode}\n")
         f.write("finetunes " + " ".join(float(x).hex() for x in
                                         [p.ftCoalTime, p.ftMigTime, p.ftTheta, p.ftMigRate, p.ftMixing] + list(p.ftTaus)) + "\n")
+        if p.mutRateMode == 1:
+            f.write(f"locusrate {float(p.varRatesAlpha).hex()} {float(p.ftLocusRate).hex()}\n")
         f.write(f"printFactors {p.numParameters} " + " ".join(float(x).hex() for x in p.printFactors) + "\n")
         for g in range(p.L):
             o0, o1 = int(p.pattern_offsets[g]), int(p.pattern_offsets[g + 1])

@@ -116,6 +116,20 @@ int gph_engine_tau_revert(gph_engine *e, int64_t first_conflict_locus);
 int gph_engine_mixing_evaluate(gph_engine *e, double c, double *dataDelta);
 int gph_engine_mixing_commit(gph_engine *e, double c, double lnc);
 int gph_engine_mixing_revert(gph_engine *e);
+/* UpdateLocusRate (GPhoCS.c:4598-4680; `locus-mut-rate VAR alpha`).  The reference loop is serial over loci (each
+ * proposal also moves the rate of the reference locus, genRateRef = 0): one wavefront scans the loci in input
+ * order with a stateless evaluator, the accepted loci are then rewritten in parallel.  in/out: the three
+ * accumulators the reference updates per accepted proposal (dataState.dataLogLikelihood, .logLikelihood,
+ * .rateVar); returns the accept count.  finetune <= 0 returns 0 accepted at once (:4606).  One GPU only. */
+typedef struct gph_locus_rate_result {
+  int64_t accepted;
+  double dataLogLikelihood, logLikelihood, rateVar;
+} gph_locus_rate_result;
+int gph_engine_locus_rate_update(gph_engine *e, double finetune, double varRatesAlpha, gph_locus_rate_result *io);
+/* starting rates of the local loci in input order, before gph_engine_init_genealogies (initializeMCMC's VAR
+ * branch, GPhoCS.c:1157-1178: the host draws and normalises, `draws` = rndu() draws each locus's stream spent
+ * on it -- 1 there); variable != 0 makes the rates part of the dumped state */
+int gph_engine_set_locus_rates(gph_engine *e, const double *rates, int32_t draws, int32_t variable);
 int gph_engine_apply_theta(gph_engine *e, int32_t pop, double lnc, double thetaold, double thetanew);
 int gph_engine_apply_migrate(gph_engine *e, int32_t band, double lnc, double old_rate, double new_rate);
 /* sums over ALL ranks; num_* returned as doubles holding exact integers */
@@ -129,7 +143,7 @@ int gph_engine_get_counters(gph_engine *e, gph_counters *out, int32_t reset);
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditionals, int32_t append);
 /* timing of the last launch of a named kernel class, measured with HIP events on the
  * engine's own stream: which = 0 sweep, 1 tau_eval, 2 mix_eval, 3 init, 4 check,
- * 5 tau_commit, 6 tau_revert, 7 mix_commit, 8 sync */
+ * 5 tau_commit, 6 tau_revert, 7 mix_commit, 8 sync, 9 locus-rate scan, 10 locus-rate apply */
 int gph_engine_last_kernel_ms(gph_engine *e, int32_t which, double *ms);
 /* accumulated per class: out5 = {launches, summed ms, evaluations, algorithmic bytes, recomputed nodes} */
 int gph_engine_class_stats(gph_engine *e, int32_t which, double *out5, int32_t reset);
@@ -154,6 +168,8 @@ typedef struct {
   int32_t seed, startMig, doMixing, samplesPerLog;
   int32_t numParameters;
   const double *printFactors;                          /* [numParameters] */
+  int32_t mutRateMode;                                 /* 0 CONST, 1 VAR (UpdateLocusRate runs, GPhoCS.c:1554), 2 FIXED */
+  double varRatesAlpha, ftLocusRate;                   /* locus-mut-rate VAR <alpha>, finetune-locus-rate */
 } gph_mcmc_config;
 
 int gph_mcmc_create(gph_engine *e, const gph_config *cfg, const gph_mcmc_config *mc, gph_mcmc **out);
@@ -176,6 +192,10 @@ int gph_mcmc_set_finetunes(gph_mcmc *m, double coalTime, double migTime, double 
 /* iterations between two checkAll() resynchronisations (= the log period, GPhoCS.c:1811-1821; the find-finetunes
  * phase uses find-finetunes-samples-per-step instead of iterations-per-log) */
 int gph_mcmc_set_log_period(gph_mcmc *m, int32_t iterations);
+/* finetune-locus-rate (changed by the find-finetunes search), and the running state of UpdateLocusRate:
+ * cumulative accept count and dataState.rateVar */
+int gph_mcmc_set_locus_rate_finetune(gph_mcmc *m, double locusRate);
+int gph_mcmc_locus_rate_state(gph_mcmc *m, int64_t *accepted, double *rateVar);
 /* recordParamVals (GPhoCS.c:802-849) of the last iteration: thetas, taus, migration rates, sample ages */
 int gph_mcmc_param_vals(gph_mcmc *m, double *vals, int32_t n);
 

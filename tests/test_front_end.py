@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
 import gphocs_amd as G  # noqa: E402
 import run_hostemu as R  # noqa: E402
 
-CASES = ["g1", "g2", "m3", "m4", "c5", "s3", "a6", "a7", "z0", "stress"]
+CASES = ["g1", "g2", "m3", "m4", "c5", "s3", "a6", "a7", "z0", "stress", "v8", "v9"]
 
 
 @pytest.fixture(scope="module")
@@ -52,7 +52,7 @@ def test_control_and_sequences_match_reference_pack(lib, name):
         got = G.Pack.from_control(name + ".ctl", lib=lib, threads=3)
     for f in ("n", "Kc", "K", "B", "rootPop", "L", "seed", "startMig", "doMixing", "samplesPerLog", "mutRateMode",
               "numParameters", "burnin", "sampleSkip", "ftCoalTime", "ftMigTime", "ftTheta", "ftMigRate",
-              "ftMixing", "popName"):
+              "ftMixing", "popName") + (("varRatesAlpha", "ftLocusRate") if ref.mutRateMode == 1 else ()):
         assert getattr(ref, f) == getattr(got, f), f
     for f in ("samplesPerPop", "popFather", "popSon0", "popSon1", "sampleAge", "updateSampleAge", "thetaAlpha",
               "thetaBeta", "thetaStart", "ageAlpha", "ageBeta", "ageStart", "ftTaus", "printFactors", "mutRates"):
@@ -73,7 +73,7 @@ def test_thread_count_does_not_change_the_result(lib):
         assert np.array_equal(getattr(a, f), getattr(b, f))
 
 
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8"])
 def test_program_writes_the_reference_trace_file(lib, name, tmp_path):
     """same control file + sequence file -> the trace file of the real G-PhoCS binary, byte for byte
     (f3: find-finetunes TRUE -- the step-size search of performMCMC, GPhoCS.c:1896-2180, incl. its acceptance

@@ -8,6 +8,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from conftest import GOLDEN, REPO
@@ -15,7 +16,7 @@ from parity_util import compare_records, compare_states
 
 pytestmark = pytest.mark.gpu
 
-CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, "a7": 100, "z0": 12}
+CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, "a7": 100, "z0": 12, "v8": 60, "v9": 60}
 
 
 @pytest.fixture(scope="module")
@@ -106,6 +107,45 @@ def test_scale_parity_against_live_oracle(G, oracle_cli, tmp_path, config, loci,
     print(f"config {config}: {loci} loci x {iters} iterations, worst accumulator rel diff {worst:.3e}, evals {cnt['evals']}")
 
 
+@pytest.mark.parametrize("config,loci,iters,mut,alpha,ft,seqlen,pscr", [
+    (3, 2000, 20, 1.0, 1.0, 0.3, 1000, None), (4, 1200, 16, 6.5, 1.6, 1.2, 1000, None),
+    (2, 1500, 16, 14.0, 0.7, 0.6, 1000, None),
+    (4, 400, 10, 24.0, 1.6, 1.2, 3000, None),    # loci with more than 64 phased patterns: strided path, LDS scratch
+    (4, 400, 10, 24.0, 1.6, 1.2, 3000, "30")])   # ... and conditionals scratch in global memory beyond 30 patterns
+def test_locus_rate_scale_parity_against_live_oracle(G, oracle_cli, tmp_path, monkeypatch, config, loci, iters, mut,
+                                                     alpha, ft, seqlen, pscr):
+    """`locus-mut-rate VAR`: UpdateLocusRate (one wavefront scanning the loci in order + parallel write-back) over
+    thousands of loci against the oracle's serial loop on the same pack: small and large steps (reflections at both
+    ends of (0, rold + rref)), alpha != 1 (Dirichlet prior term), pattern-rich loci (mut 14: loci with more than 64
+    phased patterns take the strided path and, beyond the LDS scratch, the global scratch).  Counters exact,
+    accumulators <= 1e-10 relative, per-locus state (rates included) field by field."""
+    from gphocs_amd_pkg import synth
+    if pscr:
+        monkeypatch.setenv("GPH_LR_PSCR", pscr)
+    pk = synth.make_synthetic_pack(G.Pack, config, loci, seqlen=seqlen, mut_scale=mut, data_seed=900 + config,
+                                   mcmc_seed=777, samples_per_log=8)
+    synth.make_var_rates(pk, alpha, ft)
+    pth = str(tmp_path / "var.gpk")
+    synth.write_pack(pk, pth)
+    s = G.Sampler(G.Pack.load(pth))
+    tr, st1 = tmp_path / "var.trace", tmp_path / "var.state"
+    s.set_record_file(str(tr))
+    s.initialize()
+    for it in range(iters):
+        s.iteration(it)
+    s.dump_state(str(st1), False)
+    s.set_record_file(None)
+    s.close()
+    ot, os_ = tmp_path / "o.trace", tmp_path / "o.state"
+    subprocess.run([oracle_cli, "run", pth, str(iters), str(ot), str(os_), str(iters - 1), "0"], check=True,
+                   timeout=1200)
+    worst = compare_records(tr, ot)
+    compare_states(st1, os_)
+    nacc = sum(int(l.split()[3]) for l in open(tr) if " LRATE " in l)
+    assert 0 < nacc < (loci - 1) * iters
+    print(f"VAR config {config}: {loci} loci x {iters} iterations, {nacc} accepted rate moves, Pmax {int(np.diff(pk.pattern_offsets).max())}, worst rel diff {worst:.3e}")
+
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, %(repo)r)
@@ -158,7 +198,7 @@ def test_native_library_is_the_path(G):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8"])
 def test_program_trace_file(name, tmp_path):
     """G-PhoCS-hip <control-file> on the MI355X: the trace file of the real G-PhoCS binary for the same
     control + sequence files (tests/golden/*.trace), to the printed precision (%8.5f / %.6f)."""
