@@ -43,6 +43,7 @@ GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, double c) { kb_mix_eval(D,
 GPH_KERNEL(k_mix_commit, GphKargs KA, GphDev D, int j0, double c, double lnc) { kb_mix_commit(D, j0 + GPH_BLK, c, lnc); }
 GPH_KERNEL(k_sync, GphKargs KA, GphDev D, int j0, int refresh) { kb_sync(D, j0 + GPH_BLK, refresh); }
 GPH_KERNEL(k_check, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; kb_check(D, j0 + GPH_BLK); }
+GPH_KERNEL(k_lrate_prep, GphKargs KA, GphDev D, int j0, double finetune, GphLrPre *pre) { kb_lrate_prep(D, j0 + GPH_BLK, finetune, pre); }
 GPH_KERNEL(k_lrate_scan, GphKargs KA, GphDev D, int j0, GphLrArgs A) { (void)j0; kb_lrate_scan(D, A); }
 GPH_KERNEL(k_lrate_apply, GphKargs KA, GphDev D, int j0, const GphLrRec *rec) { kb_lrate_apply(D, j0 + GPH_BLK, rec); }
 
@@ -162,6 +163,8 @@ struct gph_engine {
   bool var_rates = false;            // locus rates are part of the state (dumped as "R" lines)
   // UpdateLocusRate: per-slot records, input-order -> slot map, result scalars, scratch for pattern-rich loci
   GphLrRec *d_lrec = nullptr;
+  GphLrPre *d_lpre = nullptr;
+  double lr_hits = 0;                // proposals of the last update decided with the prepared likelihood
   int32_t *d_slot_of = nullptr;
   double *d_lr_result = nullptr, *d_lr_gscr = nullptr;
   GphLrArgs lr;
@@ -447,7 +450,7 @@ void gph_engine_destroy(gph_engine *e)
   if (!e) return;
   dev_free(e->dev.pages); dev_free(e->dev.shadow); dev_free(e->dev.cond); dev_free((void *)e->dev.cond_off);
   dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
-  dev_free(e->d_lrec); dev_free(e->d_slot_of); dev_free(e->d_lr_result); dev_free(e->d_lr_gscr);
+  dev_free(e->d_lrec); dev_free(e->d_lpre); dev_free(e->d_slot_of); dev_free(e->d_lr_result); dev_free(e->d_lr_gscr);
   dev_free(e->d_part); dev_free(e->d_red);
 #ifndef GPH_HOSTEMU
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -567,7 +570,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   // per-locus kernels use up to the wide group's dynamic LDS size; allow > 64 KiB
   const void *ks[] = {(const void *)k_init, (const void *)k_sweep, (const void *)k_tau_eval, (const void *)k_tau_commit,
                       (const void *)k_tau_revert, (const void *)k_mix_eval, (const void *)k_mix_commit,
-                      (const void *)k_sync, (const void *)k_check, (const void *)k_lrate_apply};
+                      (const void *)k_sync, (const void *)k_check, (const void *)k_lrate_apply, (const void *)k_lrate_prep};
   for (auto k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, e->lay.lds_bytes));
 #endif
   return 0;
@@ -906,20 +909,23 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     e->lr.o_rseq = seqb; e->lr.o_gnd = 2 * seqb; e->lr.o_rnd = 2 * seqb + ndb; e->lr.o_scr = fixed; e->lr.Pscr = Pscr;
     e->lr_lds_bytes = fixed + (n - 1) * Pscr * 32;
     rc |= dev_alloc((void **)&e->d_lrec, sizeof(GphLrRec) * e->L);
+    rc |= dev_alloc((void **)&e->d_lpre, sizeof(GphLrPre) * e->L);
     rc |= dev_alloc((void **)&e->d_slot_of, sizeof(int32_t) * e->L);
-    rc |= dev_alloc((void **)&e->d_lr_result, sizeof(double) * 8);
+    rc |= dev_alloc((void **)&e->d_lr_result, sizeof(double) * 16);
     rc |= dev_alloc((void **)&e->d_lr_gscr, Pmax > Pscr ? sizeof(double) * 4 * (size_t)(n - 1) * Pmax : 16);
     if (rc) return GPH_EHIP;
     if (h2d(e, e->d_slot_of, slot_of.data(), sizeof(int32_t) * e->L)) return GPH_EHIP;
-    e->lr.result = e->d_lr_result; e->lr.rec = e->d_lrec; e->lr.slot_of = e->d_slot_of; e->lr.gscr = e->d_lr_gscr;
+    e->lr.result = e->d_lr_result; e->lr.rec = e->d_lrec; e->lr.pre = e->d_lpre; e->lr.slot_of = e->d_slot_of; e->lr.gscr = e->d_lr_gscr;
 #ifndef GPH_HOSTEMU
     HIPCHK(hipFuncSetAttribute((const void *)k_lrate_scan, hipFuncAttributeMaxDynamicSharedMemorySize, e->lr_lds_bytes));
 #endif
   }
   e->lr.finetune = finetune; e->lr.alpha = alpha;
   e->lr.dataLnL = io->dataLogLikelihood; e->lr.logL = io->logLikelihood; e->lr.rateVar = io->rateVar;
+  LAUNCH(e, 11, k_lrate_prep, finetune, e->d_lpre);
+  { int rcp = finish_kernel(e); if (rcp) return rcp; }
   LAUNCH1(e, 9, k_lrate_scan, e->lr_lds_bytes, e->lr);
-  double res[8];
+  double res[16];
   int rc = d2h(e, res, e->d_lr_result, sizeof res);
   if (rc) return rc;
 #ifndef GPH_HOSTEMU
@@ -939,6 +945,13 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
   io->dataLogLikelihood = res[1];
   io->logLikelihood = res[2];
   io->rateVar = res[3];
+  e->lr_hits = res[5];
+#ifdef GPH_LRSTAMP
+  fprintf(stderr, "lik_private stamps: setup+exp %.0f, nodes %.0f, root %.0f cycles per call (%.0f calls)\n", res[8] / res[11], res[9] / res[11], res[10] / res[11], res[11]);
+#endif
+  if (getenv("GPH_LR_VERBOSE"))
+    fprintf(stderr, "gphocs_hip: locus-rate scan: %.0f of %lld proposals decided with the prepared likelihood; %.3g shader cycles in %.3g s (%.0f MHz)\n",
+            res[5], (long long)(e->L - 1), res[6], res[7] / 1e8, res[7] > 0 ? res[6] / (res[7] / 1e8) / 1e6 : 0.0);
   return 0;
 }
 

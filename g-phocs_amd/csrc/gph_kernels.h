@@ -672,27 +672,68 @@ GPH_DEV void kb_mix_commit(const GphDev &D, int g, double c, double lnc)
 // ---------------------------------------------------------------- locus rates
 // UpdateLocusRate, GPhoCS.c:4598-4680.  The proposal is serial over loci by construction: every locus g trades
 // rate with the reference locus (genRateRef = 0), so the decision at g needs the reference locus's rate and
-// likelihood after every earlier decision.  Two kernels:
-//   kb_lrate_scan   ONE wavefront walks the loci in input order.  Per locus: draw the step from the locus's own
-//                   stream, evaluate the locus at its new rate and the reference locus at its new rate with the
-//                   stateless evaluator (lik_private: node records + sequence block staged in LDS, conditionals
-//                   in LDS scratch), decide, carry the running rate / likelihood of the reference locus and the
-//                   three accumulators (dataLogLikelihood, logLikelihood, rateVar: same additions in the same
-//                   order as the reference loop).  Writes one record per locus; touches no locus state.
-//   kb_lrate_apply  one wavefront per locus, all loci in parallel: RNG state written back; an accepted locus is
-//                   recomputed in place at its new rate (computeLocusDataLikelihood(0) + resetSaved, what the
-//                   reference did when it accepted) and must reproduce the scanned value bit for bit.  The
-//                   reference locus ends at its last accepted rate; its buffer parity is the number of accepted
-//                   proposals mod 2 (every accepted proposal flipped all its nodes once).
-struct GphLrRec { double rate, lnl; uint32_t rx, ry, rz; int32_t flag; };   // flag: accepted (reference locus: accept count)
+// likelihood after every earlier decision.  What does NOT depend on the earlier decisions is done in parallel:
+//   kb_lrate_prep   one wavefront per locus, all loci at once: the step is drawn from the locus's own stream and
+//                   the locus is recomputed at the rate the proposal almost always lands on (the step reflected
+//                   at zero only; the upper bound rold + rref is the serial part).  The evaluated state goes to
+//                   the shadow page (the main page and its current conditionals stay as they are); the scan gets
+//                   a 64-byte record per locus, in input order.
+//   kb_lrate_scan   ONE wavefront walks the records in input order: reflect against the actual bounds, take the
+//                   prepared likelihood when the rate is the prepared one (bit for bit; otherwise evaluate the
+//                   locus with the stateless evaluator lik_private), evaluate the reference locus at its new rate
+//                   (lik_private: its node records and sequence block stay in LDS for the whole scan), decide,
+//                   carry the reference locus's rate / likelihood and the three accumulators
+//                   (dataLogLikelihood, logLikelihood, rateVar: same additions in the same order as the reference
+//                   loop).  Writes one decision record per locus; touches no locus state.
+//   kb_lrate_apply  one wavefront per locus, all loci at once: RNG state written back; accepted with the prepared
+//                   rate = the shadow page becomes the page (resetSaved); accepted with another rate = recomputed
+//                   in place (computeLocusDataLikelihood(0) + resetSaved) and checked against the scanned value bit
+//                   for bit.  The reference locus ends at its last accepted rate; its buffer parity is the number
+//                   of accepted proposals mod 2 (every accepted proposal flipped all its nodes once).
+struct GphLrRec { double rate, lnl; uint32_t rx, ry, rz; int32_t flag; };   // flag: 1 accepted, 2 prepared rate used; reference locus: accept count << 2
+struct alignas(16) GphLrPre {   // prepared proposal of one locus (input order)
+  double cand, rspec, lspec, rold, likold;
+  uint32_t rx, ry, rz; int32_t slot;
+  double pad;
+};
 struct GphLrArgs {
   double finetune, alpha, dataLnL, logL, rateVar;
   int32_t o_gnd, o_rnd, o_rseq, o_scr, Pscr, unused;   // dynamic-LDS byte offsets; loci with P <= Pscr use LDS scratch
-  double *result;            // [0] accepted [1] dataLogLikelihood [2] logLikelihood [3] rateVar [4] error code
+  double *result;            // [0] accepted [1] dataLogLikelihood [2] logLikelihood [3] rateVar [4] error code [5] prepared rates used
   GphLrRec *rec;             // one per slot
+  GphLrPre *pre;             // one per locus, input order
   const int32_t *slot_of;    // input-order index -> slot
   double *gscr;              // [n-1][Pmax][4] scratch for loci with P > Pscr
 };
+#define GPH_LR_SLACK 0.000000001   /* reflect()'s slack, utils.c:335 */
+
+GPH_DEV void kb_lrate_prep(const GphDev &D, int g, double finetune, GphLrPre *pre)
+{
+  const int go = D.orig[g];
+  if (go + D.locus_begin == 0) {          /* the reference locus proposes nothing */
+    if (GPH_LANE == 0) { double *o = D.out + (size_t)g * GPH_OUT_SLOTS; o[8] = 0; o[9] = 0; o[10] = 0; o[11] = 0; o[13] = 0; }
+    return;
+  }
+  stage_in(D, g, D.pages, 1);
+  GphRng rng;
+  rng_load(rng);
+  const double rold = FS(FS_MUTRATE), likold = FS(FS_DATALNL);
+  const double cand = rold + finetune * l_rnd2normal8(rng);
+  /* reflect(cand, 0, b) for every b the proposal does not reach: inside -> cand, at or below the slack -> mirrored */
+  const double a = 0.0 + GPH_LR_SLACK;
+  const double rspec = UNI(cand > a) ? cand : 2. * a - cand;
+  rng_store(rng);
+  setFS(FS_MUTRATE, rspec);
+  const double lspec = lik_compute(0);
+  if (GPH_LANE == 0) {
+    GphLrPre r;
+    r.cand = cand; r.rspec = rspec; r.lspec = lspec; r.rold = rold; r.likold = likold;
+    r.rx = rng.x; r.ry = rng.y; r.rz = rng.z; r.slot = g; r.pad = 0.0;
+    pre[go] = r;
+  }
+  out_common(D, g);
+  stage_out(D, g, D.shadow, 2);
+}
 
 GPH_DEV void lr_load(const GphDev &D, int j, int o_nd, int o_seq, int &P, int &root, double &rate, double &lnl, GphRng &rng)
 {
@@ -717,52 +758,92 @@ GPH_DEV void lr_load(const GphDev &D, int j, int o_nd, int o_seq, int &P, int &r
 
 GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
 {
-  int k, Pr, rootr, P, root, accepted = 0;
-  double rref, likref, rold, likold;
+  int k, Pr, rootr, P, root, accepted = 0, hits = 0;
+  double rref, likref, dummy_r, dummy_l;
   GphRng rng, rngr;
   for (k = 0; k < CN_COUNT; k++) setCNT(k, 0);
+#ifdef GPH_LRSTAMP
+  for (k = 0; k < 8; k++) gph_lds.s_cntf[k] = 0.0;
+#endif
+#ifndef GPH_HOSTEMU
+  const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int jr = RFL(A.slot_of[0]);
   lr_load(D, jr, A.o_rnd, A.o_rseq, Pr, rootr, rref, likref, rngr);
   double dataLnL = A.dataLnL, logL = A.logL, rateVar = A.rateVar;
   const double Ld = (double)D.Ltot;
   gdbl *gs = (gdbl *)A.gscr;
-  for (int go = 1; go < D.L; go++) {
-    const int j = RFL(A.slot_of[go]);
-    GPH_SYNC();
-    lr_load(D, j, A.o_gnd, 0, P, root, rold, likold, rng);
-    double rnew = rold + A.finetune * l_rnd2normal8(rng);
-    rnew = l_reflect(rnew, 0, rold + rref);
-    const double rrefnew = rref + rold - rnew;
-    double lnacc = (A.alpha - 1) * gph_log((rnew * rrefnew) / (rold * rref));
-    double lnLd = -(likold + likref);
-    const double lg = lik_private(A.o_gnd, 0, P, root, rnew, A.o_scr, P > A.Pscr ? gs : (gdbl *)0);
-    lnLd += lg;
-    const double lr = lik_private(A.o_rnd, A.o_rseq, Pr, rootr, rrefnew, A.o_scr, Pr > A.Pscr ? gs : (gdbl *)0);
-    lnLd += lr;
-    lnacc += lnLd;
-    bool acc = UNI(lnacc >= 0);
-    if (!acc) acc = UNI(l_rndu(rng) < gph_exp(lnacc));
-    if (acc) {
-      accepted++;
-      dataLnL += lnLd;
-      logL += lnLd / Ld;
-      rateVar += (rnew * rnew + rrefnew * rrefnew - rold * rold - rref * rref) / Ld;
-      rref = rrefnew;
-      likref = lr;
-    }
-    if (GPH_LANE == 0) {
-      GphLrRec r;
-      r.rate = acc ? rnew : rold; r.lnl = acc ? lg : likold;
-      r.rx = rng.x; r.ry = rng.y; r.rz = rng.z; r.flag = acc ? 1 : 0;
-      A.rec[j] = r;
+  for (int base = 1; base < D.L; base += GPH_NLANES) {
+    /* one batch of prepared proposals: lane i holds locus base + i */
+    const int mine = base + GPH_LANE < D.L ? base + GPH_LANE : D.L - 1;
+    const GphLrPre pm = A.pre[mine];
+    const int nb = D.L - base < GPH_NLANES ? D.L - base : GPH_NLANES;
+    for (int i = 0; i < nb; i++) {
+#ifdef GPH_HOSTEMU
+      const GphLrPre &q = pm;
+      const double cand = q.cand, rspec = q.rspec, lspec = q.lspec, rold = q.rold, likold = q.likold;
+      const int j = q.slot;
+      rng.x = q.rx; rng.y = q.ry; rng.z = q.rz;
+#else
+      const double cand = rdlane64(pm.cand, i), rspec = rdlane64(pm.rspec, i), lspec = rdlane64(pm.lspec, i),
+                   rold = rdlane64(pm.rold, i), likold = rdlane64(pm.likold, i);
+      const int j = __builtin_amdgcn_readlane(pm.slot, i);
+      rng.x = (uint32_t)__builtin_amdgcn_readlane((int)pm.rx, i);
+      rng.y = (uint32_t)__builtin_amdgcn_readlane((int)pm.ry, i);
+      rng.z = (uint32_t)__builtin_amdgcn_readlane((int)pm.rz, i);
+#endif
+      const double rnew = l_reflect(cand, 0, rold + rref);
+      const double rrefnew = rref + rold - rnew;
+      double lnacc = (A.alpha - 1) * gph_log((rnew * rrefnew) / (rold * rref));
+      double lnLd = -(likold + likref);
+      const bool hit = UNI(rnew == rspec);
+      double lg;
+      if (hit) {
+        lg = lspec;
+        hits++;
+      } else {
+        GphRng unused_rng;
+        GPH_SYNC();
+        lr_load(D, j, A.o_gnd, 0, P, root, dummy_r, dummy_l, unused_rng);
+        lg = lik_private(A.o_gnd, 0, P, root, rnew, A.o_scr, P > A.Pscr ? gs : (gdbl *)0);
+      }
+      lnLd += lg;
+      const double lr = lik_private(A.o_rnd, A.o_rseq, Pr, rootr, rrefnew, A.o_scr, Pr > A.Pscr ? gs : (gdbl *)0);
+      lnLd += lr;
+      lnacc += lnLd;
+      bool acc = UNI(lnacc >= 0);
+      if (!acc) acc = UNI(l_rndu(rng) < gph_exp(lnacc));
+      if (acc) {
+        accepted++;
+        dataLnL += lnLd;
+        logL += lnLd / Ld;
+        rateVar += (rnew * rnew + rrefnew * rrefnew - rold * rold - rref * rref) / Ld;
+        rref = rrefnew;
+        likref = lr;
+      }
+      if (GPH_LANE == 0) {
+        GphLrRec r;
+        r.rate = acc ? rnew : rold; r.lnl = acc ? lg : likold;
+        r.rx = rng.x; r.ry = rng.y; r.rz = rng.z; r.flag = (acc ? 1 : 0) | (hit ? 2 : 0);
+        A.rec[j] = r;
+      }
+      if (gph_failed()) break;
     }
     if (gph_failed()) break;
   }
   if (GPH_LANE == 0) {
     GphLrRec r;
-    r.rate = rref; r.lnl = likref; r.rx = rngr.x; r.ry = rngr.y; r.rz = rngr.z; r.flag = accepted;
+    r.rate = rref; r.lnl = likref; r.rx = rngr.x; r.ry = rngr.y; r.rz = rngr.z; r.flag = accepted << 2;
     A.rec[jr] = r;
     A.result[0] = accepted; A.result[1] = dataLnL; A.result[2] = logL; A.result[3] = rateVar; A.result[4] = CNT(CN_ERROR);
+    A.result[5] = hits;
+#ifndef GPH_HOSTEMU
+    A.result[6] = (double)(__builtin_readcyclecounter() - clk0);            /* shader-clock cycles of the scan */
+    A.result[7] = (double)(__builtin_amdgcn_s_memrealtime() - rt0);         /* 100 MHz reference ticks */
+#ifdef GPH_LRSTAMP
+    A.result[8] = gph_lds.s_cntf[1]; A.result[9] = gph_lds.s_cntf[2]; A.result[10] = gph_lds.s_cntf[3]; A.result[11] = gph_lds.s_cntf[4];
+#endif
+#endif
   }
 }
 
@@ -771,7 +852,8 @@ GPH_DEV void kb_lrate_apply(const GphDev &D, int g, const GphLrRec *rec)
   const GphLrRec r = rec[g];
   const bool isref = (D.orig[g] + D.locus_begin) == 0;
   const int flag = RFL(r.flag);
-  if (flag == 0) {
+  const int accepts = isref ? flag >> 2 : flag & 1;
+  if (accepts == 0) {
     /* rejected (or an untouched reference locus): only the stream moved on */
     if (GPH_LANE == 0) {
       int32_t *is = (int32_t *)(D.pages + (size_t)g * g_lay.page_bytes + g_lay.o_iscal);
@@ -781,15 +863,21 @@ GPH_DEV void kb_lrate_apply(const GphDev &D, int g, const GphLrRec *rec)
     }
     return;
   }
-  stage_in(D, g, D.pages, 1);
-  setISC(IS_RX, (int)r.rx); setISC(IS_RY, (int)r.ry); setISC(IS_RZ, (int)r.rz);
-  setFS(FS_MUTRATE, RFLD(r.rate));
-  const int reps = isref ? 2 - (flag & 1) : 1;
-  for (int k = 0; k < reps; k++) {
-    lik_compute(0);
+  if (!isref && (flag & 2)) {
+    /* accepted at the prepared rate: the evaluated state is in the shadow page */
+    stage_in(D, g, D.shadow, 0);
     lik_reset_saved();
+  } else {
+    stage_in(D, g, D.pages, 1);
+    setFS(FS_MUTRATE, RFLD(r.rate));
+    const int reps = isref ? 2 - (accepts & 1) : 1;
+    for (int k = 0; k < reps; k++) {
+      lik_compute(0);
+      lik_reset_saved();
+    }
   }
-  if (!UNI(FS(FS_DATALNL) == RFLD(r.lnl))) gph_fail(120);   /* the scan and the in-place evaluation must agree bit for bit */
+  setISC(IS_RX, (int)r.rx); setISC(IS_RY, (int)r.ry); setISC(IS_RZ, (int)r.rz);
+  if (!UNI(FS(FS_DATALNL) == RFLD(r.lnl)) || !UNI(FS(FS_MUTRATE) == RFLD(r.rate))) gph_fail(120);   /* scan and in-place evaluation agree bit for bit */
   out_common(D, g);
   stage_out(D, g, D.pages, 1);
 }

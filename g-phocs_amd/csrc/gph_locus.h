@@ -886,6 +886,9 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
   const int q_leaf = o_seq + GPH_Q_LEAF, q_phases = o_seq + GPH_Q_PHASES(P, n), q_count = o_seq + GPH_Q_COUNT(P, n),
             q_terms = o_seq + GPH_Q_TERMS(P, n);
   const bool isnode = lane < N;
+#ifdef GPH_LRSTAMP
+  const uint64_t st0 = __builtin_readcyclecounter();
+#endif
   typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
   union { gu32x4 v; GphNode n; } nu;
   GphNode me = {0.0, -1, -1, -1, -1};
@@ -903,6 +906,11 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
   double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
   int prev = -1;
   GPH_WAVE_FENCE();
+#ifdef GPH_LRSTAMP
+  pe = RFLD(pe) * 0.0 + pe;
+  const uint64_t st1 = __builtin_readcyclecounter();
+  gph_lds.s_cntf[1] += (double)(st1 - st0);
+#endif
   for (int guard = 0; todo != 0; guard++) {
     bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
     uint64_t rmask = __ballot(rdy);
@@ -926,6 +934,11 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
       prev = node;
     }
   }
+#ifdef GPH_LRSTAMP
+  q0 = RFLD(q0) * 0.0 + q0;
+  const uint64_t st2 = __builtin_readcyclecounter();
+  gph_lds.s_cntf[2] += (double)(st2 - st1);
+#endif
   /* root reduction, LocusDataLikelihood.c:466-479 (see lik_compute) */
   double lnl = 0.0;
   DP rc = scr + ((root - n) * P) * 4;
@@ -971,6 +984,11 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
     for (int p = 0; p < P; p++)
       if (gu8(q_phases, p) > 0) lnl += gf64(q_terms, p);
   }
+#ifdef GPH_LRSTAMP
+  lnl = RFLD(lnl);
+  gph_lds.s_cntf[3] += (double)(__builtin_readcyclecounter() - st2);
+  gph_lds.s_cntf[4] += 1.0;
+#endif
   return lnl;
 }
 GPH_DEVHOT double lik_private(int o_nd, int o_seq, int P, int root, double rate, int o_scr, gdbl *gscr)
