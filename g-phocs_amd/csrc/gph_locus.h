@@ -592,23 +592,23 @@ GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1,
 }
 
 // recompute node `node`; on entry q* hold node `prev`'s conditionals (prev < 0: nothing), on exit
-// this node's.  `fresh` = nodes written earlier in this evaluation (their stores may be in flight)
+// this node's.  po / lo / ro = offsets (in doubles) of the node's and its children's current arrays
 template <class DP, class DP2>
-GPH_DEVHOT void prune_node_q(int node, int l, int r, double pl, double pr, int cbn, int cbl, int cbr,
-                             int P, DP cb, int prev, uint64_t fresh,
+GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo, int ro,
+                             int P, DP cb, int prev,
                              double &q0, double &q1, double &q2, double &q3, int q_leaf = GPH_Q_LEAF)
 {
   const double ql = 1 - 4.0 * pl;
   const double qr = 1 - 4.0 * pr;
-  const int nint = g_lay.n - 1, n = g_lay.n, lane = GPH_LANE;
+  const int lane = GPH_LANE;
   const bool act = lane < P;
-  DP pc = cb + ((cbn * nint + (node - n)) * P) * 4;
-  DP lc = cb + (l >= n ? ((cbl * nint + (l - n)) * P) * 4 : 0);
-  DP rc = cb + (r >= n ? ((cbr * nint + (r - n)) * P) * 4 : 0);
+  DP pc = cb + po;
+  DP lc = cb + lo;
+  DP rc = cb + ro;
   const bool fl = l == prev, fr = r == prev;
-  /* a child recomputed earlier in this evaluation but not held in registers: its stores must
-   * have landed before it is re-read */
-  if ((l >= n && !fl && ((fresh >> l) & 1)) || (r >= n && !fr && ((fresh >> r) & 1))) GPH_WAVE_FENCE();
+  /* a child recomputed earlier in this evaluation is re-read after its stores: memory operations of one
+   * wavefront are performed in order, only the compiler must not reorder them (no instruction) */
+  GPH_WAVE_FENCE();
   double f0, f1, f2, f3, g0, g1, g2, g3;
   child_factor4<DP, DP2>(l, lc, fl, q0, q1, q2, q3, pl, ql, act, f0, f1, f2, f3, q_leaf);
   child_factor4<DP, DP2>(r, rc, fr, q0, q1, q2, q3, pr, qr, act, g0, g1, g2, g3, q_leaf);
@@ -679,20 +679,24 @@ GPH_DEVHOT double lik_compute(int useOld)
   const bool wide = P > GPH_WAVE;   /* more than one pattern per lane: generic (pattern, base) mapping */
   double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
   int prev = -1;
-  uint64_t fresh = 0;
+  /* copyNodeConditionals (LocusDataLikelihood.c:1889) of every node that is going to be recomputed, all at once:
+   * a node not yet dirty in this proposal switches to its other array */
+  if (useOld) { const uint64_t flip = todo & ~dirty; dirty |= flip; cbit ^= flip; newly |= flip; }
+  /* offset (in doubles) of the lane's node's current array */
+  const int coff = (((int)((cbit >> lane) & 1)) * (n - 1) + (lane - n)) * P * 4;
+  const int fal = me.father;
   /* conditionals written by an earlier evaluation of this wave must have landed before they are re-read */
   GPH_WAVE_FENCE();
   STAMPB_END(2);
   for (int guard = 0; todo != 0; guard++) {
-    bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
-    uint64_t rmask = __ballot(rdy);
-    if (rmask == 0 || guard > N) { gph_fail(100); return FS(FS_DATALNL); }
     if (wide) {
+      bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
+      uint64_t rmask = __ballot(rdy);
+      if (rmask == 0 || guard > N) { gph_fail(100); return FS(FS_DATALNL); }
       while (rmask) {
         const int node = __builtin_ctzll(rmask);
         const uint64_t bit = (uint64_t)1 << node;
         rmask &= rmask - 1;
-        if (useOld && !(dirty & bit)) { dirty |= bit; cbit ^= bit; newly |= bit; }   /* copyNodeConditionals */
         const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
         STAMP_BEGIN(7);
         prune_node_r<gdbl *>(node, l, r, rdlane64(pe, l), rdlane64(pe, r), (int)((cbit >> node) & 1),
@@ -701,18 +705,33 @@ GPH_DEVHOT double lik_compute(int useOld)
         todo &= ~bit;
       }
     } else {
-      /* one node per step, the parent of the node just computed first (its child is in registers) */
-      const uint64_t pm = __ballot(isnode && (le == prev || ri == prev)) & rmask;
-      const int node = __builtin_ctzll(pm ? pm : rmask);
-      const uint64_t bit = (uint64_t)1 << node;
-      if (useOld && !(dirty & bit)) { dirty |= bit; cbit ^= bit; newly |= bit; }     /* copyNodeConditionals */
-      const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
+      /* one node per step.  Usual case: a dirty path is a chain, the next node is the father of the one just
+       * computed (whose conditionals are still in registers) -- three lane reads and a bit test.  Otherwise
+       * (start, or the father waits for its other subtree) any node whose recomputed children are done. */
+      int node = -1, l = 0, r = 0;
+      if (prev >= 0) {
+        const int f = __builtin_amdgcn_readlane(fal, prev);
+        if (f >= 0) {
+          l = __builtin_amdgcn_readlane(le, f);
+          r = __builtin_amdgcn_readlane(ri, f);
+          const int sib = l == prev ? r : l;
+          if (sib < n || !((todo >> sib) & 1)) node = f;
+        }
+      }
+      if (node < 0) {
+        bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
+        const uint64_t rmask = __ballot(rdy);
+        if (rmask == 0 || guard > N) { gph_fail(100); return FS(FS_DATALNL); }
+        node = __builtin_ctzll(rmask);
+        l = __builtin_amdgcn_readlane(le, node);
+        r = __builtin_amdgcn_readlane(ri, node);
+      }
       STAMP_BEGIN(7);
-      prune_node_q<gdbl *, gdbl2 *>(node, l, r, rdlane64(pe, l), rdlane64(pe, r), (int)((cbit >> node) & 1),
-                                    (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, cb, prev, fresh, q0, q1, q2, q3);
+      prune_node_q<gdbl *, gdbl2 *>(l, r, rdlane64(pe, l), rdlane64(pe, r), __builtin_amdgcn_readlane(coff, node),
+                                    __builtin_amdgcn_readlane(coff, l), __builtin_amdgcn_readlane(coff, r), P, cb, prev,
+                                    q0, q1, q2, q3);
       STAMP_END(7);
-      todo &= ~bit;
-      fresh |= bit;
+      todo &= ~((uint64_t)1 << node);
       prev = node;
     }
   }
@@ -896,7 +915,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
   const int le = me.left, ri = me.right;
   const double ag = me.age;
   const uint64_t internal = (((uint64_t)1 << N) - 1) & ~(((uint64_t)1 << n) - 1);
-  uint64_t todo = internal, fresh = 0;
+  uint64_t todo = internal;
   double pe = 0.0;
   {
     const int fa = me.father;
@@ -928,9 +947,9 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
       const int node = __builtin_ctzll(pm ? pm : rmask);
       const uint64_t bit = (uint64_t)1 << node;
       const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
-      prune_node_q<DP, DP2>(node, l, r, rdlane64(pe, l), rdlane64(pe, r), 0, 0, 0, P, scr, prev, fresh, q0, q1, q2, q3, q_leaf);
+      prune_node_q<DP, DP2>(l, r, rdlane64(pe, l), rdlane64(pe, r), (node - n) * P * 4, l >= n ? (l - n) * P * 4 : 0,
+                            r >= n ? (r - n) * P * 4 : 0, P, scr, prev, q0, q1, q2, q3, q_leaf);
       todo &= ~bit;
-      fresh |= bit;
       prev = node;
     }
   }
