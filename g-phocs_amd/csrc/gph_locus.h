@@ -562,10 +562,11 @@ GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1,
     /* leaf: one-hot (or N).  S = 1 exactly, so S*pe = pe and sa*qe is qe or 0: bit-identical shortcut */
     const int code = act ? (int)gu8v(q_leaf, lane * g_lay.n + child) : 4;
     const double hit = pe + qe;
-    f0 = code == 4 ? 1.0 : (code == 0 ? hit : pe);
-    f1 = code == 4 ? 1.0 : (code == 1 ? hit : pe);
-    f2 = code == 4 ? 1.0 : (code == 2 ? hit : pe);
-    f3 = code == 4 ? 1.0 : (code == 3 ? hit : pe);
+    const double other = code == 4 ? 1.0 : pe;   /* N: every base gets 1.0 (no code matches below) */
+    f0 = code == 0 ? hit : other;
+    f1 = code == 1 ? hit : other;
+    f2 = code == 2 ? hit : other;
+    f3 = code == 3 ? hit : other;
     return;
   }
   double s0 = q0, s1 = q1, s2 = q2, s3 = q3;
@@ -578,8 +579,7 @@ GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1,
     }
     s0 = a.x; s1 = a.y; s2 = b.x; s3 = b.y;
   }
-  double S = 0.0;
-  S += s0;
+  double S = s0;     /* 0.0 + s0: conditionals are never -0.0 */
   S += s1;
   S += s2;
   S += s3;
@@ -759,8 +759,7 @@ GPH_DEVHOT double lik_compute(int useOld)
      * phases of an unphased pattern (the following rows) come from memory */
     double term = 0.0;
     const int ph = lane < P ? gu8v(q_phases, lane) : 0;
-    double prob = 0.0;
-    prob += q0;
+    double prob = q0;   /* 0.0 + q0 */
     prob += q1;
     prob += q2;
     prob += q3;
