@@ -1744,9 +1744,26 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
       }
     } else {
       rate = mig_rate + gph_div_by(2 * nlin, theta, thinv);
-      if (UNI(rate <= 0)) t = et;
-      else t = -(1 / rate) * gph_log_u(l_rndu(rng));
-      if (UNI(t >= et)) {
+      bool through;     /* the sampled waiting time reaches the end of the interval (patch.c:1075-1082) */
+      if (UNI(rate <= 0)) {
+        through = true;
+      } else {
+        const double u = l_rndu(rng);
+#ifndef GPH_HOSTEMU
+        /* t = -(1/rate) log(u) is only USED when it falls inside the interval.  -log(u) >= y + y^2/2 for
+         * y = 1 - u in (0, 1]: when that bound clears rate*et with a margin far above the rounding errors of
+         * either side (each a few 1e-16 relative), t >= et is certain and neither the logarithm nor the
+         * reciprocal is evaluated -- about three of four draws of a walk pass through their interval */
+        const double y = 1.0 - u;
+        through = UNI(y + 0.5 * y * y >= (rate * et) * (1.0 + 1e-9));
+        if (!through)
+#endif
+        {
+          t = -(1 / rate) * gph_log_u(u);
+          through = UNI(t >= et);
+        }
+      }
+      if (through) {
         t = et;
         age += t;
       } else {
