@@ -900,14 +900,17 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     // dynamic LDS of the scan: guest sequence block | reference sequence block | guest nodes | reference nodes | scratch
     const int seqb = align_up(GPH_Q_TERMS(Pmax, n) + (Pmax > GPH_WAVE ? 8 * Pmax : 0), 16), ndb = N * (int)sizeof(GphNode);
     const int fixed = 2 * seqb + 2 * ndb;
-    const int budget = 96 * 1024 - (int)sizeof(GphLds);
+    const int budget = 96 * 1024 - (int)sizeof(GphLds) - (n - 1) * GPH_WAVE * 16 - align_up(N * 8, 16);
     int Pscr = (budget - fixed) / ((n - 1) * 32);
     if (const char *ov = getenv("GPH_LR_PSCR")) Pscr = atoi(ov) < Pscr ? atoi(ov) : Pscr;   /* tests: force the global-scratch path */
     if (Pscr > Pmax) Pscr = Pmax;
     if (Pscr < 0) Pscr = 0;
     memset(&e->lr, 0, sizeof e->lr);
     e->lr.o_rseq = seqb; e->lr.o_gnd = 2 * seqb; e->lr.o_rnd = 2 * seqb + ndb; e->lr.o_scr = fixed; e->lr.Pscr = Pscr;
-    e->lr_lds_bytes = fixed + (n - 1) * Pscr * 32;
+    // behind the scratch: the reference locus's compiled program (one 16-byte entry per step and lane) and edge probabilities
+    e->lr.o_prog = fixed + (n - 1) * Pscr * 32;
+    e->lr.o_pe = e->lr.o_prog + (n - 1) * GPH_WAVE * 16;
+    e->lr_lds_bytes = e->lr.o_pe + align_up(N * 8, 16);
     rc |= dev_alloc((void **)&e->d_lrec, sizeof(GphLrRec) * e->L);
     rc |= dev_alloc((void **)&e->d_lpre, sizeof(GphLrPre) * e->L);
     rc |= dev_alloc((void **)&e->d_slot_of, sizeof(int32_t) * e->L);
@@ -947,7 +950,7 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
   io->rateVar = res[3];
   e->lr_hits = res[5];
 #ifdef GPH_LRSTAMP
-  fprintf(stderr, "lik_private stamps: setup+exp %.0f, nodes %.0f, root %.0f cycles per call (%.0f calls)\n", res[8] / res[11], res[9] / res[11], res[10] / res[11], res[11]);
+  fprintf(stderr, "evaluator stamps: setup+exp %.0f, nodes %.0f, root %.0f cycles per call (%.0f calls, %.1f steps)\n", res[8] / res[11], res[9] / res[11], res[10] / res[11], res[11], res[12] / res[11]);
 #endif
   if (getenv("GPH_LR_VERBOSE"))
     fprintf(stderr, "gphocs_hip: locus-rate scan: %.0f of %lld proposals decided with the prepared likelihood; %.3g shader cycles in %.3g s (%.0f MHz)\n",

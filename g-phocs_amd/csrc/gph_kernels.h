@@ -698,7 +698,8 @@ struct alignas(16) GphLrPre {   // prepared proposal of one locus (input order)
 };
 struct GphLrArgs {
   double finetune, alpha, dataLnL, logL, rateVar;
-  int32_t o_gnd, o_rnd, o_rseq, o_scr, Pscr, unused;   // dynamic-LDS byte offsets; loci with P <= Pscr use LDS scratch
+  int32_t o_gnd, o_rnd, o_rseq, o_scr, Pscr, o_prog;   // dynamic-LDS byte offsets; loci with P <= Pscr use LDS scratch
+  int32_t o_pe, unused;                                // o_prog / o_pe: compiled program and edge probabilities of the reference locus
   double *result;            // [0] accepted [1] dataLogLikelihood [2] logLikelihood [3] rateVar [4] error code [5] prepared rates used
   GphLrRec *rec;             // one per slot
   GphLrPre *pre;             // one per locus, input order
@@ -756,6 +757,196 @@ GPH_DEV void lr_load(const GphDev &D, int j, int o_nd, int o_seq, int &P, int &r
   GPH_SYNC();
 }
 
+#ifndef GPH_HOSTEMU
+// ---- the reference locus of the scan: its tree does not change while the scan runs, only its rate does, and it is
+// evaluated once per locus by a lone wavefront (at most one instruction every 4 cycles, whatever its type).  The
+// pruning order is therefore compiled ONCE per scan into a per-lane table: the internal nodes are sorted by height
+// (children strictly lower), nodes of equal height share a step, floor(64 / P) nodes per step, lanes = (node slot,
+// pattern).  A step is straight vector code -- table entry, the two edge probabilities, the two children's entries
+// (an LDS array or a leaf code), four products, one store -- with no scalar control and no lane reads, and there are
+// about half as many steps as nodes.  Same arithmetic per entry as child_factor4 / prune_node_q.
+struct GphRefProg {
+  int T;          // steps (0 = not compiled: the generic evaluator is used)
+  double dt;      // per lane (= node): age(father) - age, the edge above the node
+  int father;     // per lane
+};
+typedef int32_t gph_i4 __attribute__((ext_vector_type(4)));
+
+GPH_DEVHOT void lr_ref_compile(const GphLrArgs &A, int P, GphRefProg &R)
+{
+  const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
+  R.T = 0; R.dt = 0.0; R.father = -1;
+  if (P < 1 || P > GPH_WAVE) return;
+  const int S = GPH_WAVE / P;
+  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
+  union { gu32x4 v; GphNode nd; } nu;
+  GphNode me = {0.0, -1, -1, -1, -1};
+  const bool isnode = lane < N, isint = isnode && lane >= n;
+  if (isnode) { nu.v = ((GPH_LDS gu32x4 *)(GPH_SMB + A.o_rnd))[lane]; me = nu.nd; }
+  const int le = me.left, ri = me.right;
+  R.father = me.father;
+  if (isnode && me.father >= 0) R.dt = ((lf64 *)(GPH_SMB + A.o_rnd))[2 * me.father] - me.age;
+  /* heights */
+  int h = isint ? -1 : 0;
+  for (int it = 0; it <= N; it++) {
+    const int hl = __builtin_amdgcn_ds_bpermute((isint ? le : lane) << 2, h), hr = __builtin_amdgcn_ds_bpermute((isint ? ri : lane) << 2, h);
+    if (isint && h < 0 && hl >= 0 && hr >= 0) h = 1 + (hl > hr ? hl : hr);
+    if (__ballot(isint && h < 0) == 0) break;
+  }
+  if (__ballot(isint && h < 0) != 0) { gph_fail(100); return; }
+  /* rank of every internal node in (height, index) order, then steps: a new step when the height changes or the
+   * slots are used up */
+  int rank = 0;
+  for (int k = n; k < N; k++) {
+    const int hk = __builtin_amdgcn_readlane(h, k);
+    rank += (hk < h || (hk == h && k < lane)) ? 1 : 0;
+  }
+  GPH_LDS int32_t *tmp = (GPH_LDS int32_t *)(GPH_SMB + A.o_pe);      /* N ints fit the N doubles of o_pe */
+  if (isint) tmp[rank] = lane;
+  GPH_SYNC();
+  int mystep = -1, myslot = 0, t = 0, cnt = 0, curh = 0;
+  for (int r = 0; r < n - 1; r++) {
+    const int node = RFL(tmp[r]);
+    const int hh = __builtin_amdgcn_readlane(h, node);
+    if (r == 0) curh = hh;
+    else if (hh != curh || cnt == S) { t++; cnt = 0; curh = hh; }
+    if (lane == node) { mystep = t; myslot = cnt; }
+    cnt++;
+  }
+  const int T = t + 1;
+  GPH_SYNC();
+  /* the table: T x 64 entries {left, right, own, child ids}; left / right = byte offset of an internal child's
+   * four conditionals of this pattern in the scratch, or -1 - code for a leaf child; own < 0 = idle lane */
+  GPH_LDS gph_i4 *prog = (GPH_LDS gph_i4 *)(GPH_SMB + A.o_prog);
+  for (int i = lane; i < T * GPH_WAVE; i += GPH_NLANES) { gph_i4 e = {-5, -5, -1, 0}; prog[i] = e; }
+  GPH_SYNC();
+  const int q_leaf = A.o_rseq + GPH_Q_LEAF;
+  for (int pat = 0; pat < P; pat++) {
+    if (isint) {
+      gph_i4 e;
+      e.x = le < n ? -1 - gu8v(q_leaf, pat * n + le) : ((le - n) * P + pat) * 32;
+      e.y = ri < n ? -1 - gu8v(q_leaf, pat * n + ri) : ((ri - n) * P + pat) * 32;
+      e.z = ((lane - n) * P + pat) * 32;
+      e.w = le | (ri << 8);
+      prog[mystep * GPH_WAVE + myslot * P + pat] = e;
+    }
+  }
+  GPH_SYNC();
+  R.T = T;
+}
+
+GPH_DEVHOT void lr_ref_factors(int a, double pe, double qe, int o_scr, double &f0, double &f1, double &f2, double &f3)
+{
+  if (a < 0) {
+    const int code = -1 - a;
+    const double hit = pe + qe;
+    const double other = code == 4 ? 1.0 : pe;
+    f0 = code == 0 ? hit : other;
+    f1 = code == 1 ? hit : other;
+    f2 = code == 2 ? hit : other;
+    f3 = code == 3 ? hit : other;
+  } else {
+    const ld2 *c2 = (const ld2 *)(GPH_SMB + o_scr + a);
+    const gph_d2 u = c2[0], v = c2[1];
+    const double s0 = u.x, s1 = u.y, s2 = v.x, s3 = v.y;
+    double S = s0;
+    S += s1;
+    S += s2;
+    S += s3;
+    const double Sp = S * pe;
+    const bool miss = S >= 4;
+    f0 = miss ? 1.0 : (Sp + s0 * qe);
+    f1 = miss ? 1.0 : (Sp + s1 * qe);
+    f2 = miss ? 1.0 : (Sp + s2 * qe);
+    f3 = miss ? 1.0 : (Sp + s3 * qe);
+  }
+}
+
+// value of the reference locus at `rate` (== lik_private(o_rnd, o_rseq, P, root, rate, ...) bit for bit)
+GPH_DEVHOT double lr_ref_eval(const GphLrArgs &A, const GphRefProg &R, int P, double rate)
+{
+  const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
+  const int q_phases = A.o_rseq + GPH_Q_PHASES(P, n), q_count = A.o_rseq + GPH_Q_COUNT(P, n);
+  rate = RFLD(rate);
+#ifdef GPH_LRSTAMP
+  const uint64_t st0 = __builtin_readcyclecounter();
+#endif
+  double pe = 0.0;
+  if (lane < N && R.father >= 0) pe = edge_prob_v(rate * R.dt);
+  lf64 *pes = (lf64 *)(GPH_SMB + A.o_pe);
+  if (lane < N) pes[lane] = pe;
+  GPH_WAVE_FENCE();
+  const GPH_LDS gph_i4 *prog = (const GPH_LDS gph_i4 *)(GPH_SMB + A.o_prog);
+  double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+  gph_i4 e = prog[lane];
+#ifdef GPH_LRSTAMP
+  e.x = RFL(e.x) * 0 + e.x;
+  const uint64_t st1 = __builtin_readcyclecounter();
+  gph_lds.s_cntf[1] += (double)(st1 - st0);
+#endif
+  for (int t = 0; t < R.T; t++) {
+    const gph_i4 enext = prog[(t + 1 < R.T ? t + 1 : t) * GPH_WAVE + lane];   /* next step's entry rides under this step */
+    const double pl = pes[e.w & 255], pr = pes[(e.w >> 8) & 255];
+    const double ql = 1 - 4.0 * pl;
+    const double qr = 1 - 4.0 * pr;
+    double f0, f1, f2, f3, g0, g1, g2, g3;
+    lr_ref_factors(e.x, pl, ql, A.o_scr, f0, f1, f2, f3);
+    lr_ref_factors(e.y, pr, qr, A.o_scr, g0, g1, g2, g3);
+    q0 = f0 * g0;
+    q1 = f1 * g1;
+    q2 = f2 * g2;
+    q3 = f3 * g3;
+    if (e.z >= 0) {
+      ld2 *o2 = (ld2 *)(GPH_SMB + A.o_scr + e.z);
+      gph_d2 a = {q0, q1}, b = {q2, q3};
+      o2[0] = a;
+      o2[1] = b;
+    }
+    GPH_WAVE_FENCE();
+    e = enext;
+  }
+#ifdef GPH_LRSTAMP
+  q0 = RFLD(q0) * 0.0 + q0;
+  const uint64_t st2 = __builtin_readcyclecounter();
+  gph_lds.s_cntf[2] += (double)(st2 - st1);
+  gph_lds.s_cntf[5] += (double)R.T;
+#endif
+  /* the root is alone in the last step, slot 0: lane p < P holds its four conditionals of pattern p.
+   * Root reduction as in lik_compute / lik_private_t (LocusDataLikelihood.c:466-479) */
+  double lnl = 0.0, term = 0.0;
+  const int ph = lane < P ? gu8v(q_phases, lane) : 0;
+  double prob = q0;
+  prob += q1;
+  prob += q2;
+  prob += q3;
+  for (int k = 1; __ballot(ph > k) != 0; k++) {
+    const int src = ((lane + k) & (GPH_WAVE - 1)) << 2;
+    const double r0 = bperm64(src, q0), r1 = bperm64(src, q1), r2 = bperm64(src, q2), r3 = bperm64(src, q3);
+    if (ph > k) {
+      prob += r0;
+      prob += r1;
+      prob += r2;
+      prob += r3;
+    }
+  }
+  if (ph > 0) {
+    const int nc = 4 * ph;
+    double avg;
+    if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
+    else avg = prob / nc;
+    term = gph_log(avg) * gi32v(q_count, lane);
+  }
+  uint64_t pm = __ballot(ph > 0);
+  while (pm) { lnl += rdlane64(term, __builtin_ctzll(pm)); pm &= pm - 1; }
+#ifdef GPH_LRSTAMP
+  lnl = RFLD(lnl);
+  gph_lds.s_cntf[3] += (double)(__builtin_readcyclecounter() - st2);
+  gph_lds.s_cntf[4] += 1.0;
+#endif
+  return lnl;
+}
+#endif
+
 GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
 {
   int k, Pr, rootr, P, root, accepted = 0, hits = 0;
@@ -773,6 +964,10 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
   double dataLnL = A.dataLnL, logL = A.logL, rateVar = A.rateVar;
   const double Ld = (double)D.Ltot;
   gdbl *gs = (gdbl *)A.gscr;
+#ifndef GPH_HOSTEMU
+  GphRefProg RP;
+  lr_ref_compile(A, Pr, RP);
+#endif
   for (int base = 1; base < D.L; base += GPH_NLANES) {
     /* one batch of prepared proposals: lane i holds locus base + i */
     const int mine = base + GPH_LANE < D.L ? base + GPH_LANE : D.L - 1;
@@ -808,7 +1003,12 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
         lg = lik_private(A.o_gnd, 0, P, root, rnew, A.o_scr, P > A.Pscr ? gs : (gdbl *)0);
       }
       lnLd += lg;
+#ifndef GPH_HOSTEMU
+      const double lr = RP.T > 0 && Pr <= A.Pscr ? lr_ref_eval(A, RP, Pr, rrefnew)
+                                                  : lik_private(A.o_rnd, A.o_rseq, Pr, rootr, rrefnew, A.o_scr, Pr > A.Pscr ? gs : (gdbl *)0);
+#else
       const double lr = lik_private(A.o_rnd, A.o_rseq, Pr, rootr, rrefnew, A.o_scr, Pr > A.Pscr ? gs : (gdbl *)0);
+#endif
       lnLd += lr;
       lnacc += lnLd;
       bool acc = UNI(lnacc >= 0);
@@ -841,7 +1041,7 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
     A.result[6] = (double)(__builtin_readcyclecounter() - clk0);            /* shader-clock cycles of the scan */
     A.result[7] = (double)(__builtin_amdgcn_s_memrealtime() - rt0);         /* 100 MHz reference ticks */
 #ifdef GPH_LRSTAMP
-    A.result[8] = gph_lds.s_cntf[1]; A.result[9] = gph_lds.s_cntf[2]; A.result[10] = gph_lds.s_cntf[3]; A.result[11] = gph_lds.s_cntf[4];
+    A.result[8] = gph_lds.s_cntf[1]; A.result[9] = gph_lds.s_cntf[2]; A.result[10] = gph_lds.s_cntf[3]; A.result[11] = gph_lds.s_cntf[4]; A.result[12] = gph_lds.s_cntf[5];
 #endif
 #endif
   }
