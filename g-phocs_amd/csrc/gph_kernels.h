@@ -936,8 +936,7 @@ GPH_DEVHOT double lr_ref_eval(const GphLrArgs &A, const GphRefProg &R, int P, do
     else avg = prob / nc;
     term = gph_log(avg) * gi32v(q_count, lane);
   }
-  uint64_t pm = __ballot(ph > 0);
-  while (pm) { lnl += rdlane64(term, __builtin_ctzll(pm)); pm &= pm - 1; }
+  lnl = ordered_sum64(term, P);
 #ifdef GPH_LRSTAMP
   lnl = RFLD(lnl);
   gph_lds.s_cntf[3] += (double)(__builtin_readcyclecounter() - st2);

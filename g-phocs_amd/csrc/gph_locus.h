@@ -518,6 +518,25 @@ GPH_DEV double bperm64(int byteaddr, double v)
   u.i[1] = __builtin_amdgcn_ds_bpermute(byteaddr, u.i[1]);
   return u.d;
 }
+// sum of term[0..P-1] in lane order, P <= 64 (lanes >= P and lanes without a term hold +0.0: x + 0.0 == x bit for
+// bit, and the running sum is never -0.0): two lane reads with a constant lane + one add per pattern, no mask
+// bookkeeping, an exit test every eight patterns
+GPH_DEVHOT double ordered_sum64(double term, int P)
+{
+  double s = 0.0;
+#define GPH_ADD8(b) s += rdlane64(term, (b) + 0); s += rdlane64(term, (b) + 1); s += rdlane64(term, (b) + 2); s += rdlane64(term, (b) + 3); \
+                    s += rdlane64(term, (b) + 4); s += rdlane64(term, (b) + 5); s += rdlane64(term, (b) + 6); s += rdlane64(term, (b) + 7);
+  GPH_ADD8(0)
+  if (P > 8) { GPH_ADD8(8)
+  if (P > 16) { GPH_ADD8(16)
+  if (P > 24) { GPH_ADD8(24)
+  if (P > 32) { GPH_ADD8(32)
+  if (P > 40) { GPH_ADD8(40)
+  if (P > 48) { GPH_ADD8(48)
+  if (P > 56) { GPH_ADD8(56) } } } } } } }
+#undef GPH_ADD8
+  return s;
+}
 #endif
 // prune_node() with every tree scalar already in (scalar) registers
 template <class DP>
@@ -783,9 +802,8 @@ GPH_DEVHOT double lik_compute(int useOld)
       else avg = prob / nc;
       term = gph_log(avg) * gi32v(q_count, lane);
     }
-    uint64_t pm = __ballot(ph > 0);
-    U = __builtin_popcountll(pm);
-    while (pm) { lnl += rdlane64(term, __builtin_ctzll(pm)); pm &= pm - 1; }
+    U = __builtin_popcountll(__ballot(ph > 0));
+    lnl = ordered_sum64(term, P);
   } else {
     GPH_WAVE_FENCE();
     for (int p = lane; p < P; p += GPH_NLANES) {
@@ -985,8 +1003,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
       else avg = prob / nc;
       term = gph_log(avg) * gi32v(q_count, lane);
     }
-    uint64_t pm = __ballot(ph > 0);
-    while (pm) { lnl += rdlane64(term, __builtin_ctzll(pm)); pm &= pm - 1; }
+    lnl = ordered_sum64(term, P);
   } else {
     GPH_WAVE_FENCE();
     for (int p = lane; p < P; p += GPH_NLANES) {
