@@ -146,6 +146,26 @@ def test_locus_rate_scale_parity_against_live_oracle(G, oracle_cli, tmp_path, mo
     print(f"VAR config {config}: {loci} loci x {iters} iterations, {nacc} accepted rate moves, Pmax {int(np.diff(pk.pattern_offsets).max())}, worst rel diff {worst:.3e}")
 
 
+@pytest.mark.parametrize("loci,zero_ref", [(1, False), (2, False), (70, False), (70, True)])
+def test_locus_rate_edge_cases(G, oracle_cli, tmp_path, loci, zero_ref):
+    """UpdateLocusRate with only the reference locus, with one proposing locus, across a batch boundary of the scan (65+
+    loci), and with a reference locus without informative columns (P = 0), against the oracle run live."""
+    from gphocs_amd_pkg import synth
+    pk = synth.make_synthetic_pack(G.Pack, 3, loci, mut_scale=1.0, data_seed=5, mcmc_seed=99, samples_per_log=4)
+    synth.make_var_rates(pk, 1.3, 0.8)
+    if zero_ref:
+        p0 = int(pk.pattern_offsets[1])
+        pk.leafcodes, pk.numPhases, pk.counts = pk.leafcodes[p0:], pk.numPhases[p0:], pk.counts[p0:]
+        pk.pattern_offsets = np.concatenate([[0], pk.pattern_offsets[1:] - p0]).astype(np.int64)
+    pth = str(tmp_path / "ve.gpk")
+    synth.write_pack(pk, pth)
+    tr, _, st1, _ = _run(G, pth, 12, tmp_path, "ve")
+    ot, os_ = tmp_path / "o.trace", tmp_path / "o.state"
+    subprocess.run([oracle_cli, "run", pth, "12", str(ot), str(os_), "11", "1"], check=True, timeout=300)
+    assert compare_records(tr, ot) <= 1e-10
+    compare_states(st1, os_)
+
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, %(repo)r)

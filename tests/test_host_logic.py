@@ -58,3 +58,30 @@ def test_engine_creation_fails_loudly_without_a_gpu():
     pk = G.Pack.load(os.path.join(GOLDEN, "g1.gpk"))
     with pytest.raises(RuntimeError):
         G.Sampler(pk)      # libgphocs_hip.so: no device -> GPH_EHIP, no silent CPU fallback
+
+
+@pytest.mark.parametrize("loci,zero_ref", [(1, False), (2, False), (3, False), (40, False), (40, True)])
+def test_locus_rate_edge_cases_against_live_oracle(hostemu, oracle_cli, tmp_path, loci, zero_ref):
+    """`locus-mut-rate VAR` (UpdateLocusRate, GPhoCS.c:4598): a chain with only the reference locus, with one and two
+    proposing loci, and with a reference locus that has no informative column (P = 0: its likelihood is 0 at any rate);
+    large steps (reflections at both bounds) and alpha != 1.  Host build of the engine sources against the oracle's
+    serial loop on the same pack: records and final per-locus state (rates included)."""
+    import subprocess
+    import numpy as np
+    import gphocs_amd as G
+    from gphocs_amd_pkg import synth
+    R, lib = hostemu
+    pk = synth.make_synthetic_pack(G.Pack, 3, loci, mut_scale=1.0, data_seed=5, mcmc_seed=99, samples_per_log=4)
+    synth.make_var_rates(pk, 1.3, 0.8)
+    if zero_ref:      # drop every pattern of locus 0
+        p0 = int(pk.pattern_offsets[1])
+        pk.leafcodes, pk.numPhases, pk.counts = pk.leafcodes[p0:], pk.numPhases[p0:], pk.counts[p0:]
+        pk.pattern_offsets = np.concatenate([[0], pk.pattern_offsets[1:] - p0]).astype(np.int64)
+    pth = str(tmp_path / "ve.gpk")
+    synth.write_pack(pk, pth)
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(pth, 12, str(tr), str(st), 11, lib=lib)
+    ot, os_ = tmp_path / "o.t", tmp_path / "o.s"
+    subprocess.run([oracle_cli, "run", pth, "12", str(ot), str(os_), "11", "1"], check=True, timeout=300)
+    assert compare_records(tr, ot) < 1e-12
+    compare_states(st, os_)
