@@ -159,6 +159,8 @@ struct gph_engine {
   struct Bucket { int j0, count, lds_bytes; };   // a launch group: slots [j0, j0+count), dynamic LDS per wave
   std::vector<Bucket> buckets;
   double *d_mutRate = nullptr;
+  std::vector<double> totals;        // coal_stats, num_coals, mig_stats, num_migs summed over ALL ranks, as of the last genealogy sweep
+  bool totals_valid = false;         // ... and nothing has changed a locus's statistics since
   int init_predraws = 0;             // rndu() draws every locus spent before its genealogy is sampled (VAR start-up: 1)
   bool var_rates = false;            // locus rates are part of the state (dumped as "R" lines)
   // UpdateLocusRate: per-slot records, input-order -> slot map, result scalars, scratch for pattern-rich loci
@@ -370,6 +372,7 @@ static int flush_sync(gph_engine *e)
 {
   if (!e->sync_pending) return 0;
   e->sync_pending = false;
+  e->totals_valid = false;
   LAUNCH(e, 8, k_sync, 0);
   int rc = finish_kernel(e);
   if (rc) return rc;
@@ -597,6 +600,7 @@ int gph_engine_seed(gph_engine *e, uint32_t seed)
 int gph_engine_init_genealogies(gph_engine *e, double *sumGen, double *sumData)
 {
   if (!e || !e->loaded || !e->seeded || !e->model_set) return GPH_ESTATE;
+  e->totals_valid = false;
   LAUNCH(e, 3, k_init, e->seedz, (const double *)e->d_mutRate, e->init_predraws);
   int rc = finish_kernel(e);
   if (rc) return rc;
@@ -617,8 +621,16 @@ int gph_engine_genealogy_sweep(gph_engine *e, int32_t flags, double ftCoal, doub
   int rc = finish_kernel(e);
   if (rc) return rc;
   if (with_sync && RMIN(e, 15) < 1.0) { fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n"); return GPH_EKERNEL; }
-  double s[9] = {RSUM(e, 0), RSUM(e, 1), RSUM(e, 2), RSUM(e, 3), RSUM(e, 4), RSUM(e, 5), RSUM(e, 6), RSUM(e, 7), RSUM(e, 12)};
-  rc = xreduce(e, s, 9, nullptr, 0);
+  /* the statistics totals the host asks for next (computeTotalStats, patch.c:2134) ride in the same all-reduce */
+  const int C = 2 * e->cfg.K + 2 * e->cfg.B;
+  std::vector<double> s(9 + C);
+  { const double s9[9] = {RSUM(e, 0), RSUM(e, 1), RSUM(e, 2), RSUM(e, 3), RSUM(e, 4), RSUM(e, 5), RSUM(e, 6), RSUM(e, 7), RSUM(e, 12)};
+    for (int c = 0; c < 9; c++) s[c] = s9[c]; }
+  if ((rc = reduce_local(e, 1, C))) return rc;
+  for (int c = 0; c < C; c++) s[9 + c] = RSUM(e, c);
+  rc = xreduce(e, s.data(), 9 + C, nullptr, 0);
+  e->totals.assign(s.begin() + 9, s.end());
+  e->totals_valid = rc == 0;
   out->accepted_internal = (int64_t)s[0];
   out->accepted_mignode = (int64_t)s[1];
   out->accepted_spr = (int64_t)s[2];
@@ -665,6 +677,7 @@ int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result
 int gph_engine_tau_commit(gph_engine *e)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
+  e->totals_valid = false;
   LAUNCH(e, 5, k_tau_commit, e->tau);
   return finish_kernel(e);
 }
@@ -678,6 +691,7 @@ int gph_engine_tau_revert(gph_engine *e, int64_t first_conflict)
 #else
   HIPCHK(hipMemsetAsync(e->dev.out, 0, sizeof(double) * GPH_OUT_SLOTS * e->L, e->stream));
 #endif
+  e->totals_valid = false;
   LAUNCH(e, 6, k_tau_revert, limit);
   return finish_kernel(e);
 }
@@ -698,6 +712,7 @@ int gph_engine_mixing_evaluate(gph_engine *e, double c, double *dataDelta)
 int gph_engine_mixing_commit(gph_engine *e, double c, double lnc)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
+  e->totals_valid = false;
   LAUNCH(e, 7, k_mix_commit, c, lnc);
   return finish_kernel(e);
 }
@@ -754,11 +769,16 @@ int gph_engine_get_totals(gph_engine *e, double *cs, double *nc, double *ms, dou
   int rc0 = upload_tables(e);
   if (rc0) return rc0;
 #endif
-  int rc = reduce_local(e, 1, 2 * K + 2 * B);
-  if (rc) return rc;
+  int rc = 0;
   std::vector<double> s(2 * K + 2 * B);
-  for (int c = 0; c < 2 * K + 2 * B; c++) s[c] = RSUM(e, c);
-  rc = xreduce(e, s.data(), 2 * K + 2 * B, nullptr, 0);
+  if (e->totals_valid) {
+    s = e->totals;
+  } else {
+    rc = reduce_local(e, 1, 2 * K + 2 * B);
+    if (rc) return rc;
+    for (int c = 0; c < 2 * K + 2 * B; c++) s[c] = RSUM(e, c);
+    rc = xreduce(e, s.data(), 2 * K + 2 * B, nullptr, 0);
+  }
   for (int p = 0; p < K; p++) { cs[p] = s[p]; nc[p] = s[K + p]; }
   for (int b = 0; b < B; b++) { ms[b] = s[2 * K + b]; nm[b] = s[2 * K + B + b]; }
   return rc;
@@ -776,6 +796,7 @@ int gph_engine_synchronize(gph_engine *e, int32_t refresh, double *oldGen, doubl
     return 0;
   }
   { int rcs = flush_sync(e); if (rcs) return rcs; }
+  e->totals_valid = false;
   LAUNCH(e, 8, k_sync, (int)refresh);
   int rc = finish_kernel(e);
   if (rc) return rc;
@@ -791,6 +812,7 @@ int gph_engine_check_all(gph_engine *e, int32_t *ok, double *sumData, double *su
 {
   if (!e || !e->initialized) return GPH_ESTATE;
   { int rcs = flush_sync(e); if (rcs) return rcs; }
+  e->totals_valid = false;
   LAUNCH(e, 4, k_check, 0);
   int rc = finish_kernel(e);
   if (rc) return rc;
@@ -941,6 +963,7 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
   }
 #endif
   if (res[4] != 0.0) { fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by the locus-rate scan\n", (int)res[4]); return GPH_EKERNEL; }
+  e->totals_valid = false;
   LAUNCH(e, 10, k_lrate_apply, (const GphLrRec *)e->d_lrec);
   rc = finish_kernel(e);
   if (rc) return rc;

@@ -583,7 +583,8 @@ int gph_mcmc_iteration(gph_mcmc *m, int32_t iteration)
   if ((rc = update_sample_age(m, iteration, accArr.data()))) return rc;
   for (int pop = 0; pop < m->Kc; pop++) { m->acc[5] += accArr[pop]; m->accTau[pop] += accArr[pop]; }
   if (m->doMixing) {
-    if ((rc = refresh_totals(m))) return rc;
+    /* mixing reads the event COUNTS only (GPhoCS.c:4722-4760); UpdateTau / UpdateSampleAge move events inside
+     * their populations and change no count, so the totals taken after the genealogy sweep still hold them */
     if ((rc = mixing(m, m->ftMixing, &acc))) return rc;
     m->acc[6] += acc;
     rec_line(m, iteration, "MIX", acc);
