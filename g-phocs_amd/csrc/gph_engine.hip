@@ -169,6 +169,8 @@ struct gph_engine {
   double lr_hits = 0;                // proposals of the last update decided with the prepared likelihood
   int32_t *d_slot_of = nullptr;
   double *d_lr_result = nullptr, *d_lr_gscr = nullptr;
+  char *d_ref_page = nullptr, *d_ref_seq = nullptr;   // the reference locus's node records / scalars and sequence block on this rank
+  std::vector<uint64_t> h_seq_off;
   GphLrArgs lr;
   int lr_lds_bytes = 0;
   double *d_part = nullptr, *d_red = nullptr;
@@ -453,7 +455,7 @@ void gph_engine_destroy(gph_engine *e)
   if (!e) return;
   dev_free(e->dev.pages); dev_free(e->dev.shadow); dev_free(e->dev.cond); dev_free((void *)e->dev.cond_off);
   dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
-  dev_free(e->d_lrec); dev_free(e->d_lpre); dev_free(e->d_slot_of); dev_free(e->d_lr_result); dev_free(e->d_lr_gscr);
+  dev_free(e->d_lrec); dev_free(e->d_lpre); dev_free(e->d_slot_of); dev_free(e->d_lr_result); dev_free(e->d_lr_gscr); dev_free(e->d_ref_page); dev_free(e->d_ref_seq);
   dev_free(e->d_part); dev_free(e->d_red);
 #ifndef GPH_HOSTEMU
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -525,6 +527,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   }
   e->h_cond_off[L] = off;
   seq_off[L] = soff;
+  e->h_seq_off = seq_off;
   std::vector<char> seq(soff, 0);
   for (int64_t j = 0; j < L; j++) {
     int64_t g = e->h_orig[j];
@@ -904,19 +907,68 @@ int gph_engine_set_locus_rates(gph_engine *e, const double *rates, int32_t draws
 }
 
 // UpdateLocusRate (GPhoCS.c:4598-4680): a serial scan by one wavefront + a parallel write-back (gph_kernels.h)
+// one vector of doubles from the rank that owns it to every rank, through the sum all-reduce (the others add
+// zeros: exact), in pieces small enough for any caller-supplied hook (<= 24 doubles a call)
+static int lr_share(gph_engine *e, bool mine, std::vector<double> &v)
+{
+  if (!e->allreduce) return 0;
+  for (size_t off = 0; off < v.size(); off += 24) {
+    double buf[24];
+    const int nn = (int)(v.size() - off < 24 ? v.size() - off : 24);
+    for (int i = 0; i < nn; i++) buf[i] = mine ? v[off + i] : 0.0;
+    int rc = xreduce(e, buf, nn, nullptr, 0);
+    if (rc) return rc;
+    for (int i = 0; i < nn; i++) v[off + i] = buf[i];
+  }
+  return 0;
+}
+
 int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, gph_locus_rate_result *io)
 {
   if (!e || !e->initialized || !io) return GPH_ESTATE;
   io->accepted = 0;
   if (finetune <= 0.0) return 0;                       /* GPhoCS.c:4606 */
-  if (e->allreduce || e->cfg.locus_begin != 0 || e->cfg.L_total != e->L) {
-    fprintf(stderr, "gphocs_hip: UpdateLocusRate couples every locus to locus 0 serially; it runs on one GPU only\n");
+  const bool owner = e->cfg.locus_begin == 0;          /* this rank holds the reference locus (genRateRef = 0) */
+  if (!e->allreduce && (!owner || e->cfg.L_total != e->L)) {
+    fprintf(stderr, "gphocs_hip: UpdateLocusRate over a shard of the loci needs the all-reduce hook (gph_engine_set_allreduce)\n");
     return GPH_EARG;
   }
   { int rcs = flush_sync(e); if (rcs) return rcs; }
-  const int n = e->cfg.n, N = 2 * n - 1, Pmax = e->lay.Pmax;
+  const GphLayout &y = e->lay;
+  const int n = e->cfg.n, N = 2 * n - 1;
+  int rc = 0;
+  /* ---- the reference locus as every rank needs it: node records + rate, likelihood, root (every call), sequence
+   * block (first call: it never changes).  32-bit words travel as doubles */
+  std::vector<char> refpg(y.page_bytes, 0);
+  int jr = -1;
+  if (owner) {
+    for (int64_t j = 0; j < e->L; j++) if (e->h_orig[j] == 0) jr = (int)j;
+    if ((rc = d2h(e, refpg.data(), e->dev.pages + (size_t)jr * y.page_bytes, y.page_bytes))) return rc;
+  }
+  {
+    std::vector<double> v(4 * N + 4, 0.0);
+    if (owner) {
+      const uint32_t *w = (const uint32_t *)(refpg.data() + y.o_nd);
+      for (int i = 0; i < 4 * N; i++) v[i] = (double)w[i];
+      v[4 * N] = ((const double *)(refpg.data() + y.o_fscal))[FS_MUTRATE];
+      v[4 * N + 1] = ((const double *)(refpg.data() + y.o_fscal))[FS_DATALNL];
+      v[4 * N + 2] = (double)((const int32_t *)(refpg.data() + y.o_iscal))[IS_ROOT];
+      v[4 * N + 3] = (double)e->h_P[jr];
+    }
+    if ((rc = lr_share(e, owner, v))) return rc;
+    if (!owner) {
+      uint32_t *w = (uint32_t *)(refpg.data() + y.o_nd);
+      for (int i = 0; i < 4 * N; i++) w[i] = (uint32_t)v[i];
+      ((double *)(refpg.data() + y.o_fscal))[FS_MUTRATE] = v[4 * N];
+      ((double *)(refpg.data() + y.o_fscal))[FS_DATALNL] = v[4 * N + 1];
+      ((int32_t *)(refpg.data() + y.o_iscal))[IS_ROOT] = (int32_t)v[4 * N + 2];
+    }
+    e->lr.ref_P = (int32_t)v[4 * N + 3];
+    e->lr.rref0 = v[4 * N];
+    e->lr.likref0 = v[4 * N + 1];
+  }
+  const int Pr = e->lr.ref_P, Pmax = y.Pmax > Pr ? y.Pmax : Pr;
   if (!e->d_lrec) {
-    int rc = 0;
     std::vector<int32_t> slot_of(e->L);
     for (int64_t j = 0; j < e->L; j++) slot_of[e->h_orig[j]] = (int32_t)j;
     // dynamic LDS of the scan: guest sequence block | reference sequence block | guest nodes | reference nodes | scratch
@@ -927,57 +979,103 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     if (const char *ov = getenv("GPH_LR_PSCR")) Pscr = atoi(ov) < Pscr ? atoi(ov) : Pscr;   /* tests: force the global-scratch path */
     if (Pscr > Pmax) Pscr = Pmax;
     if (Pscr < 0) Pscr = 0;
+    const double finetune0 = e->lr.finetune; (void)finetune0;
+    const int32_t refP = e->lr.ref_P; const double r0 = e->lr.rref0, l0 = e->lr.likref0;
     memset(&e->lr, 0, sizeof e->lr);
+    e->lr.ref_P = refP; e->lr.rref0 = r0; e->lr.likref0 = l0;
     e->lr.o_rseq = seqb; e->lr.o_gnd = 2 * seqb; e->lr.o_rnd = 2 * seqb + ndb; e->lr.o_scr = fixed; e->lr.Pscr = Pscr;
     // behind the scratch: the reference locus's compiled program (one 16-byte entry per step and lane) and edge probabilities
     e->lr.o_prog = fixed + (n - 1) * Pscr * 32;
     e->lr.o_pe = e->lr.o_prog + (n - 1) * GPH_WAVE * 16;
     e->lr_lds_bytes = e->lr.o_pe + align_up(N * 8, 16);
+    e->lr.ref_seq_bytes = GPH_Q_BYTES(Pr, n);
     rc |= dev_alloc((void **)&e->d_lrec, sizeof(GphLrRec) * e->L);
     rc |= dev_alloc((void **)&e->d_lpre, sizeof(GphLrPre) * e->L);
     rc |= dev_alloc((void **)&e->d_slot_of, sizeof(int32_t) * e->L);
     rc |= dev_alloc((void **)&e->d_lr_result, sizeof(double) * 16);
     rc |= dev_alloc((void **)&e->d_lr_gscr, Pmax > Pscr ? sizeof(double) * 4 * (size_t)(n - 1) * Pmax : 16);
+    rc |= dev_alloc((void **)&e->d_ref_page, y.page_bytes);
+    rc |= dev_alloc((void **)&e->d_ref_seq, e->lr.ref_seq_bytes + 16);
     if (rc) return GPH_EHIP;
     if (h2d(e, e->d_slot_of, slot_of.data(), sizeof(int32_t) * e->L)) return GPH_EHIP;
     e->lr.result = e->d_lr_result; e->lr.rec = e->d_lrec; e->lr.pre = e->d_lpre; e->lr.slot_of = e->d_slot_of; e->lr.gscr = e->d_lr_gscr;
+    /* the reference locus's sequence block: the owner's copy goes round once */
+    std::vector<char> seqblk(e->lr.ref_seq_bytes + 16, 0);
+    if (owner && e->lr.ref_seq_bytes > 0 &&
+        (rc = d2h(e, seqblk.data(), e->dev.seq + e->h_seq_off[jr], e->lr.ref_seq_bytes))) return rc;
+    {
+      std::vector<double> v(e->lr.ref_seq_bytes / 4, 0.0);
+      if (owner) for (size_t i = 0; i < v.size(); i++) v[i] = (double)((const uint32_t *)seqblk.data())[i];
+      if ((rc = lr_share(e, owner, v))) return rc;
+      if (!owner) for (size_t i = 0; i < v.size(); i++) ((uint32_t *)seqblk.data())[i] = (uint32_t)v[i];
+    }
+    if (e->lr.ref_seq_bytes > 0 && h2d(e, e->d_ref_seq, seqblk.data(), e->lr.ref_seq_bytes)) return GPH_EHIP;
+    e->lr.ref_seq = e->d_ref_seq;
+    e->lr.ref_page = e->d_ref_page;
 #ifndef GPH_HOSTEMU
     HIPCHK(hipFuncSetAttribute((const void *)k_lrate_scan, hipFuncAttributeMaxDynamicSharedMemorySize, e->lr_lds_bytes));
 #endif
   }
+  if (h2d(e, e->d_ref_page, refpg.data(), y.page_bytes)) return GPH_EHIP;
   e->lr.finetune = finetune; e->lr.alpha = alpha;
-  e->lr.dataLnL = io->dataLogLikelihood; e->lr.logL = io->logLikelihood; e->lr.rateVar = io->rateVar;
+  e->lr.first = owner ? 1 : 0;
   LAUNCH(e, 11, k_lrate_prep, finetune, e->d_lpre);
   { int rcp = finish_kernel(e); if (rcp) return rcp; }
-  LAUNCH1(e, 9, k_lrate_scan, e->lr_lds_bytes, e->lr);
-  double res[16];
-  int rc = d2h(e, res, e->d_lr_result, sizeof res);
-  if (rc) return rc;
+  /* ---- the scan, rank after rank in locus order: state = {next locus, rref, likref, dataLogLikelihood,
+   * logLikelihood, rateVar, accepted, prepared rates used}; the rank whose block starts at `next` scans and
+   * publishes the state, the others add zeros */
+  double st[8] = {0.0, e->lr.rref0, e->lr.likref0, io->dataLogLikelihood, io->logLikelihood, io->rateVar, 0.0, 0.0};
+  double res[16] = {0};
+  for (int guard = 0; (int64_t)st[0] < e->cfg.L_total; guard++) {
+    if (guard > 1 << 20) return GPH_ESTATE;
+    const bool mine = (int64_t)st[0] == e->cfg.locus_begin;
+    double nx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (mine) {
+      e->lr.rref0 = st[1]; e->lr.likref0 = st[2];
+      e->lr.dataLnL = st[3]; e->lr.logL = st[4]; e->lr.rateVar = st[5];
+      LAUNCH1(e, 9, k_lrate_scan, e->lr_lds_bytes, e->lr);
+      if ((rc = d2h(e, res, e->d_lr_result, sizeof res))) return rc;
 #ifndef GPH_HOSTEMU
-  if (e->timing_pending) {
-    float ms = 0;
-    e->timing_pending = false;
-    HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    e->last_ms[9] = ms;
-    e->cls_ms[9] += ms;
-  }
+      if (e->timing_pending) {
+        float ms = 0;
+        e->timing_pending = false;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->last_ms[9] = ms;
+        e->cls_ms[9] += ms;
+      }
 #endif
-  if (res[4] != 0.0) { fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by the locus-rate scan\n", (int)res[4]); return GPH_EKERNEL; }
+      if (res[4] != 0.0) { fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by the locus-rate scan\n", (int)res[4]); return GPH_EKERNEL; }
+      nx[0] = (double)(e->cfg.locus_begin + e->L); nx[1] = res[13]; nx[2] = res[14];
+      nx[3] = res[1]; nx[4] = res[2]; nx[5] = res[3]; nx[6] = st[6] + res[0]; nx[7] = st[7] + res[5];
+    }
+    if (e->allreduce) { if ((rc = xreduce(e, nx, 8, nullptr, 0))) return rc; }
+    else if (!mine) return GPH_ESTATE;
+    if (nx[0] <= st[0]) { fprintf(stderr, "gphocs_hip: the ranks' locus blocks do not tile 0..L_total\n"); return GPH_EARG; }
+    memcpy(st, nx, sizeof st);
+  }
+  if (owner) {
+    /* the reference locus's record: its last accepted rate / likelihood and the number of accepted proposals */
+    GphLrRec r;
+    const int32_t *is = (const int32_t *)(refpg.data() + y.o_iscal);
+    r.rate = st[1]; r.lnl = st[2]; r.rx = (uint32_t)is[IS_RX]; r.ry = (uint32_t)is[IS_RY]; r.rz = (uint32_t)is[IS_RZ];
+    r.flag = (int32_t)st[6] << 2;
+    if (h2d(e, e->d_lrec + jr, &r, sizeof r)) return GPH_EHIP;
+  }
   e->totals_valid = false;
   LAUNCH(e, 10, k_lrate_apply, (const GphLrRec *)e->d_lrec);
   rc = finish_kernel(e);
   if (rc) return rc;
-  io->accepted = (int64_t)res[0];
-  io->dataLogLikelihood = res[1];
-  io->logLikelihood = res[2];
-  io->rateVar = res[3];
-  e->lr_hits = res[5];
+  io->accepted = (int64_t)st[6];
+  io->dataLogLikelihood = st[3];
+  io->logLikelihood = st[4];
+  io->rateVar = st[5];
+  e->lr_hits = st[7];
 #ifdef GPH_LRSTAMP
   fprintf(stderr, "evaluator stamps: setup+exp %.0f, nodes %.0f, root %.0f cycles per call (%.0f calls, %.1f steps)\n", res[8] / res[11], res[9] / res[11], res[10] / res[11], res[11], res[12] / res[11]);
 #endif
   if (getenv("GPH_LR_VERBOSE"))
     fprintf(stderr, "gphocs_hip: locus-rate scan: %.0f of %lld proposals decided with the prepared likelihood; %.3g shader cycles in %.3g s (%.0f MHz)\n",
-            res[5], (long long)(e->L - 1), res[6], res[7] / 1e8, res[7] > 0 ? res[6] / (res[7] / 1e8) / 1e6 : 0.0);
+            st[7], (long long)(e->cfg.L_total - 1), res[6], res[7] / 1e8, res[7] > 0 ? res[6] / (res[7] / 1e8) / 1e6 : 0.0);
   return 0;
 }
 

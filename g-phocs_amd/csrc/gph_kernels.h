@@ -699,7 +699,12 @@ struct alignas(16) GphLrPre {   // prepared proposal of one locus (input order)
 struct GphLrArgs {
   double finetune, alpha, dataLnL, logL, rateVar;
   int32_t o_gnd, o_rnd, o_rseq, o_scr, Pscr, o_prog;   // dynamic-LDS byte offsets; loci with P <= Pscr use LDS scratch
-  int32_t o_pe, unused;                                // o_prog / o_pe: compiled program and edge probabilities of the reference locus
+  int32_t o_pe, first;                                 // o_prog / o_pe: compiled program and edge probabilities of the reference locus; first = first local locus that proposes
+  // the reference locus as this rank sees it: its node records / scalars (page layout), its sequence block, and the
+  // rate / likelihood it has after the loci scanned before this rank's block
+  const char *ref_page, *ref_seq;
+  int32_t ref_P, ref_seq_bytes;
+  double rref0, likref0;
   double *result;            // [0] accepted [1] dataLogLikelihood [2] logLikelihood [3] rateVar [4] error code [5] prepared rates used
   GphLrRec *rec;             // one per slot
   GphLrPre *pre;             // one per locus, input order
@@ -736,9 +741,8 @@ GPH_DEV void kb_lrate_prep(const GphDev &D, int g, double finetune, GphLrPre *pr
   stage_out(D, g, D.shadow, 2);
 }
 
-GPH_DEV void lr_load(const GphDev &D, int j, int o_nd, int o_seq, int &P, int &root, double &rate, double &lnl, GphRng &rng)
+GPH_DEV void lr_load(const char *pg, const char *seqp, int seqbytes, int o_nd, int o_seq, int &root, double &rate, double &lnl, GphRng &rng)
 {
-  const char *pg = D.pages + (size_t)j * g_lay.page_bytes;
 #ifdef GPH_HOSTEMU
   memcpy(gph_sm + o_nd, pg + g_lay.o_nd, (size_t)g_lay.N * sizeof(GphNode));
 #else
@@ -746,14 +750,13 @@ GPH_DEV void lr_load(const GphDev &D, int j, int o_nd, int o_seq, int &P, int &r
   typedef GPH_LDS gu32x4 luint4;
   if (GPH_LANE < g_lay.N) ((luint4 *)(GPH_SMB + o_nd))[GPH_LANE] = ((const gu32x4 *)(pg + g_lay.o_nd))[GPH_LANE];
 #endif
-  copy16_g2l(o_seq, D.seq + D.seq_off[j], (int)(D.seq_off[j + 1] - D.seq_off[j]));
+  copy16_g2l(o_seq, seqp, seqbytes);
   const double *fs = (const double *)(pg + g_lay.o_fscal);
   const int32_t *is = (const int32_t *)(pg + g_lay.o_iscal);
   rate = RFLD(fs[FS_MUTRATE]);
   lnl = RFLD(fs[FS_DATALNL]);
   root = RFL(is[IS_ROOT]);
   rng.x = (uint32_t)RFL(is[IS_RX]); rng.y = (uint32_t)RFL(is[IS_RY]); rng.z = (uint32_t)RFL(is[IS_RZ]);
-  P = RFL(D.P[j]);
   GPH_SYNC();
 }
 
@@ -958,8 +961,10 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
 #ifndef GPH_HOSTEMU
   const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int jr = RFL(A.slot_of[0]);
-  lr_load(D, jr, A.o_rnd, A.o_rseq, Pr, rootr, rref, likref, rngr);
+  Pr = A.ref_P;
+  lr_load(A.ref_page, A.ref_seq, A.ref_seq_bytes, A.o_rnd, A.o_rseq, rootr, dummy_r, dummy_l, rngr);
+  rref = A.rref0;
+  likref = A.likref0;
   double dataLnL = A.dataLnL, logL = A.logL, rateVar = A.rateVar;
   const double Ld = (double)D.Ltot;
   gdbl *gs = (gdbl *)A.gscr;
@@ -967,7 +972,7 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
   GphRefProg RP;
   lr_ref_compile(A, Pr, RP);
 #endif
-  for (int base = 1; base < D.L; base += GPH_NLANES) {
+  for (int base = A.first; base < D.L; base += GPH_NLANES) {
     /* one batch of prepared proposals: lane i holds locus base + i */
     const int mine = base + GPH_LANE < D.L ? base + GPH_LANE : D.L - 1;
     const GphLrPre pm = A.pre[mine];
@@ -998,7 +1003,9 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
       } else {
         GphRng unused_rng;
         GPH_SYNC();
-        lr_load(D, j, A.o_gnd, 0, P, root, dummy_r, dummy_l, unused_rng);
+        P = RFL(D.P[j]);
+        lr_load(D.pages + (size_t)j * g_lay.page_bytes, D.seq + D.seq_off[j], (int)(D.seq_off[j + 1] - D.seq_off[j]), A.o_gnd, 0, root,
+                dummy_r, dummy_l, unused_rng);
         lg = lik_private(A.o_gnd, 0, P, root, rnew, A.o_scr, P > A.Pscr ? gs : (gdbl *)0);
       }
       lnLd += lg;
@@ -1031,9 +1038,8 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
     if (gph_failed()) break;
   }
   if (GPH_LANE == 0) {
-    GphLrRec r;
-    r.rate = rref; r.lnl = likref; r.rx = rngr.x; r.ry = rngr.y; r.rz = rngr.z; r.flag = accepted << 2;
-    A.rec[jr] = r;
+    /* the reference locus's own record is written by the host once every rank's block has been scanned */
+    A.result[13] = rref; A.result[14] = likref;
     A.result[0] = accepted; A.result[1] = dataLnL; A.result[2] = logL; A.result[3] = rateVar; A.result[4] = CNT(CN_ERROR);
     A.result[5] = hits;
 #ifndef GPH_HOSTEMU

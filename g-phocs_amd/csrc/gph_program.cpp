@@ -62,8 +62,6 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
   if ((rc = gph_control_read(ctl, ctl2, &C))) return fail(rc, "reading the control file");
   gph_control_get(C, &cfg, &mc, &info);
   if (lead) printf("Done.\n");
-  if (info.mutRateMode == 1 && world > 1)
-    return fail(GPH_EARG, "locus-mut-rate VAR with several ranks (UpdateLocusRate couples every locus to locus 0 serially: one GPU only)");
   if (mc.seed < 0) {
     if (world > 1) return fail(GPH_EARG, "random-seed must be given in the control file when several ranks run one chain");
     mc.seed = abs(2 * (int)time(NULL) + 1);   /* GPhoCS.c:188-191 */

@@ -120,7 +120,9 @@ int gph_engine_mixing_revert(gph_engine *e);
  * proposal also moves the rate of the reference locus, genRateRef = 0): one wavefront scans the loci in input
  * order with a stateless evaluator, the accepted loci are then rewritten in parallel.  in/out: the three
  * accumulators the reference updates per accepted proposal (dataState.dataLogLikelihood, .logLikelihood,
- * .rateVar); returns the accept count.  finetune <= 0 returns 0 accepted at once (:4606).  One GPU only. */
+ * .rateVar); returns the accept count.  finetune <= 0 returns 0 accepted at once (:4606).  With loci sharded over
+ * ranks the scan is chained through the ranks in locus order over the all-reduce hook (same additions in the same
+ * order: bit-identical to one rank); every rank gets the same result. */
 typedef struct gph_locus_rate_result {
   int64_t accepted;
   double dataLogLikelihood, logLikelihood, rateVar;

@@ -246,18 +246,19 @@ def test_program_trace_file(name, tmp_path):
 
 
 @pytest.mark.gpu
-def test_program_through_rccl_launcher(tmp_path):
+@pytest.mark.parametrize("name", ["a7", "v8"])
+def test_program_through_rccl_launcher(tmp_path, name):
     """tools/run_multi_gpu.py under torch.distributed.run with the nccl (= RCCL) backend and one rank on this GPU:
     the all-gather hook with device tensors, gph_run_control_file_ranked, trace file vs the real binary's"""
     import shutil
     for ext in (".ctl", ".seq"):
-        shutil.copy(os.path.join(GOLDEN, "a7" + ext), tmp_path)
+        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(REPO, "tools", "run_multi_gpu.py"), "a7.ctl"]
+           "--master-port", "29533", os.path.join(REPO, "tools", "run_multi_gpu.py"), name + ".ctl"]
     r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    want = open(os.path.join(GOLDEN, "a7.trace")).read().splitlines()
-    got = open(os.path.join(tmp_path, "a7.trace")).read().splitlines()
+    want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
+    got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
     assert want[0] == got[0] and len(want) == len(got)
     for w, g in zip(want[1:], got[1:]):
         if w == g:

@@ -48,8 +48,11 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("name,iters,presharded", [("m3", 60, 0), ("g1", 12, 0), ("m3", 40, 1)])
-def test_two_ranks_equal_one_rank(name, iters, presharded, tmp_path):
+@pytest.mark.parametrize("name,iters,presharded,world", [("m3", 60, 0, 2), ("g1", 12, 0, 2), ("m3", 40, 1, 2),
+                                                         # locus-mut-rate VAR: the serial scan of UpdateLocusRate is chained
+                                                         # through the ranks, the reference locus travels from rank 0
+                                                         ("v8", 60, 0, 2), ("v9", 40, 1, 2), ("v8", 30, 0, 3)])
+def test_two_ranks_equal_one_rank(name, iters, presharded, world, tmp_path):
     sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
     import run_hostemu as R
     R.build_hostemu()
@@ -57,12 +60,13 @@ def test_two_ranks_equal_one_rank(name, iters, presharded, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % dict(repo=REPO, pack=os.path.join(GOLDEN, name + ".gpk"), out=out, iters=iters,
                                       presharded=presharded))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     # every rank runs the same host driver and must have written identical records
-    assert open(out + ".0").read() == open(out + ".1").read()
+    for r in range(1, world):
+        assert open(out + ".0").read() == open(out + ".%d" % r).read()
     # and they must equal the single-rank run (= the reference golden) up to reduction order
     golden = open(os.path.join(GOLDEN, name + ".rtrace")).read().splitlines()
     mine = open(out + ".0").read().splitlines()
@@ -72,7 +76,8 @@ def test_two_ranks_equal_one_rank(name, iters, presharded, tmp_path):
     compare_records(out + ".0", str(tmp_path / "g"))
 
 
-def test_program_over_two_ranks(tmp_path):
+@pytest.mark.parametrize("name", ["m3", "v8"])
+def test_program_over_two_ranks(tmp_path, name):
     """the whole program (control file -> trace file) over two ranks: tools/run_multi_gpu.py with gloo and the
     host-emulation build; rank 0's trace file against the real binary's (reduction order differs from the
     single-process run, so values agree to ~1e-13 relative and the printed digits may differ in the last place)"""
@@ -81,14 +86,14 @@ def test_program_over_two_ranks(tmp_path):
     import run_hostemu as R
     lib = R.build_hostemu()
     for ext in (".ctl", ".seq"):
-        shutil.copy(os.path.join(GOLDEN, "m3" + ext), tmp_path)
+        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
-    cmd = [sys.executable, os.path.join(REPO, "tools", "run_multi_gpu.py"), "m3.ctl", "--backend", "gloo", "--lib", lib]
+    cmd = [sys.executable, os.path.join(REPO, "tools", "run_multi_gpu.py"), name + ".ctl", "--backend", "gloo", "--lib", lib]
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=tmp_path) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=600) == 0
-    want = open(os.path.join(GOLDEN, "m3.trace")).read().splitlines()
-    got = open(os.path.join(tmp_path, "m3.trace")).read().splitlines()
+    want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
+    got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
     assert want[0] == got[0] and len(want) == len(got)
     for w, g in zip(want[1:], got[1:]):
         if w == g:
