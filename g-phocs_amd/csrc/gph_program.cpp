@@ -78,8 +78,16 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
     int64_t up = 0;
     for (int64_t g = 0; g < L; g++) up += unph[g];
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (lead) printf("Read %lld loci over %d samples: %lld patterns (%.2f per locus) -> %lld phased patterns (%.2f per locus) in %.2f s.\n",
-           (long long)L, n, (long long)up, (double)up / L, (long long)offs[L], (double)offs[L] / L, sec);
+    if (lead) {   /* the progress text of readSeqFile (AlignmentProcessor.c:547, 562, 678-687) and main's blank line (GPhoCS.c:233) */
+      printf("Reading sequence data...  %lld loci, as specified in sequence file %s.\n", (long long)L, info.seqFile);
+      printf("Reading loci (.=100 loci): ");
+      for (int64_t g = 1; g <= L; g++)
+        if (g % 100 == 0) { printf("."); if (g % 1000 == 0) { printf(" "); if (g % 10000 == 0) printf("\n"); } }
+      printf("\n");
+      if (verbose) printf("Read %lld loci over %d samples: %lld patterns (%.2f per locus) -> %lld phased patterns (%.2f per locus) in %.2f s.\n",
+                          (long long)L, n, (long long)up, (double)up / L, (long long)offs[L], (double)offs[L] / L, sec);
+      printf("\n");
+    }
   }
   // loci shard in contiguous blocks of ceil(L / world) (OpenMP static scheduling of the reference, MultiCoreUtils.h:8)
   const int64_t per = (L + world - 1) / world, lb = std::min<int64_t>(rank * per, L), le = std::min<int64_t>((rank + 1) * per, L);
@@ -112,9 +120,31 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
   std::vector<double> vals(mc.numParameters + 4, 0.0);
   double logL = 0, dataL = 0;
   auto t1 = std::chrono::steady_clock::now();
+  const time_t wall0 = time(NULL);
+  auto printtime = [&](char *buf, size_t len) {   /* printtime(), utils.c:314-326 */
+    const long t = (long)(time(NULL) - wall0);
+    const long h = t / 3600, mm = (t % 3600) / 60, ss = t - (t / 60) * 60;
+    if (h) snprintf(buf, len, "%ld:%02ld:%02ld", h, mm, ss);
+    else snprintf(buf, len, "%2ld:%02ld", mm, ss);
+    return buf;
+  };
+  char tbuf[64];
+  // the log on stdout: title, GPhoCS.c:1329, 1356-1374
+  if (lead) {
+    printf("There are %d parameters in the model.\n", mc.numParameters);
+    printf("Samples   CoalTimes MigTimes  SPRs      Thetas    MigRates ");
+    for (int p = 0; p < cfg.K; p++) if (p >= cfg.Kc || mc.updateSampleAge[p]) printf("TAU_%2d    ", p);
+    printf("RbberBnd  MutRates  Mixing    | DATA-ln-ld |  TIME\n");
+    printf("-------------------------------------------------------------"
+           "-------------------------------------------------------------"
+           "---------------------------\n");
+    fflush(stdout);
+  }
+  int logsPerLine = info.logsPerLine;
   // log periods and the find-finetunes search, GPhoCS.c:1401-1447, 1808-2249
   int samplesPerLog = mc.samplesPerLog, findingFinetunes = 0;
-  Finetune fCoal{mc.ftCoalTime}, fMig{mc.ftMigTime}, fTheta{mc.ftTheta}, fRate{mc.ftMigRate}, fMix{mc.ftMixing}, fLocus{mc.ftLocusRate};
+  Finetune fCoal{mc.ftCoalTime}, fMig{mc.ftMigTime}, fTheta{mc.ftTheta}, fRate{mc.ftMigRate}, fMix{mc.ftMixing}, fLocus{mc.ftLocusRate}, fAdmix{-1.0};
+  /* fAdmix: upstream also bisects the (unused) admixture step and prints it (GPhoCS.c:2040-2066, 2190) */
   std::vector<Finetune> fTau(cfg.K);
   for (int p = 0; p < cfg.K; p++) fTau[p].v = mc.ftTaus[p];
   auto push_finetunes = [&]() {
@@ -126,17 +156,34 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
   if (info.findFinetunes) {
     findingFinetunes = 1;
     samplesPerLog = info.findFinetunesSamplesPerStep;
-    if (lead) printf("   ---  Dynamically finding finetune settings for the first %d samples, updating finetunes every %d samples  ---- \n",
-           samplesPerLog * info.findFinetunesNumSteps, samplesPerLog);
-    for (Finetune *f : {&fCoal, &fMig, &fTheta, &fRate, &fMix, &fLocus}) if (f->v < 0) f->v = 1.0;
+    logsPerLine = 1;
+    if (lead) {
+      printf("   ---  Dynamically finding finetune settings for the first %d samples, updating finetunes every %d samples  ---- \n",
+             samplesPerLog * info.findFinetunesNumSteps, samplesPerLog);
+      printf("------------------------------------------------------------"
+             "------------------------------------------------------------"
+             "-----------------------------\n");
+    }
+    for (Finetune *f : {&fCoal, &fMig, &fTheta, &fRate, &fMix, &fLocus, &fAdmix}) if (f->v < 0) f->v = 1.0;
     for (int p = 0; p < cfg.K; p++) if (fTau[p].v < 0) fTau[p].v = 1.0;
     if ((rc = push_finetunes())) return fail(rc, "gph_mcmc_set_finetunes");
     gph_mcmc_set_log_period(M, samplesPerLog);
   }
   int64_t logCount = 1, a0[9] = {0}, a[9], aLocus0 = 0, aLocus = 0;
   std::vector<int64_t> t0v(cfg.K, 0), tv(cfg.K, 0);
+  /* TAU columns of the log exactly as upstream accumulates them (GPhoCS.c:1620-1650): the whole accept array is
+   * added after UpdateTau AND after UpdateSampleAge, so an ancestral population's count goes in twice and an
+   * estimated sample age's goes in once stale (the previous iteration's) and once fresh */
+  std::vector<int64_t> tauPrevTotal(cfg.K, 0), tauLastIter(cfg.K, 0), tauShown(cfg.K, 0);
   for (int it = -info.burnin; it < info.numSamples; it++) {
     if ((rc = gph_mcmc_iteration(M, it))) return fail(rc, "gph_mcmc_iteration");
+    gph_mcmc_tau_accept_counts(M, tv.data());
+    for (int p = 0; p < cfg.K; p++) {
+      const int64_t now = tv[p] - tauPrevTotal[p];
+      tauShown[p] += p >= cfg.Kc ? 2 * now : tauLastIter[p] + now;
+      tauLastIter[p] = now;
+      tauPrevTotal[p] = tv[p];
+    }
     if (it >= 0 && it % (info.sampleSkip + 1) == 0) {   /* GPhoCS.c:1763-1769 */
       gph_mcmc_param_vals(M, vals.data(), mc.numParameters);
       gph_mcmc_get_state(M, &logL, &dataL, nullptr, nullptr, nullptr);
@@ -162,17 +209,23 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
       const double pMix = (a[6] - a0[6]) * 100.0 / lc;
       gph_mcmc_locus_rate_state(M, &aLocus, nullptr);
       const double pLocus = (aLocus - aLocus0) * 100.0 / (lc * (double)(info.numLoci - 1));   /* GPhoCS.c:1842-1845 */
-      double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-      if (lead) printf("%7d   %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    ", it + 1, pCoal, pMig, pSpr, pTheta, pRate);
-      for (int p = cfg.Kc; p < cfg.K; p++) if (lead) printf("%5.1f%%    ", 2 * (tv[p] - t0v[p]) * 100.0 / lc);
-      if (lead) printf("%5.1f%%    | %.6f | %.1f s\n", pMix, dataL, sec);
-      fflush(stdout);
+      if (lead) {   /* the log line, GPhoCS.c:1857-1895 */
+        printf("\r%7d   %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    %5.1f%%    ", it + 1, pCoal, pMig, pSpr, pTheta, pRate);
+        for (int p = 0; p < cfg.K; p++)
+          if (p >= cfg.Kc || mc.updateSampleAge[p]) printf("%5.1f%%    ", tauShown[p] * 100.0 / lc);
+        printf("%6.1f%%    %5.1f%%    %5.1f%%    ", (a[8] - a0[8]) * 100.0 / (lc * (cfg.K - cfg.Kc)), pLocus, pMix);
+        printf("|%12.6f|", logL);
+        printf(" %s", printtime(tbuf, sizeof tbuf));
+        if ((it + 1) % (samplesPerLog * logsPerLine) == 0) printf("\n");
+        fflush(stdout);
+      }
       if (findingFinetunes) {
         fCoal.adjust(pCoal); fMig.adjust(pMig); fTheta.adjust(pTheta); fRate.adjust(pRate); fMix.adjust(pMix);
         fLocus.adjust(pLocus);
+        fAdmix.adjust(0.0);
         for (int p = cfg.Kc; p < cfg.K; p++) fTau[p].adjust(2 * (tv[p] - t0v[p]) * 100.0 / lc);
         if ((rc = push_finetunes())) return fail(rc, "gph_mcmc_set_finetunes");
-        if (lead) printf("          %-9.7lf %-9.7lf           %-9.7lf %-9.7lf ", fCoal.v, fMig.v, fTheta.v, fRate.v);
+        if (lead) printf("          %-9.7lf %-9.7lf           %-9.7lf %-9.7lf %-9.7lf ", fCoal.v, fMig.v, fTheta.v, fRate.v, fAdmix.v);
         for (int p = cfg.Kc; p < cfg.K; p++) if (lead) printf("%-9.7lf ", fTau[p].v);
         if (lead) printf("          %-9.7lf %-9.7lf \n", fLocus.v, fMix.v);
       }
@@ -180,16 +233,28 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
       memcpy(a0, a, sizeof a0);
       aLocus0 = aLocus;
       t0v = tv;
+      std::fill(tauShown.begin(), tauShown.end(), 0);
       if (findingFinetunes && it + 1 >= info.findFinetunesSamplesPerStep * info.findFinetunesNumSteps) {
         findingFinetunes = 0;
         samplesPerLog = mc.samplesPerLog;
         gph_mcmc_set_log_period(M, samplesPerLog);
-        if (lead) printf("\n-------------------------------------  finetunes  ------------------------------------\n");
+        logsPerLine = info.logsPerLine;
+        if (lead) {   /* GPhoCS.c:2232-2251 */
+          printf("\n");
+          printf("-------------------------------------  finetunes  ------------------------------------\n");
+          printf("          %8lf  %8lf            %8lf  %8lf  ", fCoal.v, fMig.v, fTheta.v, fRate.v);
+          for (int p = 0; p < cfg.K; p++) printf("%8lf  ", fTau[p].v);
+          printf("          %8lf  %8lf  \n", fLocus.v, fMix.v);
+          printf("--------------------------------------------------------------------------------------\n");
+        }
       }
     }
   }
   double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-  if (lead) printf("MCMC finished. Time used: %.2f s (%.3f iterations/s).\n", sec, (info.burnin + info.numSamples) / (sec > 0 ? sec : 1));
+  if (lead) {
+    printf("\nMCMC finished. Time used: %s\n", printtime(tbuf, sizeof tbuf));   /* GPhoCS.c:2262 */
+    if (verbose) printf("(%.2f s, %.3f iterations/s)\n", sec, (info.burnin + info.numSamples) / (sec > 0 ? sec : 1));
+  }
   fclose(trace);
   gph_mcmc_destroy(M);
   gph_engine_destroy(E);

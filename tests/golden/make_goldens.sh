@@ -61,3 +61,7 @@ $RT g1.trace -b 3   > g1.readtrace_b3.txt
 $RT m3.trace -b 40  > m3.readtrace_b40.txt
 $RT a7.trace -d 20  > a7.readtrace_d20.txt
 $RT f3.trace -b 10 -d 20 > f3.readtrace_b10_d20.txt
+
+# the reference binary's stdout log for the same runs (banner, title, one line per log period, finetune search):
+# G-PhoCS-hip prints the same text from "Starting MCMC" on (the elapsed-time column aside)
+for name in g1 f3 v8 a7; do timeout 900 $REF main -n 1 $name.ctl > $name.stdout 2>/dev/null; done

@@ -208,3 +208,36 @@ def test_read_trace_partial_tail_and_errors(lib, tmp_path):
     open(p, "w").write("Sample\ta\tb\n0\t1.0\t2.0\n1\t3.0\t5.0\n2\t100.0\t100.0")
     rc, got, _ = _read_trace(lib, p)
     assert rc == 0 and got.split("\n")[1].split() == ["2.000000", "3.500000"]
+
+
+@pytest.mark.parametrize("name", ["g1", "f3", "v8", "a7"])
+def test_program_prints_the_reference_log(name, tmp_path):
+    """stdout of gph_run_control_file against the real binary's stdout for the same control file (tests/golden/*.stdout):
+    from "Reading control settings" on (i.e. everything but the version banner and the thread-count line) -- title, one `\\r`-refreshed line per log period with the acceptance percentages exactly as
+    upstream computes them (GPhoCS.c:1821-1895, quirks included), the finetune-search lines, the closing line -- equal
+    but for the elapsed-time column.  a7: upstream's first TAU entry of an estimated sample age is read before it is
+    ever written (GPhoCS.c:1620-1628), that one number is skipped."""
+    import re
+    import subprocess
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import gphocs_amd as G, run_hostemu as R\n"
+            "lib = G.load_library(R.build_hostemu())\n"
+            "lib.gph_run_control_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]\n"
+            "sys.exit(lib.gph_run_control_file(%r, None, 0, 0))\n") % (REPO, os.path.join(REPO, "tests", "hostemu"),
+                                                                     (name + ".ctl").encode())
+    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def norm(t):
+        t = t.replace("\r", "\n")
+        t = re.sub(r"\|\s*\d+:\d\d(:\d\d)?", "| T", t)
+        t = re.sub(r"Time used:\s+\d+:\d\d(:\d\d)?", "Time used: T", t)
+        return t[t.index("Reading control settings"):].split("\n")
+    want, got = norm(open(os.path.join(GOLDEN, name + ".stdout")).read()), norm(r.stdout)
+    assert len(want) == len(got)
+    for i, (w, g) in enumerate(zip(want, got)):
+        if name == "a7" and w != g and w.split()[:6] == g.split()[:6] and w.split()[7:] == g.split()[7:]:
+            continue      # the uninitialised TAU entry of the first period
+        assert w == g, (i, w, g)
