@@ -974,7 +974,8 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     // dynamic LDS of the scan: guest sequence block | reference sequence block | guest nodes | reference nodes | scratch
     const int seqb = align_up(GPH_Q_TERMS(Pmax, n) + (Pmax > GPH_WAVE ? 8 * Pmax : 0), 16), ndb = N * (int)sizeof(GphNode);
     const int fixed = 2 * seqb + 2 * ndb;
-    const int budget = 96 * 1024 - (int)sizeof(GphLds) - (n - 1) * GPH_WAVE * 16 - align_up(N * 8, 16);
+    const int lfb = Pr >= 1 && Pr <= GPH_WAVE ? n * Pr * 32 : 0;      // the reference locus's leaves as conditional arrays
+    const int budget = 96 * 1024 - (int)sizeof(GphLds) - (n - 1) * GPH_WAVE * 16 - align_up(N * 8, 16) - lfb;
     int Pscr = (budget - fixed) / ((n - 1) * 32);
     if (const char *ov = getenv("GPH_LR_PSCR")) Pscr = atoi(ov) < Pscr ? atoi(ov) : Pscr;   /* tests: force the global-scratch path */
     if (Pscr > Pmax) Pscr = Pmax;
@@ -987,7 +988,8 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     // behind the scratch: the reference locus's compiled program (one 16-byte entry per step and lane) and edge probabilities
     e->lr.o_prog = fixed + (n - 1) * Pscr * 32;
     e->lr.o_pe = e->lr.o_prog + (n - 1) * GPH_WAVE * 16;
-    e->lr_lds_bytes = e->lr.o_pe + align_up(N * 8, 16);
+    e->lr.o_lf = lfb ? e->lr.o_pe + align_up(N * 8, 16) : 0;
+    e->lr_lds_bytes = e->lr.o_pe + align_up(N * 8, 16) + lfb;
     e->lr.ref_seq_bytes = GPH_Q_BYTES(Pr, n);
     rc |= dev_alloc((void **)&e->d_lrec, sizeof(GphLrRec) * e->L);
     rc |= dev_alloc((void **)&e->d_lpre, sizeof(GphLrPre) * e->L);

@@ -700,6 +700,7 @@ struct GphLrArgs {
   double finetune, alpha, dataLnL, logL, rateVar;
   int32_t o_gnd, o_rnd, o_rseq, o_scr, Pscr, o_prog;   // dynamic-LDS byte offsets; loci with P <= Pscr use LDS scratch
   int32_t o_pe, first;                                 // o_prog / o_pe: compiled program and edge probabilities of the reference locus; first = first local locus that proposes
+  int32_t o_lf, pad0;                                  // o_lf: the reference locus's leaves as conditional arrays [n][P][4] (0 = no room: generic evaluator)
   // the reference locus as this rank sees it: its node records / scalars (page layout), its sequence block, and the
   // rate / likelihood it has after the loci scanned before this rank's block
   const char *ref_page, *ref_seq;
@@ -779,7 +780,7 @@ GPH_DEVHOT void lr_ref_compile(const GphLrArgs &A, int P, GphRefProg &R)
 {
   const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
   R.T = 0; R.dt = 0.0; R.father = -1;
-  if (P < 1 || P > GPH_WAVE) return;
+  if (P < 1 || P > GPH_WAVE || A.o_lf == 0) return;
   const int S = GPH_WAVE / P;
   typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
   union { gu32x4 v; GphNode nd; } nu;
@@ -818,18 +819,30 @@ GPH_DEVHOT void lr_ref_compile(const GphLrArgs &A, int P, GphRefProg &R)
   }
   const int T = t + 1;
   GPH_SYNC();
-  /* the table: T x 64 entries {left, right, own, child ids}; left / right = byte offset of an internal child's
-   * four conditionals of this pattern in the scratch, or -1 - code for a leaf child; own < 0 = idle lane */
-  GPH_LDS gph_i4 *prog = (GPH_LDS gph_i4 *)(GPH_SMB + A.o_prog);
-  for (int i = lane; i < T * GPH_WAVE; i += GPH_NLANES) { gph_i4 e = {-5, -5, -1, 0}; prog[i] = e; }
-  GPH_SYNC();
+  /* the leaves as conditional arrays, the way the reference keeps them (computeLeafConditionals,
+   * LocusDataLikelihood.c:1321): one-hot, or all ones for N.  With S = 1 exactly the internal-child formula
+   * S*pe + s*qe gives pe + qe / pe, bit for bit what the leaf shortcut of child_factor4 gives; N has S = 4 -> 1.0 */
   const int q_leaf = A.o_rseq + GPH_Q_LEAF;
+  for (int i = lane; i < n * P; i += GPH_NLANES) {
+    const int leaf = i / P, pat = i - leaf * P;
+    const int code = gu8v(q_leaf, pat * n + leaf);
+    ld2 *o2 = (ld2 *)(GPH_SMB + A.o_lf + i * 32);
+    gph_d2 a = {code == 4 || code == 0 ? 1.0 : 0.0, code == 4 || code == 1 ? 1.0 : 0.0};
+    gph_d2 b = {code == 4 || code == 2 ? 1.0 : 0.0, code == 4 || code == 3 ? 1.0 : 0.0};
+    o2[0] = a;
+    o2[1] = b;
+  }
+  /* the table: T x 64 entries {left, right, own, child ids}; left / right = dynamic-LDS byte offset of the child's four
+   * conditionals of this pattern (scratch for an internal child, leaf array for a leaf); own < 0 = idle lane */
+  GPH_LDS gph_i4 *prog = (GPH_LDS gph_i4 *)(GPH_SMB + A.o_prog);
+  for (int i = lane; i < T * GPH_WAVE; i += GPH_NLANES) { gph_i4 e = {A.o_lf, A.o_lf, -1, 0}; prog[i] = e; }
+  GPH_SYNC();
   for (int pat = 0; pat < P; pat++) {
     if (isint) {
       gph_i4 e;
-      e.x = le < n ? -1 - gu8v(q_leaf, pat * n + le) : ((le - n) * P + pat) * 32;
-      e.y = ri < n ? -1 - gu8v(q_leaf, pat * n + ri) : ((ri - n) * P + pat) * 32;
-      e.z = ((lane - n) * P + pat) * 32;
+      e.x = le < n ? A.o_lf + (le * P + pat) * 32 : A.o_scr + ((le - n) * P + pat) * 32;
+      e.y = ri < n ? A.o_lf + (ri * P + pat) * 32 : A.o_scr + ((ri - n) * P + pat) * 32;
+      e.z = A.o_scr + ((lane - n) * P + pat) * 32;
       e.w = le | (ri << 8);
       prog[mystep * GPH_WAVE + myslot * P + pat] = e;
     }
@@ -838,31 +851,21 @@ GPH_DEVHOT void lr_ref_compile(const GphLrArgs &A, int P, GphRefProg &R)
   R.T = T;
 }
 
-GPH_DEVHOT void lr_ref_factors(int a, double pe, double qe, int o_scr, double &f0, double &f1, double &f2, double &f3)
+GPH_DEVHOT void lr_ref_factors(int a, double pe, double qe, double &f0, double &f1, double &f2, double &f3)
 {
-  if (a < 0) {
-    const int code = -1 - a;
-    const double hit = pe + qe;
-    const double other = code == 4 ? 1.0 : pe;
-    f0 = code == 0 ? hit : other;
-    f1 = code == 1 ? hit : other;
-    f2 = code == 2 ? hit : other;
-    f3 = code == 3 ? hit : other;
-  } else {
-    const ld2 *c2 = (const ld2 *)(GPH_SMB + o_scr + a);
-    const gph_d2 u = c2[0], v = c2[1];
-    const double s0 = u.x, s1 = u.y, s2 = v.x, s3 = v.y;
-    double S = s0;
-    S += s1;
-    S += s2;
-    S += s3;
-    const double Sp = S * pe;
-    const bool miss = S >= 4;
-    f0 = miss ? 1.0 : (Sp + s0 * qe);
-    f1 = miss ? 1.0 : (Sp + s1 * qe);
-    f2 = miss ? 1.0 : (Sp + s2 * qe);
-    f3 = miss ? 1.0 : (Sp + s3 * qe);
-  }
+  const ld2 *c2 = (const ld2 *)(GPH_SMB + a);
+  const gph_d2 u = c2[0], v = c2[1];
+  const double s0 = u.x, s1 = u.y, s2 = v.x, s3 = v.y;
+  double S = s0;
+  S += s1;
+  S += s2;
+  S += s3;
+  const double Sp = S * pe;
+  const bool miss = S >= 4;
+  f0 = miss ? 1.0 : (Sp + s0 * qe);
+  f1 = miss ? 1.0 : (Sp + s1 * qe);
+  f2 = miss ? 1.0 : (Sp + s2 * qe);
+  f3 = miss ? 1.0 : (Sp + s3 * qe);
 }
 
 // value of the reference locus at `rate` (== lik_private(o_rnd, o_rseq, P, root, rate, ...) bit for bit)
@@ -893,14 +896,14 @@ GPH_DEVHOT double lr_ref_eval(const GphLrArgs &A, const GphRefProg &R, int P, do
     const double ql = 1 - 4.0 * pl;
     const double qr = 1 - 4.0 * pr;
     double f0, f1, f2, f3, g0, g1, g2, g3;
-    lr_ref_factors(e.x, pl, ql, A.o_scr, f0, f1, f2, f3);
-    lr_ref_factors(e.y, pr, qr, A.o_scr, g0, g1, g2, g3);
+    lr_ref_factors(e.x, pl, ql, f0, f1, f2, f3);
+    lr_ref_factors(e.y, pr, qr, g0, g1, g2, g3);
     q0 = f0 * g0;
     q1 = f1 * g1;
     q2 = f2 * g2;
     q3 = f3 * g3;
     if (e.z >= 0) {
-      ld2 *o2 = (ld2 *)(GPH_SMB + A.o_scr + e.z);
+      ld2 *o2 = (ld2 *)(GPH_SMB + e.z);
       gph_d2 a = {q0, q1}, b = {q2, q3};
       o2[0] = a;
       o2[1] = b;
@@ -993,7 +996,11 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
 #endif
       const double rnew = l_reflect(cand, 0, rold + rref);
       const double rrefnew = rref + rold - rnew;
-      double lnacc = (A.alpha - 1) * gph_log((rnew * rrefnew) / (rold * rref));
+      /* Dirichlet(alpha) prior ratio; with alpha = 1 and both rates positive and finite the term is a signed zero that
+       * cannot change the decision or any accumulator: the logarithm is skipped */
+      const double prat = (rnew * rrefnew) / (rold * rref);
+      double lnacc = 0.0;
+      if (!(A.alpha == 1.0 && UNI(prat > 0 && prat < 1e300))) lnacc = (A.alpha - 1) * gph_log(prat);
       double lnLd = -(likold + likref);
       const bool hit = UNI(rnew == rspec);
       double lg;
