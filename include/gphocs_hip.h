@@ -63,7 +63,8 @@ typedef struct {
 } gph_config;
 
 /* cross-rank reduction hook (one process per GPU): sums[0..nsum) are summed, mins[0..nmin)
- * minimised, in place, over all ranks.  NULL = single rank. */
+ * minimised, in place, over all ranks.  NULL = single rank.  nsum + nmin <= 9 + 2K + 2B (<= 57 with the
+ * largest compiled capacities): one call per global proposal, six per MCMC iteration. */
 typedef int (*gph_allreduce_fn)(void *user, double *sums, int32_t nsum, double *mins, int32_t nmin);
 
 typedef struct {
