@@ -1,0 +1,122 @@
+"""GPU parity at BASELINE.json's FULL size (-m gpu): the benchmark workload itself -- configs[3], 100 000 loci x
+1 kb, 16 leaves, 9 populations, 4 migration bands, the exact synthetic data `bench.py` times -- through the C ABI.
+
+ (a) directly against the oracle restatement run live on all 100 000 loci for the first iterations (the oracle
+     needs seconds per iteration at this size, so the trajectory is short; every proposal type, two checkAll
+     resynchronisations): accept counters of every proposal exact, accumulators within 1e-10 relative;
+ (b) size-independent properties on a longer trajectory: run-to-run determinism (byte-identical records), the
+     reference's own invariant check (`checkAll`, patch.c:2745: incremental statistics, log-likelihoods and
+     conditionals against a from-scratch recomputation of every locus) passing at every log period, and
+     shard invariance -- the same chain with the loci split over two ranks (two processes on this GPU, exchanging
+     only the reduced vectors) takes identical decisions."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+from parity_util import compare_records
+
+pytestmark = pytest.mark.gpu
+
+L_FULL = 100000
+CACHE = os.path.join(REPO, "bench_cache")
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import gphocs_amd as G
+    G.build()
+    return G
+
+
+def _workload(G, samples_per_log):
+    import bench
+    pk = bench.build_workload(G, 4, L_FULL, 6.5, 20261002 + 4, CACHE)   # bench.py's default data set
+    pk.samplesPerLog = samples_per_log
+    return pk
+
+
+def _run(G, pk, iters, path):
+    s = G.Sampler(pk)
+    s.set_record_file(path)
+    s.initialize()
+    for it in range(iters):
+        s.iteration(it)
+    s.set_record_file(None)
+    cnt, acc = s.counters(), s.accept_counts()
+    s.close()
+    return cnt, acc
+
+
+def test_full_size_against_live_oracle(G, oracle_cli, tmp_path):
+    from gphocs_amd_pkg import synth
+    iters = 8
+    pk = _workload(G, 4)            # checkAll (and its accumulator resynchronisation) after iterations 3 and 7
+    assert pk.L == L_FULL and pk.n == 16 and pk.K == 9 and pk.B == 4
+    pth = str(tmp_path / "full.gpk")
+    synth.write_pack(pk, pth)
+    mine, theirs = str(tmp_path / "hip.rec"), str(tmp_path / "oracle.rec")
+    cnt, _ = _run(G, pk, iters, mine)
+    subprocess.run([oracle_cli, "run", pth, str(iters), theirs], check=True, timeout=1500)
+    worst = compare_records(mine, theirs)
+    assert any(l.startswith(f"IT {iters - 1} CHECK") for l in open(mine).read().splitlines())
+    assert cnt["evals"] > 45 * L_FULL * iters
+    print(f"full size: {L_FULL} loci x {iters} iterations, {cnt['evals']} evaluations, worst accumulator rel diff "
+          f"{worst:.3e}")
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(repo)r)
+import numpy as np, torch, torch.distributed as dist
+import gphocs_amd as G, bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+def allreduce(sums, mins):
+    if sums.size:
+        t = torch.from_numpy(sums); dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if mins.size:
+        t = torch.from_numpy(mins); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+pk = bench.build_workload(G, 4, %(L)d, 6.5, 20261006, %(cache)r)
+pk.samplesPerLog = %(spl)d
+s = G.Sampler(pk, device=0, rank=rank, world=world, allreduce=allreduce)
+s.set_record_file(%(out)r + ".%%d" %% rank)
+s.initialize()
+for it in range(%(iters)d):
+    s.iteration(it)
+s.set_record_file(None)
+s.close()
+dist.destroy_process_group()
+'''
+
+
+def test_full_size_determinism_checkall_and_shard_invariance(G, tmp_path):
+    iters, spl = 24, 6
+    pk = _workload(G, spl)
+    a, b = str(tmp_path / "a.rec"), str(tmp_path / "b.rec")
+    cnt_a, acc_a = _run(G, pk, iters, a)
+    cnt_b, acc_b = _run(G, pk, iters, b)
+    ra = open(a).read()
+    assert ra == open(b).read(), "two runs of the same chain differ"
+    assert cnt_a == cnt_b and acc_a == acc_b
+    lines = ra.splitlines()
+    # checkAll ran (and passed: a failure aborts the iteration with an error status) at every log period
+    assert sum(1 for l in lines if " CHECK " in l) == iters // spl
+    # every proposal class was exercised and accepted somewhere along the trajectory (0 node ages, 1 migration-event
+    # ages, 2 SPR, 3 theta, 4 migration rates, 5 tau, 6 mixing; 7 = migration events proposed on)
+    assert all(acc_a[i] > 0 for i in (0, 1, 2, 3, 4, 5, 6, 7)), acc_a
+    # the same chain over two ranks (contiguous shards of 50 000 loci, one process each, both on cuda:0)
+    out = str(tmp_path / "rk")
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % dict(repo=REPO, L=L_FULL, cache=CACHE, spl=spl, out=out, iters=iters))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    assert open(out + ".0").read() == open(out + ".1").read()
+    worst = compare_records(out + ".0", a)
+    print(f"full size: {iters} iterations deterministic; two ranks vs one: worst accumulator rel diff {worst:.3e}")
