@@ -563,7 +563,7 @@ GPH_DEV void kb_tau_eval(const GphDev &D, int g, const GphTauArgs &A)
       dGen += gd;
       if (A.mode || n1_0 + n1_1) {     /* UpdateSampleAge always re-evaluates (GPhoCS.c:4431) */
         dData -= FS(FS_DATALNL);
-        dData += lik_compute(1);
+        dData += lik_compute(1, true);
       }
     }
   }

@@ -602,12 +602,15 @@ GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1,
   S += s1;
   S += s2;
   S += s3;
-  const double Sp = S * pe;
   const bool miss = S >= 4;
-  f0 = miss ? 1.0 : (Sp + s0 * qe);
-  f1 = miss ? 1.0 : (Sp + s1 * qe);
-  f2 = miss ? 1.0 : (Sp + s2 * qe);
-  f3 = miss ? 1.0 : (Sp + s3 * qe);
+  /* the skip of LocusDataLikelihood.c:1660-1663 as two selects instead of four: 1.0 + s*0.0 == 1.0 exactly
+   * (conditionals are finite and non-negative) */
+  const double Sp = miss ? 1.0 : S * pe;
+  const double qm = miss ? 0.0 : qe;
+  f0 = Sp + s0 * qm;
+  f1 = Sp + s1 * qm;
+  f2 = Sp + s2 * qm;
+  f3 = Sp + s3 * qm;
 }
 
 // recompute node `node`; on entry q* hold node `prev`'s conditionals (prev < 0: nothing), on exit
@@ -650,7 +653,7 @@ GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo,
 // nodes are processed as soon as their recomputed children are done (any such order gives
 // bit-identical conditionals), copyNodeConditionals bookkeeping is applied to the masks and
 // written back once, and the per-pattern terms are added in pattern order through v_readlane.
-GPH_DEVHOT double lik_compute(int useOld)
+GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
 {
   const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
   useOld = RFL(useOld);
@@ -706,6 +709,21 @@ GPH_DEVHOT double lik_compute(int useOld)
   const int fal = me.father;
   /* conditionals written by an earlier evaluation of this wave must have landed before they are re-read */
   GPH_WAVE_FENCE();
+  if (warm && !wide) {
+    /* a kernel that evaluates ONE proposal per locus finds the conditionals it reads (the children of recomputed
+     * nodes that are not recomputed themselves) cold in HBM, one dependent miss per node of the path.  Touch
+     * them all with a single load first -- 8 lanes per array, one 128-byte line each -- so the misses overlap. */
+    uint64_t sm = __ballot(isnode && lane >= n && !((todo >> lane) & 1) && fal >= 0 && ((todo >> fal) & 1));
+    const int last = 32 * P - 8, mine = (lane & 7) * 128;
+    int off = -1;
+    for (int j = 0; sm != 0 && j < 8; j++) {
+      const int sn = __builtin_ctzll(sm);
+      sm &= sm - 1;
+      const int c = __builtin_amdgcn_readlane(coff, sn);
+      if ((lane >> 3) == j && mine < last + 128) off = c * 8 + (mine < last ? mine : last);
+    }
+    if (off >= 0) (void)*(const volatile GPH_GLB int *)((const GPH_GLB char *)cb + off);
+  }
   STAMPB_END(2);
   for (int guard = 0; todo != 0; guard++) {
     if (wide) {
@@ -830,9 +848,10 @@ GPH_DEVHOT double lik_compute(int useOld)
 // computeConditionalJC_new (:1559-1636) replaced by: mark the ancestors of every
 // dirty node, list the marked internal nodes parent-before-child, process the
 // list backwards.  Same set of recomputed nodes, children always before parents.
-GPH_DEVHOT double lik_compute(int useOld)
+GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
 {
   const int n = g_lay.n, N = g_lay.N;
+  (void)warm;
   useOld = RFL(useOld);
   int P = CNT(CN_P), i, node, k, sp, nord, ncc, U;
   uint64_t need = 0;

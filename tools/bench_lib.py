@@ -21,5 +21,7 @@ for it in range(3, 11):
 dt = time.perf_counter() - t0
 c = s.counters()
 sw = s.class_stats(0)
-print(f"{sys.argv[1]}: {c['evals']/dt/1e6:.1f} M evals/s, {8/dt:.2f} it/s, sweep {sw['ms']/sw['launches']:.2f} ms")
+te, me = s.class_stats(1), s.class_stats(2)
+print(f"{sys.argv[1]}: {c['evals']/dt/1e6:.1f} M evals/s, {8/dt:.2f} it/s, sweep {sw['ms']/sw['launches']:.2f} ms, "
+      f"tau_eval {te['ms']/max(te['launches'],1):.3f} ms x{te['launches']/8:.0f}, mix_eval {me['ms']/max(me['launches'],1):.3f} ms")
 s.close()
