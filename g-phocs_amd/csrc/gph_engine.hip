@@ -34,18 +34,18 @@ GphModel g_model;
 #endif
 
 // j0 = first slot of the launch group (see GphDev)
-GPH_KERNEL(k_init, GphKargs KA, GphDev D, int j0, uint32_t seedz, const double *mutRate, int preDraws) { kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0, preDraws); }
-GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphKargs KA, GphDev D, int j0, int flags, double ftCoal, double ftMig) { kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
-GPH_KERNEL(k_tau_eval, GphKargs KA, GphDev D, int j0, GphTauArgs A) { kb_tau_eval(D, j0 + GPH_BLK, A); }
-GPH_KERNEL(k_tau_commit, GphKargs KA, GphDev D, int j0, GphTauArgs A) { kb_tau_commit(D, j0 + GPH_BLK, A); }
-GPH_KERNEL(k_tau_revert, GphKargs KA, GphDev D, int j0, long long limit) { kb_tau_revert(D, j0 + GPH_BLK, limit); }
-GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, double c) { kb_mix_eval(D, j0 + GPH_BLK, c); }
-GPH_KERNEL(k_mix_commit, GphKargs KA, GphDev D, int j0, double c, double lnc) { kb_mix_commit(D, j0 + GPH_BLK, c, lnc); }
-GPH_KERNEL(k_sync, GphKargs KA, GphDev D, int j0, int refresh) { kb_sync(D, j0 + GPH_BLK, refresh); }
-GPH_KERNEL(k_check, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; kb_check(D, j0 + GPH_BLK); }
-GPH_KERNEL(k_lrate_prep, GphKargs KA, GphDev D, int j0, double finetune, GphLrPre *pre) { kb_lrate_prep(D, j0 + GPH_BLK, finetune, pre); }
-GPH_KERNEL(k_lrate_scan, GphKargs KA, GphDev D, int j0, GphLrArgs A) { (void)j0; kb_lrate_scan(D, A); }
-GPH_KERNEL(k_lrate_apply, GphKargs KA, GphDev D, int j0, const GphLrRec *rec) { kb_lrate_apply(D, j0 + GPH_BLK, rec); }
+GPH_KERNEL(k_init, GphKargs KA, GphDev D, int j0, uint32_t seedz, const double *mutRate, int preDraws) { GphCtx lx; lx.kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0, preDraws); }
+GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphKargs KA, GphDev D, int j0, int flags, double ftCoal, double ftMig) { GphCtx lx; lx.kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
+GPH_KERNEL(k_tau_eval, GphKargs KA, GphDev D, int j0, GphTauArgs A) { GphCtx lx; lx.kb_tau_eval(D, j0 + GPH_BLK, A); }
+GPH_KERNEL(k_tau_commit, GphKargs KA, GphDev D, int j0, GphTauArgs A) { GphCtx lx; lx.kb_tau_commit(D, j0 + GPH_BLK, A); }
+GPH_KERNEL(k_tau_revert, GphKargs KA, GphDev D, int j0, long long limit) { GphCtx lx; lx.kb_tau_revert(D, j0 + GPH_BLK, limit); }
+GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, double c) { GphCtx lx; lx.kb_mix_eval(D, j0 + GPH_BLK, c); }
+GPH_KERNEL(k_mix_commit, GphKargs KA, GphDev D, int j0, double c, double lnc) { GphCtx lx; lx.kb_mix_commit(D, j0 + GPH_BLK, c, lnc); }
+GPH_KERNEL(k_sync, GphKargs KA, GphDev D, int j0, int refresh) { GphCtx lx; lx.kb_sync(D, j0 + GPH_BLK, refresh); }
+GPH_KERNEL(k_check, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtx lx; lx.kb_check(D, j0 + GPH_BLK); }
+GPH_KERNEL(k_lrate_prep, GphKargs KA, GphDev D, int j0, double finetune, GphLrPre *pre) { GphCtx lx; lx.kb_lrate_prep(D, j0 + GPH_BLK, finetune, pre); }
+GPH_KERNEL(k_lrate_scan, GphKargs KA, GphDev D, int j0, GphLrArgs A) { (void)j0; GphCtx lx; lx.kb_lrate_scan(D, A); }
+GPH_KERNEL(k_lrate_apply, GphKargs KA, GphDev D, int j0, const GphLrRec *rec) { GphCtx lx; lx.kb_lrate_apply(D, j0 + GPH_BLK, rec); }
 
 // ---------------------------------------------------------------- small elementwise / reduction kernels
 #define GPH_RED_BLOCKS 256

@@ -6,7 +6,7 @@
 // (MultiCoreUtils.h:8-21) is the grid here.  Cross-locus `omp atomic`
 // accumulations become per-locus output slots reduced by a fixed-shape tree.
 #pragma once
-#include "gph_locus.h"
+#include "gph_rt.h"
 
 struct GphDev {            // device pointers (passed by value to every kernel)
   char *pages;             // L * page_bytes
@@ -23,6 +23,9 @@ struct GphDev {            // device pointers (passed by value to every kernel)
   int32_t Ltot;            // loci over all devices (dataSetup.numLoci)
   int64_t locus_begin;     // global index of this device's first locus
 };
+
+#include "gph_locus.h"   // opens struct GphCtx; closed at the end of this file
+
 // Loci are stored sorted by their number of phased patterns and launched in buckets of
 // similar P, each bucket with an LDS allocation sized for ITS largest locus: the few
 // pattern-rich loci no longer dictate the occupancy of all the others.
@@ -89,11 +92,13 @@ GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withSeq)
   page_in(pages + (size_t)g * g_lay.page_bytes);
   if (withSeq) copy16_g2l(0, D.seq + D.seq_off[g], (int)(D.seq_off[g + 1] - D.seq_off[g]));
   GPH_SYNC();
+  load_scalars();
   scratch_init(D, g);
 }
 GPH_DEV void stage_out(const GphDev &D, int g, char *pages, int unused)
 {
   (void)unused;
+  flush_scalars();
   GPH_SYNC();
   page_out(pages + (size_t)g * g_lay.page_bytes);
   if (pages == D.pages) {
@@ -1133,3 +1138,7 @@ GPH_DEV void kb_check(const GphDev &D, int g)
   out_common(D, g);
   stage_out(D, g, D.pages, 1);
 }
+};   // struct GphCtx
+using GphLrRec = GphCtx::GphLrRec;
+using GphLrPre = GphCtx::GphLrPre;
+using GphLrArgs = GphCtx::GphLrArgs;

@@ -11,6 +11,24 @@
 #pragma once
 #include "gph_rt.h"
 
+// Everything below (and gph_kernels.h) is the body of ONE struct: the per-locus functions are its members and
+// the wave-uniform INTEGER scalars of the locus -- page scalars (root, list lengths, free-list head, migration
+// count, generator state), evaluation counters and the SPR bookkeeping -- are its data members.  Every member
+// function is inlined into its kernel, the object never leaves registers, and the scalars sit in the lanes of ONE
+// vector register: a read is a v_readlane with a constant lane, a write a v_writelane -- no LDS round trip
+// (~90 cycles plus a v_readfirstlane) every time the chain logic branches on one of them.
+// load_scalars() after the page has been staged in, flush_scalars() before it is staged out.
+struct GphCtx {
+#ifdef GPH_HOSTEMU
+  int32_t r_pad[IS_COUNT + CN_COUNT + SI_COUNT] = {};
+#define GPH_PADGET(i) (r_pad[i])
+#define GPH_PADSET(i, v) (r_pad[i] = (v))
+#else
+  int32_t r_pad = 0;      /* lane i of this vector register holds scalar i */
+#define GPH_PADGET(i) __builtin_amdgcn_readlane(r_pad, (i))
+#define GPH_PADSET(i, v) do { const int pv_ = RFL(v); asm("v_writelane_b32 %0, %1, %2" : "+v"(r_pad) : "s"(pv_), "i"(i)); } while (0)
+#endif
+
 // ---------------------------------------------------------------- accessors
 #define AGE(i) (gph_lds.nd[i].age)
 #define setAGE(i, v) (gph_lds.nd[i].age = (v))
@@ -65,8 +83,8 @@
 #define setNMIGB(b, v) si16(&GphLds::nmig, (b), (v))
 #define RBI(k, i) gi16(&GphLds::rb_i, (k) * GPH_CAP_RB + (i))
 #define setRBI(k, i, v) si16(&GphLds::rb_i, (k) * GPH_CAP_RB + (i), (v))
-#define ISC(k) gi32(&GphLds::iscal, (k))
-#define setISC(k, v) si32(&GphLds::iscal, (k), (v))
+#define ISC(k) GPH_PADGET(k)
+#define setISC(k, v) GPH_PADSET((k), (v))
 #define CBIT(i) gu8(&GphLds::condbit, (i))
 #define setCBIT(i, v) su8(&GphLds::condbit, (i), (v))
 #define DIRTY(i) gu8(&GphLds::dirty, (i))
@@ -84,16 +102,16 @@
 #define setDBANDS(inst, i, v) si16(&GphLds::s_dbands, (inst), (i), (v))
 #define DI(inst, k) RFL(gph_lds.s_di[inst][k])
 #define setDI(inst, k, v) (gph_lds.s_di[inst][k] = (v))
-#define SPRI(k) gi32(&GphLds::s_spri, (k))
-#define setSPRI(k, v) si32(&GphLds::s_spri, (k), (v))
+#define SPRI(k) GPH_PADGET(IS_COUNT + CN_COUNT + (k))
+#define setSPRI(k, v) GPH_PADSET(IS_COUNT + CN_COUNT + (k), (v))
 #define SPRA(k, i) gi16(&GphLds::s_spri16, (k) * GPH_MAX_MIGS + (i))
 #define setSPRA(k, i, v) si16(&GphLds::s_spri16, (k) * GPH_MAX_MIGS + (i), (v))
 #define SPRAGE(i) gf64(&GphLds::s_sprf, (i))
 #define setSPRAGE(i, v) sf64(&GphLds::s_sprf, (i), (v))
 #define SPRLN(r) gf64(&GphLds::s_sprf, GPH_MAX_MIGS + (r))
 #define setSPRLN(r, v) sf64(&GphLds::s_sprf, GPH_MAX_MIGS + (r), (v))
-#define CNT(k) gi32(&GphLds::s_cnt, (k))
-#define setCNT(k, v) si32(&GphLds::s_cnt, (k), (v))
+#define CNT(k) GPH_PADGET(IS_COUNT + (k))
+#define setCNT(k, v) GPH_PADSET(IS_COUNT + (k), (v))
 
 // ordered list of live migration bands (<= 16 entries of 4 bits): the reference keeps
 // int live_mig_bands[MAX_MIG_BANDS] with swap-removal; the order decides which band a
@@ -201,6 +219,24 @@ GPH_DEVHOT GphEvS ld_ev(int ev)
 #endif
 GPH_DEV void gph_fail(int code) { if (CNT(CN_ERROR) == 0) setCNT(CN_ERROR, code); }
 GPH_DEV int gph_failed() { return CNT(CN_ERROR) != 0; }
+GPH_DEV void load_scalars()
+{
+#ifdef GPH_HOSTEMU
+  for (int k = 0; k < IS_COUNT + CN_COUNT + SI_COUNT; k++) r_pad[k] = k < IS_COUNT ? gph_lds.iscal[k] : 0;
+#else
+  const int lane = GPH_LANE;
+  r_pad = lane < IS_COUNT ? gph_lds.iscal[lane] : 0;
+#endif
+}
+GPH_DEV void flush_scalars()
+{
+#ifdef GPH_HOSTEMU
+  for (int k = 0; k < IS_COUNT; k++) gph_lds.iscal[k] = r_pad[k];
+#else
+  const int lane = GPH_LANE;
+  if (lane < IS_COUNT) gph_lds.iscal[lane] = r_pad;
+#endif
+}
 
 // IEEE-exact quotients a / theta[pop] and a / 3 without the ~12-instruction divide expansion: with
 // y = RN(1/b) (computed by a true division, on the host for theta), q0 = a*y, r = fma(-q0, b, a) (exact),

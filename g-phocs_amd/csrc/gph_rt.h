@@ -20,9 +20,9 @@
 
 #ifdef GPH_HOSTEMU
 #include <string.h>
-#define GPH_DEV static inline
+#define GPH_DEV inline
 #define GPH_DEVNI static
-#define GPH_DEVHOT static inline
+#define GPH_DEVHOT inline
 #define GPH_LDS
 #define GPH_LANE 0
 #define GPH_NLANES 1
