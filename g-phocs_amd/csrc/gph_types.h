@@ -92,7 +92,7 @@ struct GphKargs {
 #define GPH_Q_TERMS(P, n) GPH_Q_BYTES(P, n)
 // delta scalars (s_di[inst])
 enum { DI_ORIG = 0, DI_UPD, DI_DLIN, DI_NEV, DI_NPOPS, DI_NBANDS, DI_COUNT };
-// spr scalars (s_spri), i16 arrays (s_spri16 + 10*k), f64 (s_sprf: new_ages[0..9], dlnLd[10..11])
+// spr scalars (register lanes, GphCtx), i16 arrays (s_spri16 + 10*k), f64 (s_sprf: new_ages[0..9], dlnLd[10..11])
 enum { SI_FEV_OLD = 0, SI_FEV_NEW, SI_FPOP_NEW, SI_TARGET, SI_NOLD, SI_NNEW, SI_COUNT };
 enum { SA_OLD = 0, SA_NEWIN, SA_NEWOUT, SA_NEWBAND };
 // counters (s_cnt i32): evals, evalNodes, error, P, U ; (s_cntf f64): evalBytes
@@ -169,7 +169,7 @@ struct alignas(16) GphLds {
 #if defined(GPH_STAMPS) || defined(GPH_HOSTEMU)
   double s_stamp[8];          // diagnostic cycle sums (tools/stamp_breakdown.py); not in production device builds
 #endif
-  int32_t s_di[2][8], s_spri[8], s_cnt[8];
+  int32_t s_di[2][8];   /* the SPR scalars and the counters (SI_*, CN_*) live in register lanes: GphCtx, gph_locus.h */
   uint32_t s_condptr[2];
   int16_t s_dpops[2][GPH_CAP_K], s_dbands[2][GPH_CAP_B], s_spri16[4 * GPH_MAX_MIGS];
   int16_t s_ord[GPH_CAP_N + 1], s_stack[GPH_CAP_N + 1], s_targets[GPH_CAP_N + 1], s_chknc[GPH_CAP_K], s_chknm[GPH_CAP_B];
