@@ -48,7 +48,9 @@ GPH_KERNEL(k_lrate_scan, GphKargs KA, GphDev D, int j0, GphLrArgs A) { (void)j0;
 GPH_KERNEL(k_lrate_apply, GphKargs KA, GphDev D, int j0, const GphLrRec *rec) { GphCtx lx; lx.kb_lrate_apply(D, j0 + GPH_BLK, rec); }
 
 // ---------------------------------------------------------------- small elementwise / reduction kernels
+#ifndef GPH_RED_BLOCKS
 #define GPH_RED_BLOCKS 256
+#endif
 #define GPH_RED_COLS 128   // >= 2K+2B and >= GPH_OUT_SLOTS
 static_assert(2 * GPH_CAP_K + 2 * GPH_CAP_B <= 64 && GPH_OUT_SLOTS <= 64, "the reduction kernels fold at most 64 columns");
 
@@ -76,52 +78,72 @@ __global__ void k_apply_migrate(GphKargs KA, GphDev D, int band, double lnc, dou
   fs[FS_GENLNL] += (lnc * nm - rate_diff * ms);
 }
 // fixed-shape two-level reduction (deterministic run to run): block b owns a contiguous chunk of
-// loci; inside it 8 sub-sequences (g = g0+s, g0+s+8, ...) are summed in index order by 8 thread
-// groups and combined in sub order; the final pass adds the 256 block partials in order.
+// loci; inside it Q = 8 * (64 / column width) sub-sequences (g = g0+q, g0+q+Q, ...) are summed in index
+// order and combined in sub-sequence order; the final pass adds the 256 block partials in a fixed shape.
 // mode 0 = per-locus outputs (GPH_OUT_SLOTS columns), mode 1 = compact statistics (2K+2B columns)
 // part: [3][GPH_RED_BLOCKS][GPH_RED_COLS] (sum, min, max)
 #define GPH_RED_SUBS 8
 __global__ void __launch_bounds__(GPH_RED_SUBS * 64) k_reduce_partial(GphDev D, int mode, int ncols, double *part)
 {
-  __shared__ double sh[3][GPH_RED_SUBS][64];
-  const int col = threadIdx.x & 63, sub = threadIdx.x >> 6, b = blockIdx.x;
+  __shared__ double sh[3][GPH_RED_SUBS * 4][16];
+  /* a wavefront covers 64 / cw loci at a time (cw = columns rounded up to 16, 32 or 64): every lane has work */
+  const int cw = ncols <= 16 ? 16 : ncols <= 32 ? 32 : 64, ng = 64 / cw, Q = GPH_RED_SUBS * ng;
+  const int lane = threadIdx.x & 63, col = lane % cw, q = (threadIdx.x >> 6) * ng + lane / cw, b = blockIdx.x;
   const int chunk = (D.L + GPH_RED_BLOCKS - 1) / GPH_RED_BLOCKS;
   const int g0 = b * chunk, g1 = g0 + chunk < D.L ? g0 + chunk : D.L;
   const double *src = mode == 0 ? D.out : D.stats;
   const int stride = mode == 0 ? GPH_OUT_SLOTS : ncols;
   double s = 0.0, mn = 1e300, mx = -1e300;
   if (col < ncols)
-    for (int g = g0 + sub; g < g1; g += GPH_RED_SUBS) {
+    for (int g = g0 + q; g < g1; g += Q) {
       double v = src[(size_t)g * stride + col];
       s += v;
       mn = v < mn ? v : mn;
       mx = v > mx ? v : mx;
     }
-  sh[0][sub][col] = s; sh[1][sub][col] = mn; sh[2][sub][col] = mx;
-  __syncthreads();
-  if (sub == 0 && col < ncols) {
-    s = 0.0; mn = 1e300; mx = -1e300;
-    for (int k = 0; k < GPH_RED_SUBS; k++) {
-      s += sh[0][k][col];
-      mn = sh[1][k][col] < mn ? sh[1][k][col] : mn;
-      mx = sh[2][k][col] > mx ? sh[2][k][col] : mx;
+  /* combine the Q sub-sequences of a column in sub-sequence order; 16 columns at a time through shared memory */
+  for (int c0 = 0; c0 < ncols; c0 += 16) {
+    __syncthreads();
+    if (col >= c0 && col < c0 + 16) { sh[0][q][col - c0] = s; sh[1][q][col - c0] = mn; sh[2][q][col - c0] = mx; }
+    __syncthreads();
+    if (threadIdx.x < 16 && c0 + (int)threadIdx.x < ncols) {
+      const int c = threadIdx.x;
+      double ts = 0.0, tmn = 1e300, tmx = -1e300;
+      for (int k = 0; k < Q; k++) {
+        ts += sh[0][k][c];
+        tmn = sh[1][k][c] < tmn ? sh[1][k][c] : tmn;
+        tmx = sh[2][k][c] > tmx ? sh[2][k][c] : tmx;
+      }
+      part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + c0 + c] = ts;
+      part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + c0 + c] = tmn;
+      part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + c0 + c] = tmx;
     }
-    part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = s;
-    part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = mn;
-    part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col] = mx;
   }
 }
-__global__ void k_reduce_final(int ncols, const double *part, double *red)
+// final pass: column c's block partials in block order, as GPH_RED_SUBS contiguous runs (one thread each) combined
+// in run order -- a fixed shape, so the result does not depend on scheduling
+__global__ void __launch_bounds__(GPH_RED_SUBS * GPH_RED_COLS) k_reduce_final(int ncols, const double *part, double *red)
 {
-  int col = threadIdx.x;
-  if (col >= ncols) return;
+  __shared__ double sh[3][GPH_RED_SUBS][GPH_RED_COLS];
+  const int col = threadIdx.x % GPH_RED_COLS, sub = threadIdx.x / GPH_RED_COLS;
+  const int per = GPH_RED_BLOCKS / GPH_RED_SUBS;
   double s = 0.0, mn = 1e300, mx = -1e300;
-  for (int b = 0; b < GPH_RED_BLOCKS; b++) {
-    s += part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
-    double v = part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
-    mn = v < mn ? v : mn;
-    v = part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
-    mx = v > mx ? v : mx;
+  if (col < ncols)
+    for (int b = sub * per; b < (sub + 1) * per; b++) {
+      s += part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
+      double v = part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
+      mn = v < mn ? v : mn;
+      v = part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
+      mx = v > mx ? v : mx;
+    }
+  sh[0][sub][col] = s; sh[1][sub][col] = mn; sh[2][sub][col] = mx;
+  __syncthreads();
+  if (sub != 0 || col >= ncols) return;
+  s = 0.0; mn = 1e300; mx = -1e300;
+  for (int k = 0; k < GPH_RED_SUBS; k++) {
+    s += sh[0][k][col];
+    mn = sh[1][k][col] < mn ? sh[1][k][col] : mn;
+    mx = sh[2][k][col] > mx ? sh[2][k][col] : mx;
   }
   red[col] = s;
   red[GPH_RED_COLS + col] = mn;
@@ -328,7 +350,7 @@ static int reduce_local(gph_engine *e, int mode, int ncols)
   return 0;
 #else
   hipLaunchKernelGGL(k_reduce_partial, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_SUBS * 64), 0, e->stream, e->dev, mode, ncols, e->d_part);
-  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(GPH_RED_COLS), 0, e->stream, ncols, e->d_part, e->d_red);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(GPH_RED_SUBS * GPH_RED_COLS), 0, e->stream, ncols, e->d_part, e->d_red);
   HIPCHK(hipGetLastError());
   return d2h(e, e->h_red, e->d_red, sizeof(double) * 3 * GPH_RED_COLS);
 #endif
