@@ -195,8 +195,8 @@ struct gph_engine {
   std::vector<uint64_t> h_seq_off;
   GphLrArgs lr;
   int lr_lds_bytes = 0;
-  double *d_part = nullptr, *d_red = nullptr;
-  double h_red[3 * GPH_RED_COLS];
+  double *d_part = nullptr, *d_red = nullptr;   // d_red: device-side address of h_red
+  double *h_red = nullptr;                       // pinned host memory mapped into the device's address space
   gph_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   uint32_t seedz = 0;
@@ -352,7 +352,8 @@ static int reduce_local(gph_engine *e, int mode, int ncols)
   hipLaunchKernelGGL(k_reduce_partial, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_SUBS * 64), 0, e->stream, e->dev, mode, ncols, e->d_part);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(GPH_RED_SUBS * GPH_RED_COLS), 0, e->stream, ncols, e->d_part, e->d_red);
   HIPCHK(hipGetLastError());
-  return d2h(e, e->h_red, e->d_red, sizeof(double) * 3 * GPH_RED_COLS);
+  HIPCHK(hipStreamSynchronize(e->stream));   /* the final pass wrote h_red through the mapping: no copy to wait for */
+  return 0;
 #endif
 }
 #define RSUM(e, c) ((e)->h_red[(c)])
@@ -478,8 +479,11 @@ void gph_engine_destroy(gph_engine *e)
   dev_free(e->dev.pages); dev_free(e->dev.shadow); dev_free(e->dev.cond); dev_free((void *)e->dev.cond_off);
   dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
   dev_free(e->d_lrec); dev_free(e->d_lpre); dev_free(e->d_slot_of); dev_free(e->d_lr_result); dev_free(e->d_lr_gscr); dev_free(e->d_ref_page); dev_free(e->d_ref_seq);
-  dev_free(e->d_part); dev_free(e->d_red);
-#ifndef GPH_HOSTEMU
+  dev_free(e->d_part);
+#ifdef GPH_HOSTEMU
+  free(e->h_red);
+#else
+  if (e->h_red) (void)hipHostFree(e->h_red);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -580,7 +584,12 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   rc |= dev_alloc((void **)&e->dev.out, sizeof(double) * GPH_OUT_SLOTS * L);
   rc |= dev_alloc((void **)&e->dev.stats, sizeof(double) * (2 * e->cfg.K + 2 * e->cfg.B) * L);
   rc |= dev_alloc((void **)&e->d_part, sizeof(double) * 3 * GPH_RED_BLOCKS * GPH_RED_COLS);
-  rc |= dev_alloc((void **)&e->d_red, sizeof(double) * 3 * GPH_RED_COLS);
+#ifdef GPH_HOSTEMU
+  if (!e->h_red) e->h_red = (double *)calloc(3 * GPH_RED_COLS, sizeof(double));
+#else
+  if (!e->h_red && (hipHostMalloc((void **)&e->h_red, sizeof(double) * 3 * GPH_RED_COLS, hipHostMallocMapped) != hipSuccess ||
+                    hipHostGetDevicePointer((void **)&e->d_red, e->h_red, 0) != hipSuccess)) rc = GPH_EHIP;
+#endif
   if (mutRates) rc |= dev_alloc((void **)&e->d_mutRate, sizeof(double) * L);
   if (rc) { fprintf(stderr, "gphocs_hip: device allocation failed\n"); return GPH_EHIP; }
   rc |= h2d(e, (void *)e->dev.cond_off, e->h_cond_off.data(), sizeof(uint64_t) * (L + 1));
