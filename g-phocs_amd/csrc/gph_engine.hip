@@ -122,8 +122,9 @@ __global__ void __launch_bounds__(GPH_RED_SUBS * 64) k_reduce_partial(GphDev D, 
 }
 // final pass: column c's block partials in block order, as GPH_RED_SUBS contiguous runs (one thread each) combined
 // in run order -- a fixed shape, so the result does not depend on scheduling
-__global__ void __launch_bounds__(GPH_RED_SUBS * GPH_RED_COLS) k_reduce_final(int ncols, const double *part, double *red)
+__global__ void __launch_bounds__(GPH_RED_SUBS * GPH_RED_COLS) k_reduce_final(int ncols, const double *part, double *red, const int32_t *err)
 {
+  if (threadIdx.x == 0) red[3 * GPH_RED_COLS] = (double)*err;
   __shared__ double sh[3][GPH_RED_SUBS][GPH_RED_COLS];
   const int col = threadIdx.x % GPH_RED_COLS, sub = threadIdx.x / GPH_RED_COLS;
   const int per = GPH_RED_BLOCKS / GPH_RED_SUBS;
@@ -212,6 +213,8 @@ struct gph_engine {
 #ifndef GPH_HOSTEMU
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t aev0 = nullptr, aev1 = nullptr;   // bracket the last launch that was NOT followed by a reduction
+  int async_which = -1;                         // its class while the elapsed time has not been read yet
 #else
   std::vector<char> lds;
 #endif
@@ -316,6 +319,33 @@ static int upload_tables(gph_engine *) { return 0; }
     (e)->last_which = (which); (e)->cls_launches[which] += 1; (e)->timing_pending = true; } while (0)   /* elapsed time is read in finish_kernel(), after the result copy has synchronised the stream */
 #endif
 
+// a launch whose per-locus outputs nobody waits for (commit / revert of a global proposal): no reduction, no host
+// synchronisation -- the stream orders it before the next kernel, an error raises the sticky flag D.err that the
+// next reduction reports, and the elapsed time is read at the next synchronisation point
+#ifdef GPH_HOSTEMU
+#define LAUNCH_ASYNC(e, which, name, ...) LAUNCH(e, which, name, __VA_ARGS__)
+static int collect_async_time(gph_engine *) { return 0; }
+#else
+static int collect_async_time(gph_engine *e)
+{
+  if (e->async_which >= 0) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e->aev0, e->aev1) == hipSuccess) { e->last_ms[e->async_which] = ms; e->cls_ms[e->async_which] += ms; }
+    e->async_which = -1;
+  }
+  return 0;
+}
+#define LAUNCH_ASYNC(e, which, name, ...) do { \
+    GphKargs &ka_ = (e)->ka; ka_.model = (e)->model; ka_.lay = (e)->lay; \
+    if ((e)->async_which >= 0) { (void)hipEventSynchronize((e)->aev1); collect_async_time(e); } \
+    HIPCHK(hipEventRecord((e)->aev0, (e)->stream)); \
+    for (auto &bk_ : (e)->buckets) { \
+      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
+      HIPCHK(hipGetLastError()); } \
+    HIPCHK(hipEventRecord((e)->aev1, (e)->stream)); \
+    (e)->async_which = (which); (e)->cls_launches[which] += 1; } while (0)
+#endif
+
 // one single-wave workgroup with its own dynamic-LDS size (the serial scan of UpdateLocusRate)
 #ifdef GPH_HOSTEMU
 #define LAUNCH1(e, which, name, ldsbytes, ...) do { g_model = (e)->model; \
@@ -347,10 +377,11 @@ static int reduce_local(gph_engine *e, int mode, int ncols)
     }
     e->h_red[c] = s; e->h_red[GPH_RED_COLS + c] = mn; e->h_red[2 * GPH_RED_COLS + c] = mx;
   }
+  e->h_red[3 * GPH_RED_COLS] = (double)*e->dev.err;
   return 0;
 #else
   hipLaunchKernelGGL(k_reduce_partial, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_SUBS * 64), 0, e->stream, e->dev, mode, ncols, e->d_part);
-  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(GPH_RED_SUBS * GPH_RED_COLS), 0, e->stream, ncols, e->d_part, e->d_red);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(GPH_RED_SUBS * GPH_RED_COLS), 0, e->stream, ncols, e->d_part, e->d_red, e->dev.err);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));   /* the final pass wrote h_red through the mapping: no copy to wait for */
   return 0;
@@ -365,7 +396,8 @@ static int finish_kernel(gph_engine *e)
   int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
   if (rc) return rc;
 #ifndef GPH_HOSTEMU
-  if (e->timing_pending) {   /* the device-to-host copy above synchronised the stream: both events are complete */
+  collect_async_time(e);
+  if (e->timing_pending) {   /* the reduction above synchronised the stream: both events are complete */
     float ms = 0;
     e->timing_pending = false;
     HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
@@ -380,8 +412,8 @@ static int finish_kernel(gph_engine *e)
   e->cls_evals[e->last_which] += RSUM(e, 8);
   e->cls_nodes[e->last_which] += RSUM(e, 9);
   e->cls_bytes[e->last_which] += RSUM(e, 10);
-  if (RMAX(e, 11) != 0.0) {
-    fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by a locus kernel\n", (int)RMAX(e, 11));
+  if (RMAX(e, 11) != 0.0 || e->h_red[3 * GPH_RED_COLS] != 0.0) {
+    fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by a locus kernel\n", (int)(RMAX(e, 11) != 0.0 ? RMAX(e, 11) : e->h_red[3 * GPH_RED_COLS]));
     return GPH_EKERNEL;
   }
   return 0;
@@ -467,7 +499,8 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
     return GPH_EHIP;
   }
   if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess ||
-      hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) { delete e; return GPH_EHIP; }
+      hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess ||
+      hipEventCreate(&e->aev0) != hipSuccess || hipEventCreate(&e->aev1) != hipSuccess) { delete e; return GPH_EHIP; }
 #endif
   *out = e;
   return 0;
@@ -479,13 +512,15 @@ void gph_engine_destroy(gph_engine *e)
   dev_free(e->dev.pages); dev_free(e->dev.shadow); dev_free(e->dev.cond); dev_free((void *)e->dev.cond_off);
   dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
   dev_free(e->d_lrec); dev_free(e->d_lpre); dev_free(e->d_slot_of); dev_free(e->d_lr_result); dev_free(e->d_lr_gscr); dev_free(e->d_ref_page); dev_free(e->d_ref_seq);
-  dev_free(e->d_part);
+  dev_free(e->d_part); dev_free(e->dev.err);
 #ifdef GPH_HOSTEMU
   free(e->h_red);
 #else
   if (e->h_red) (void)hipHostFree(e->h_red);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->aev0) (void)hipEventDestroy(e->aev0);
+  if (e->aev1) (void)hipEventDestroy(e->aev1);
   if (e->stream) (void)hipStreamDestroy(e->stream);
 #endif
   delete e;
@@ -584,10 +619,16 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   rc |= dev_alloc((void **)&e->dev.out, sizeof(double) * GPH_OUT_SLOTS * L);
   rc |= dev_alloc((void **)&e->dev.stats, sizeof(double) * (2 * e->cfg.K + 2 * e->cfg.B) * L);
   rc |= dev_alloc((void **)&e->d_part, sizeof(double) * 3 * GPH_RED_BLOCKS * GPH_RED_COLS);
+  rc |= dev_alloc((void **)&e->dev.err, sizeof(int32_t));
 #ifdef GPH_HOSTEMU
-  if (!e->h_red) e->h_red = (double *)calloc(3 * GPH_RED_COLS, sizeof(double));
+  if (e->dev.err) *e->dev.err = 0;
 #else
-  if (!e->h_red && (hipHostMalloc((void **)&e->h_red, sizeof(double) * 3 * GPH_RED_COLS, hipHostMallocMapped) != hipSuccess ||
+  if (!rc && hipMemset(e->dev.err, 0, sizeof(int32_t)) != hipSuccess) rc = GPH_EHIP;
+#endif
+#ifdef GPH_HOSTEMU
+  if (!e->h_red) e->h_red = (double *)calloc(3 * GPH_RED_COLS + 1, sizeof(double));
+#else
+  if (!e->h_red && (hipHostMalloc((void **)&e->h_red, sizeof(double) * (3 * GPH_RED_COLS + 1), hipHostMallocMapped) != hipSuccess ||
                     hipHostGetDevicePointer((void **)&e->d_red, e->h_red, 0) != hipSuccess)) rc = GPH_EHIP;
 #endif
   if (mutRates) rc |= dev_alloc((void **)&e->d_mutRate, sizeof(double) * L);
@@ -712,22 +753,17 @@ int gph_engine_tau_commit(gph_engine *e)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
   e->totals_valid = false;
-  LAUNCH(e, 5, k_tau_commit, e->tau);
-  return finish_kernel(e);
+  LAUNCH_ASYNC(e, 5, k_tau_commit, e->tau);
+  return 0;
 }
 
 int gph_engine_tau_revert(gph_engine *e, int64_t first_conflict)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
   long long limit = first_conflict >= 0 ? (long long)first_conflict : (long long)1 << 62;
-#ifdef GPH_HOSTEMU
-  for (int64_t g = 0; g < e->L; g++) for (int k = 0; k < GPH_OUT_SLOTS; k++) e->dev.out[g * GPH_OUT_SLOTS + k] = 0;
-#else
-  HIPCHK(hipMemsetAsync(e->dev.out, 0, sizeof(double) * GPH_OUT_SLOTS * e->L, e->stream));
-#endif
   e->totals_valid = false;
-  LAUNCH(e, 6, k_tau_revert, limit);
-  return finish_kernel(e);
+  LAUNCH_ASYNC(e, 6, k_tau_revert, limit);
+  return 0;
 }
 
 int gph_engine_mixing_evaluate(gph_engine *e, double c, double *dataDelta)
@@ -747,8 +783,8 @@ int gph_engine_mixing_commit(gph_engine *e, double c, double lnc)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
   e->totals_valid = false;
-  LAUNCH(e, 7, k_mix_commit, c, lnc);
-  return finish_kernel(e);
+  LAUNCH_ASYNC(e, 7, k_mix_commit, c, lnc);
+  return 0;
 }
 
 // mixing reject (GPhoCS.c:4881-4887): revertToSaved restores every locus exactly, and

@@ -22,6 +22,7 @@ struct GphDev {            // device pointers (passed by value to every kernel)
   int32_t L;               // loci on this device
   int32_t Ltot;            // loci over all devices (dataSetup.numLoci)
   int64_t locus_begin;     // global index of this device's first locus
+  int32_t *err;            // sticky error code of the kernels that are not followed by a reduction (commit / revert)
 };
 
 #include "gph_locus.h"   // opens struct GphCtx; closed at the end of this file
@@ -123,6 +124,13 @@ GPH_DEV void out_common(const GphDev &D, int g)
     o[10] = gf64(&GphLds::s_cntf, 0);
     o[11] = CNT(CN_ERROR);
     o[13] = CNT(CN_NOTENOUGH);
+    if (CNT(CN_ERROR) != 0) {
+#ifdef GPH_HOSTEMU
+      if (*D.err == 0) *D.err = CNT(CN_ERROR);
+#else
+      atomicMax(D.err, CNT(CN_ERROR));
+#endif
+    }
   }
 }
 #define OUT(g, k, v) do { if (GPH_LANE == 0) D.out[(size_t)(g) * GPH_OUT_SLOTS + (k)] = (v); } while (0)
