@@ -72,29 +72,62 @@ GPH_DEV void page_out(char *page)
 #endif
 }
 
-GPH_DEV void scratch_init(const GphDev &D, int g)
+GPH_DEV void scratch_init(const GphDev &D, int g, int P, uint64_t cond_off)
 {
   int k;
   for (k = 0; k < CN_COUNT; k++) setCNT(k, 0);
-  setCNT(CN_P, D.P[g]);
+  setCNT(CN_P, P);
   sf64(&GphLds::s_cntf, 0, 0.0);
 #if defined(GPH_STAMPS) || defined(GPH_HOSTEMU)
   for (k = 0; k < 8; k++) gph_lds.s_stamp[k] = 0.0;
 #endif
-  set_cond_base(D.cond + D.cond_off[g]);
+  set_cond_base(D.cond + cond_off);
   delta_clear(0);
   delta_clear(1);
 }
 
 // load page (+ optionally the read-only sequence block: leaf codes, phases, counts).
 // Conditionals are never staged: kernels read/write them in place (see cond_base()).
+// All global loads of the stage-in are ISSUED before the first one is waited for: the generic copy loops
+// (load 1 KB, wait, write LDS, repeat) serialised 5-7 memory round trips at the head of every wavefront, a quarter
+// of the lifetime of a wavefront of the short kernels (tau / mixing evaluate, commit).
 GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withSeq)
 {
+#ifdef GPH_HOSTEMU
+  const int P_ = D.P[g];
+  const uint64_t co_ = D.cond_off[g];
   page_in(pages + (size_t)g * g_lay.page_bytes);
   if (withSeq) copy16_g2l(0, D.seq + D.seq_off[g], (int)(D.seq_off[g + 1] - D.seq_off[g]));
+#else
+  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
+  typedef GPH_LDS gu32x4 luint4;
+  constexpr int PCH = (int)((offsetof(GphLds, s_dcoal) + 1023) / 1024);   /* 1 KB chunks of the page part */
+  constexpr int SCH = 2;                                                   /* first 2 KB of the sequence block */
+  const int lane = GPH_LANE;
+  const gu32x4 *ps = (const gu32x4 *)(pages + (size_t)g * g_lay.page_bytes);
+  const int pn = g_lay.page_bytes >> 4;
+  uint64_t o0 = 0, o1 = 0;
+  if (withSeq) { o0 = D.seq_off[g]; o1 = D.seq_off[g + 1]; }
+  const int P_ = D.P[g];                   /* per-locus table entries: scalar loads, in flight with everything else */
+  const uint64_t co_ = D.cond_off[g];
+  gu32x4 pr[PCH], sr[SCH];
+#pragma unroll
+  for (int k = 0; k < PCH; k++) if (lane + 64 * k < pn) pr[k] = ps[lane + 64 * k];
+  const gu32x4 *ss = (const gu32x4 *)(D.seq + o0);
+  const int sn = (int)(o1 - o0) >> 4;
+#pragma unroll
+  for (int k = 0; k < SCH; k++) if (lane + 64 * k < sn) sr[k] = ss[lane + 64 * k];
+  luint4 *pd = (luint4 *)&gph_lds;
+#pragma unroll
+  for (int k = 0; k < PCH; k++) if (lane + 64 * k < pn) pd[lane + 64 * k] = pr[k];
+  luint4 *sd = (luint4 *)(GPH_SMB);
+#pragma unroll
+  for (int k = 0; k < SCH; k++) if (lane + 64 * k < sn) sd[lane + 64 * k] = sr[k];
+  for (int i = lane + 64 * SCH; i < sn; i += GPH_NLANES) sd[i] = ss[i];   /* pattern-rich loci */
+#endif
   GPH_SYNC();
   load_scalars();
-  scratch_init(D, g);
+  scratch_init(D, g, P_, co_);
 }
 GPH_DEV void stage_out(const GphDev &D, int g, char *pages, int unused)
 {
@@ -201,7 +234,7 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate, int
   for (i = GPH_LANE; i < (int)(sizeof(GphLds) / 4); i += GPH_NLANES) ((GPH_LDS int32_t *)&gph_lds)[i] = 0;
   copy16_g2l(0, D.seq + D.seq_off[g], (int)(D.seq_off[g + 1] - D.seq_off[g]));
   GPH_SYNC();
-  scratch_init(D, g);
+  scratch_init(D, g, D.P[g], D.cond_off[g]);
   setISC(IS_RX, 11);
   setISC(IS_RY, 23);
   setISC(IS_RZ, (int)seedz);
