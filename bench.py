@@ -10,9 +10,10 @@ step      = one MCMC iteration of performMCMC's proposal sequence (GPhoCS.c:1476
 workload  = BASELINE.json configs[3], the one the metric is quoted on: 100k loci x 1 kb, 8 diploid
             samples (16 leaves), 5 current populations + 4 migration bands; synthetic data
             (g-phocs_amd/synth.py), resident in HBM before the timed region.
-scaling   = weak: every rank holds --loci loci (default 100k); whole-job value = all ranks' units
-            / max-over-ranks time.  Ranks share nothing but the <= 240-byte all-reduce (RCCL) of
-            each global proposal.
+scaling   = strong (default): ONE --loci-locus data set (100k) sharded over the ranks in contiguous blocks, the
+            reference's `-n threads` over a fixed numLoci (GPhoCS.c:116-145, MultiCoreUtils.h:8); --weak: --loci
+            loci on every rank.  whole-job value = all ranks' units / max-over-ranks time.  Ranks share nothing but
+            the reduced row (RCCL all-gather on the engine's stream) of each reduction point.
 value     = locus-likelihood evaluations per second (computeLocusDataLikelihood(useOld=1)
             equivalents, counted by the kernels); MCMC iterations/s is reported next to it.
 roofline  = dominant kernel (fused genealogy sweep): algorithmic bytes (96*R*P + 20*N + 8*U + 8 per
@@ -147,9 +148,9 @@ def cpu_baseline_reference(config, pack, nloci, iters):
             try:
                 r2 = json.loads(subprocess.run([ref_omp, "time", "s.ctl", str(iters), "2"], cwd=td, check=True, env=env,
                                                capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1])
-                out["openmp_all_cores"] = {"value": r2["evals_per_s"], "cores": nc, "seconds": r2["seconds"]}
+                out["openmp_8_threads"] = {"value": r2["evals_per_s"], "cores": nc, "seconds": r2["seconds"]}
             except Exception as ex:  # pragma: no cover
-                out["openmp_all_cores"] = {"error": str(ex)}
+                out["openmp_8_threads"] = {"error": str(ex)}
     return out
 
 
@@ -178,17 +179,48 @@ def cpu_baseline(G, pack, nloci, iters):
             "iters_per_s_at_sample": r["iters_per_s"]}
 
 
+def shard_of(L_total, rank, world):
+    """contiguous block of ceil(L/world) loci (OpenMP static scheduling of the reference, MultiCoreUtils.h:8)"""
+    per = (L_total + world - 1) // world
+    return min(rank * per, L_total), min((rank + 1) * per, L_total)
+
+
+def build_shard(G, config, L_total, begin, end, mut_scale, seed0, cache_dir):
+    """loci [begin, end) of the L_total-locus synthetic data set: the 4000-locus generator chunks that overlap the
+    block are generated (or read from the cache) and sliced -- every rank sees the same data set whatever the rank count"""
+    chunk = 4000
+    c0, c1 = begin // chunk, (end - 1) // chunk
+    lo = c0 * chunk
+    hi = min((c1 + 1) * chunk, L_total)
+    pk = build_workload(G, config, hi - lo, mut_scale, seed0, cache_dir, begin=lo, L_total=L_total)
+    a, b = begin - lo, end - lo
+    o0, o1 = int(pk.pattern_offsets[a]), int(pk.pattern_offsets[b])
+    pk.pattern_offsets = (pk.pattern_offsets[a:b + 1] - o0).astype(np.int64)
+    pk.leafcodes, pk.numPhases, pk.counts = pk.leafcodes[o0:o1], pk.numPhases[o0:o1], pk.counts[o0:o1]
+    pk.L = pk.numLoci = end - begin
+    pk.mutRates = np.ones(pk.L)
+    pk.global_L, pk.global_begin = L_total, begin
+    return pk
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--loci", type=int, default=100000, help="loci per GPU")
+    ap.add_argument("--loci", type=int, default=100000, help="loci of the data set (strong scaling: sharded over the "
+                    "ranks; with --weak: per GPU)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --loci loci on every rank")
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--mut-scale", type=float, default=6.5, help="mutation scale of the synthetic data (P ~ 18)")
+    ap.add_argument("--preroll", type=int, default=200, help="untimed iterations before the warm-up (SURVEY 8d: measure "
+                    "after 200 iterations from the prior-sampled start)")
+    ap.add_argument("--samples-per-log", type=int, default=0, help="checkAll period (0 = the pack's: 100)")
     ap.add_argument("--cpu-loci", type=int, default=5000)
     ap.add_argument("--cpu-iters", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "hook"], help="cross-rank exchange: native RCCL all-gather on "
+                    "the engine's stream (default) or the torch.distributed hook (a host round trip per reduction)")
     a = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): anything native libraries print there (RCCL's version banner,
@@ -205,116 +237,171 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     allreduce = None
+    comm = None
+    ncoll = [0]
     force_dist = os.environ.get("GPH_BENCH_FORCE_DIST") == "1"   # exercise the collective path on one GPU
+    L_total = a.loci * world if a.weak else a.loci
+    begin, end = (rank * a.loci, (rank + 1) * a.loci) if a.weak else shard_of(L_total, rank, world)
+    pack = build_shard(G, a.config, L_total, begin, end, a.mut_scale, 20261002 + a.config, os.path.join(REPO, "bench_cache"))
+    if a.samples_per_log > 0:
+        pack.samplesPerLog = a.samples_per_log
+    lib = G.load_library(dims=(pack.n, pack.K, pack.B))
     if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm (bench bookkeeping only)
         dev = torch.device("cuda", local_rank)
+        if a.comm == "rccl":
+            # the engine's own communicator: rank 0 makes the id, torch.distributed carries the 128 bytes
+            idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                import ctypes
+                raw = (ctypes.c_uint8 * 128)()
+                assert lib.gph_comm_unique_id(raw) == 0
+                idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
+            dist.broadcast(idbuf, 0)
+            idbytes = bytes(idbuf.cpu().tolist())
+            comm = lib.gph_comm_create_rccl(idbytes, rank, world, local_rank)
+            assert comm, "gph_comm_create_rccl failed"
+        else:
+            # <= 512-byte payloads through torch.distributed: every rank all-gathers the (sums | mins) vector and
+            # reduces the `world` rows itself in rank order
+            SLOTS = 192
+            hbuf = torch.zeros(SLOTS, dtype=torch.float64).pin_memory()
+            dbuf = torch.zeros(SLOTS, dtype=torch.float64, device=dev)
+            dout = torch.zeros(world * SLOTS, dtype=torch.float64, device=dev)
+            hout = torch.zeros(world * SLOTS, dtype=torch.float64).pin_memory()
 
-        # <= 240-byte payloads.  One collective per reduction point: every rank all-gathers the (sums | mins)
-        # vector over RCCL and reduces the `world` rows itself in rank order -- one launch instead of an
-        # all-reduce(SUM) plus an all-reduce(MIN), and every rank adds in the same order (identical bits)
-        SLOTS = 64
-        hbuf = torch.zeros(SLOTS, dtype=torch.float64).pin_memory()
-        dbuf = torch.zeros(SLOTS, dtype=torch.float64, device=dev)
-        dout = torch.zeros(world * SLOTS, dtype=torch.float64, device=dev)
-        hout = torch.zeros(world * SLOTS, dtype=torch.float64).pin_memory()
-        ncoll = [0]
+            def allreduce(sums, mins):
+                ns, nm = sums.size, mins.size
+                assert ns + nm <= SLOTS
+                hb = hbuf.numpy()
+                hb[:ns] = sums
+                hb[ns:ns + nm] = mins
+                dbuf.copy_(hbuf, non_blocking=True)
+                dist.all_gather_into_tensor(dout, dbuf)
+                hout.copy_(dout, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                rows = hout.numpy().reshape(world, SLOTS)
+                if ns:
+                    acc = rows[0, :ns].copy()
+                    for r in range(1, world):
+                        acc += rows[r, :ns]
+                    sums[:] = acc
+                if nm:
+                    mins[:] = rows[:, ns:ns + nm].min(axis=0)
+                ncoll[0] += 1
 
-        def allreduce(sums, mins):
-            ns, nm = sums.size, mins.size
-            assert ns + nm <= SLOTS
-            hb = hbuf.numpy()
-            hb[:ns] = sums
-            hb[ns:ns + nm] = mins
-            dbuf.copy_(hbuf, non_blocking=True)
-            dist.all_gather_into_tensor(dout, dbuf)
-            hout.copy_(dout, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            rows = hout.numpy().reshape(world, SLOTS)
-            if ns:
-                acc = rows[0, :ns].copy()
-                for r in range(1, world):
-                    acc += rows[r, :ns]
-                sums[:] = acc
-            if nm:
-                mins[:] = rows[:, ns:ns + nm].min(axis=0)
-            ncoll[0] += 1
-
-    L_total = a.loci * world
-    # weak scaling: every rank generates (and holds) only its own a.loci loci of the L_total-locus data set
-    pack = build_workload(G, a.config, a.loci, a.mut_scale, 20261002 + a.config,
-                          os.path.join(REPO, "bench_cache"), begin=rank * a.loci, L_total=L_total)
     P = np.diff(pack.pattern_offsets)
-    s = G.Sampler(pack, device=local_rank, rank=rank, world=world, allreduce=allreduce)
+    s = G.Sampler(pack, lib=lib, device=local_rank, rank=rank, world=world, allreduce=allreduce, comm=comm)
     s.initialize()
-    for it in range(a.warmup):
+    it0 = 0
+    # untimed pre-roll: the chain leaves the prior-sampled start; then W warm-up steps; then K timed
+    for it in range(a.preroll):
         s.iteration(it)
+    it0 = a.preroll
+    for it in range(it0, it0 + a.warmup):
+        s.iteration(it)
+    it0 += a.warmup
     s.counters(reset=True)
     for k in range(16):
         s.class_stats(k, reset=True)
+    hs0 = s.host_stats()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for it in range(a.warmup, a.warmup + a.steps):
+    for it in range(it0, it0 + a.steps):
         s.iteration(it)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    cnt = s.counters()
+    hs1 = s.host_stats()
+    cnt = s.counters()            # summed over all ranks by the engine (the counters ride in the reduced rows)
     sweep = s.class_stats(0)
     evals, tmax = float(cnt["evals"]), dt
     if dist:
-        t = torch.tensor([evals], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        evals = float(t.item())
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
+    # amortised cost of checkAll (patch.c:2745, every iterations-per-log = 100 iterations): one untimed-region call
+    check_ms = None
+    if rank == 0 or dist:
+        spl = int(pack.samplesPerLog)
+        in_window = sum(1 for it in range(it0, it0 + a.steps) if (it + 1) % spl == 0)
+        st4 = s.class_stats(4)
+        if st4["launches"]:
+            check_ms = st4["ms"] / st4["launches"]
     if rank == 0:
         kern = {}
-        names = {0: "sweep", 1: "tau_eval", 2: "mix_eval", 4: "check", 5: "tau_commit", 6: "tau_revert",
-                 7: "mix_commit", 8: "sync"}
+        names = {0: "sweep", 1: "tau_eval", 2: "mix_eval", 4: "check", 5: "tau_finish", 7: "mix_finish", 8: "sync"}
         for k, nm in names.items():
             st = s.class_stats(k)
             if st["launches"]:
                 kern[nm] = {"launches": int(st["launches"]), "avg_ms": st["ms"] / st["launches"]}
-        ach = (sweep["bytes"] / max(sweep["launches"], 1)) / (sweep["ms"] / max(sweep["launches"], 1) * 1e-3) / 1e9 \
-            if sweep["ms"] > 0 else 0.0
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2
-        # gfx950 correction + WRITE_SIZE, per launch) committed under profiles/; null if absent
-        traffic = None
+        nl = max(sweep["launches"], 1)
+        sweep_ms = sweep["ms"] / nl
+        # sweep["bytes"] is summed over the ranks (the counters ride in the reduced rows); the kernel time is this rank's
+        alg_bytes = sweep["bytes"] / nl / world
+        ach = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        L_local = pack.L
+        # load-once / store-once bound of a sweep: 2 * (32 N P + 32 E + 20 N) bytes per locus
+        N_, E_ = 2 * pack.n - 1, 2 * pack.n + 40 + 3 * pack.B + pack.K + 10
+        per_sweep_bytes = float(np.sum(2.0 * (32.0 * N_ * P + 32.0 * E_ + 20.0 * N_)))
+        # HBM traffic of the dominant kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
+        # WRITE_SIZE, per launch) of an EARLIER run of this command, committed under profiles/ -- not measured here
+        traffic, traffic_src = None, None
         tf = os.path.join(REPO, "profiles", "traffic_k_sweep.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                if tj.get("loci") == a.loci:
+                if tj.get("loci") == L_local:
                     traffic = tj["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/traffic_k_sweep.json (%s)" % tj.get("build", "committed rocprofv3 --pmc passes, not this run")
             except Exception:
                 pass
+        nsync = (hs1["syncs"] - hs0["syncs"]) / a.steps
+        ncol = (hs1["collectives"] - hs0["collectives"]) / a.steps if comm else ncoll[0] / max(a.preroll + a.warmup + a.steps, 1)
         line = {
-            "metric": "locus-likelihood evals/sec (+ MCMC iters/sec), 100k loci per MI355X",
+            "metric": "locus-likelihood evals/sec (+ MCMC iters/sec), 100k loci, 1/2/4/8 MI355X",
             "value": evals / tmax, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": tmax / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": tmax / a.steps * 1e3, "higher_is_better": True, "scaling": "weak" if a.weak else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "mcmc_iters_per_sec": a.steps / tmax,
-            "config": {"workload": f"BASELINE configs[3]: {a.loci} loci/GPU x 1 kb, 8 diploid samples (16 leaves), "
-                                   f"5 current pops + 4 migration bands, full MCMC iteration",
-                       "loci_total": L_total, "leaves": int(pack.n), "pops": int(pack.K), "bands": int(pack.B),
+            "config": {"workload": f"BASELINE configs[3]: {L_total} loci x 1 kb, 8 diploid samples (16 leaves), "
+                                   f"5 current pops + 4 migration bands, full MCMC iteration; "
+                                   + (f"{a.loci} loci on every rank (weak)" if a.weak else
+                                      f"ONE data set sharded over {world} rank(s) (strong)"),
+                       "loci_total": L_total, "loci_this_rank": int(L_local), "leaves": int(pack.n), "pops": int(pack.K),
+                       "bands": int(pack.B),
                        "mean_phased_patterns": float(P.mean()), "max_phased_patterns": int(P.max()),
+                       "data_diversity": f"mutation scale {a.mut_scale} x the prior mean theta (tunes P to ~18 phased patterns per 1-kb locus)",
                        "evals_per_locus_iter": evals / (L_total * a.steps),
                        "recomputed_nodes_per_eval": cnt["eval_nodes"] / max(cnt["evals"], 1),
                        "algorithmic_bytes_per_eval": cnt["eval_bytes"] / max(cnt["evals"], 1),
+                       "preroll_iterations": a.preroll,
+                       "checkall_period": int(pack.samplesPerLog), "checkall_in_timed_window": in_window,
+                       "checkall_ms": check_ms,
+                       "checkall_amortised_ms_per_iteration": (check_ms / int(pack.samplesPerLog)) if check_ms else None,
+                       "host_syncs_per_iteration": nsync,
+                       "collectives_per_iteration": ncol if (dist is not None) else 0,
+                       "decisions": "device-resident (k_global)" if hs1["resident"] else "host",
+                       "kernel_launches_per_iteration": (hs1["launches"] - hs0["launches"]) / a.steps,
                        "parallelism": f"loci sharded over {world} rank(s), one process per GPU"
-                                      + (f", {ncoll[0] / max(a.warmup + a.steps, 1):.1f} RCCL all-gathers (<= 512 B) per "
-                                         f"iteration" if dist else "")},
+                                      + (f", native RCCL all-gather of the reduced row on the engine's stream" if comm else
+                                         (", torch.distributed hook" if dist else ""))},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (fused UpdateGB_InternalNode+MigrationNode+MigSPR)",
-                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
-                         "avg_launch_ms": sweep["ms"] / max(sweep["launches"], 1),
-                         "algorithmic_bytes_per_launch": sweep["bytes"] / max(sweep["launches"], 1),
-                         "evals_per_launch": sweep["evals"] / max(sweep["launches"], 1)},
+                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                         "accounting": "ALGORITHMIC bytes per evaluation (96 R P + 20 N + 8 U + 8, SURVEY 8d) / HIP-event "
+                                       "kernel time; mostly L2 / Infinity-Cache hits, see hbm_counter_frac for DRAM",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "hbm_counter_frac": (traffic / (sweep_ms * 1e-3) / 8e12) if traffic else None,
+                         "per_sweep": {"bytes": per_sweep_bytes, "bound_ms_at_peak": per_sweep_bytes / 8e12 * 1e3,
+                                       "frac": per_sweep_bytes / 8e12 * 1e3 / sweep_ms if sweep_ms > 0 else None,
+                                       "accounting": "load-once/store-once: 2 (32 N P + 32 E + 20 N) bytes per locus per sweep"},
+                         "avg_launch_ms": sweep_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "evals_per_launch": sweep["evals"] / nl / world},
             "kernels": kern,
             "hbm_resident_bytes": s.hbm_bytes(),
         }
@@ -324,12 +411,17 @@ def main():
                 port = cpu_baseline(G, pack, min(a.cpu_loci, L_total), a.cpu_iters)
                 if cb is None:
                     cb = port
+                    cb["note"] = "oracle/_ref (the real reference binary) is absent on this box: the restatement was timed"
                 else:
                     cb["port_single_thread"] = {"value": port["value"], "kind": "port"}
+                cb["sample_caveat"] = (f"timed on {min(a.cpu_loci, L_total)} loci (working set ~"
+                                       f"{min(a.cpu_loci, L_total) * 0.035:.0f} MB) against {L_total} on the GPU: not like for like")
                 line["cpu_baseline"] = cb
             except Exception as ex:  # pragma: no cover
                 line["cpu_baseline"] = {"error": str(ex)}
     s.close()
+    if comm:
+        lib.gph_comm_destroy(comm)
     if dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -26,7 +26,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # memory -- and reload, hundreds of cycles each, ~10 times per proposal.  Without it the sweep kernel has no vector
 # spills at 80 VGPRs (25 before) and 23 instead of 47 scalar spills: -5.4 % sweep time.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wno-unused-result", "-pthread", "-mllvm", "-disable-machine-licm"]
+               "-Wno-unused-result", "-pthread", "-mllvm", "-disable-machine-licm", "-ldl", "-lrt"]
 
 # Capacity variants of the same library (same C ABI, same sources): the static LDS image of a locus is
 # sized by compile-time capacities (csrc/gph_types.h), and a tighter image means more resident
@@ -35,19 +35,21 @@ VARIANTS = {  # name: (max leaves, max pops, max bands, waves per SIMD of the sw
     "s": (16, 9, 4, 6, "libgphocs_hip_s.so"),     # BASELINE configs[0..3]
     "l": (20, 13, 4, 5, "libgphocs_hip_l.so"),    # BASELINE configs[4] (20 leaves, 13 populations)
     "m": (24, 16, 8, 5, "libgphocs_hip.so"),
+    "x": (32, 32, 16, 4, "libgphocs_hip_x.so"),   # the engine's hard caps: one genealogy node per lane (2n-1 <= 63), 32-bit population masks
 }
 
 
-LIB_SOURCES = ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp", "gph_readtrace.cpp")
+LIB_SOURCES = ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp", "gph_readtrace.cpp", "gph_comm.cpp")
 
 
 def variant_for(n, K, B):
-    for name in ("s", "l", "m"):
+    for name in ("s", "l", "m", "x"):
         cl, ck, cb, _, _ = VARIANTS[name]
         if n <= cl and K <= ck and B <= cb:
             return name
-    raise RuntimeError(f"model (leaves={n}, pops={K}, bands={B}) exceeds the largest compiled capacity "
-                       f"{VARIANTS['m'][:3]}; rebuild with larger -DGPH_CAP_* (csrc/gph_types.h)")
+    raise RuntimeError(f"model (leaves={n}, pops={K}, bands={B}) exceeds the engine's hard caps {VARIANTS['x'][:3]} "
+                       f"(one genealogy node per lane, 32-bit population masks); the reference's own compile-time caps are "
+                       f"200 leaves / 39 populations / 100 bands (upstream src/patch.h:17-22)")
 
 
 def lib_path(name="m"):
@@ -149,7 +151,10 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
     "gph_control_sample_name", "gph_loci_read", "gph_loci_free", "gph_loci_arrays", "gph_run_control_file", "gph_run_control_file_ranked",
     "gph_read_trace", "gph_engine_locus_rate_update", "gph_engine_set_locus_rates", "gph_mcmc_set_locus_rate_finetune",
-    "gph_mcmc_locus_rate_state",
+    "gph_mcmc_locus_rate_state", "gph_engine_set_comm", "gph_engine_host_stats", "gph_engine_set_timing",
+    "gph_comm_unique_id", "gph_comm_create_rccl", "gph_comm_create_shm", "gph_comm_attach_shm", "gph_comm_shm_bytes",
+    "gph_comm_destroy", "gph_comm_world", "gph_comm_rank", "gph_comm_on_stream", "gph_comm_kind",
+    "gph_comm_allgather_stream", "gph_comm_allreduce_host", "gph_run_control_file_comm", "gph_device_count",
 ]
 
 
@@ -215,6 +220,20 @@ def _load_library(path):
     lib.gph_run_control_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
     lib.gph_run_control_file_ranked.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                 ALLREDUCE_FN, C.c_void_p]
+    lib.gph_comm_unique_id.argtypes = [C.c_void_p]
+    lib.gph_comm_create_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.gph_comm_create_rccl.restype = C.c_void_p
+    lib.gph_comm_create_shm.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
+    lib.gph_comm_create_shm.restype = C.c_void_p
+    lib.gph_comm_destroy.argtypes = [C.c_void_p]
+    lib.gph_comm_destroy.restype = None
+    lib.gph_comm_kind.argtypes = [C.c_void_p]
+    lib.gph_comm_kind.restype = C.c_char_p
+    lib.gph_engine_set_comm.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gph_engine_host_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int32)]
+    lib.gph_engine_set_timing.argtypes = [C.c_void_p, C.c_uint32]
+    lib.gph_run_control_file_comm.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
     return lib
 
 
@@ -299,7 +318,7 @@ class Pack:
             offs.append(offs[-1] + P)
         p.pattern_offsets = np.array(offs, dtype=np.int64)
         p.leafcodes = np.array(leaf, dtype=np.uint8).reshape(-1, p.n)
-        p.numPhases = np.array(phases, dtype=np.uint8)
+        p.numPhases = np.array(phases, dtype=np.uint16)
         p.counts = np.array(counts, dtype=np.int32)
         p.mutRates = np.array(rates)
         return p
@@ -362,7 +381,7 @@ class Pack:
                 p.pattern_offsets = view(po, p.L + 1, C.c_int64, np.int64)
                 Ptot = int(p.pattern_offsets[-1])
                 p.leafcodes = view(lf, Ptot * p.n, C.c_uint8, np.uint8).reshape(-1, p.n)
-                p.numPhases = view(ph, Ptot, C.c_uint8, np.uint8)
+                p.numPhases = view(ph, Ptot, C.c_uint16, np.uint16)
                 p.counts = view(cn, Ptot, C.c_int32, np.int32)
                 p.mutRates = view(mr, p.L, C.c_double, np.float64)
                 p.unphased = view(up, p.L, C.c_int32, np.int32)
@@ -390,7 +409,9 @@ def _ip(a):
 class Sampler:
     """Engine + host MCMC driver for one rank's shard of a Pack."""
 
-    def __init__(self, pack, lib=None, device=0, rank=0, world=1, allreduce=None):
+    def __init__(self, pack, lib=None, device=0, rank=0, world=1, allreduce=None, comm=None):
+        """allreduce: Python hook (gloo tests) -- forces a host synchronisation per reduction point;
+        comm: native communicator handle (gph_comm_create_rccl / _shm) -- RCCL runs on the engine's stream"""
         self.lib = lib or load_library(dims=(pack.n, pack.K, pack.B))
         self.pack = pack
         self.rank, self.world = rank, world
@@ -426,11 +447,13 @@ class Sampler:
                     return 1
             self._cb = ALLREDUCE_FN(_cb)
             self._chk(self.lib.gph_engine_set_allreduce(self.engine, self._cb, None), "set_allreduce")
+        if comm is not None:
+            self._chk(self.lib.gph_engine_set_comm(self.engine, comm), "set_comm")
         b, e = self.begin, self.end
         o0, o1 = p.pattern_offsets[b], p.pattern_offsets[e]
         offs = np.ascontiguousarray(p.pattern_offsets[b:e + 1] - o0, dtype=np.int64)
         leaf = np.ascontiguousarray(p.leafcodes[o0:o1])
-        ph = np.ascontiguousarray(p.numPhases[o0:o1])
+        ph = np.ascontiguousarray(p.numPhases[o0:o1], dtype=np.uint16)
         cn = np.ascontiguousarray(p.counts[o0:o1])
         rates = np.ascontiguousarray(p.mutRates[b:e], dtype=np.float64)
         use_rates = bool(np.any(rates != 1.0))
@@ -499,6 +522,14 @@ class Sampler:
         o = (C.c_double * 5)()
         self._chk(self.lib.gph_engine_class_stats(self.engine, which, o, int(reset)), "class_stats")
         return dict(launches=o[0], ms=o[1], evals=o[2], bytes=o[3], nodes=o[4])
+
+    def host_stats(self):
+        a, b, c, r = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        self._chk(self.lib.gph_engine_host_stats(self.engine, C.byref(a), C.byref(b), C.byref(c), C.byref(r)), "host_stats")
+        return dict(syncs=a.value, collectives=b.value, launches=c.value, resident=bool(r.value))
+
+    def set_timing(self, mask):
+        self._chk(self.lib.gph_engine_set_timing(self.engine, mask), "set_timing")
 
     def hbm_bytes(self):
         b = C.c_double()

@@ -1,0 +1,295 @@
+// gph_comm.cpp -- see gph_comm.h.  Host code (no kernels): RCCL through dlopen + a shared-memory exchange.
+#include "gph_comm.h"
+#include <atomic>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#ifndef GPH_HOSTEMU
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#endif
+
+#define GPH_COMM_MAXN 192
+
+struct ShmSeg {                       // one cache line per rank's arrival counter
+  std::atomic<uint32_t> magic;
+  std::atomic<uint32_t> failed;
+  char pad0[56];
+  struct alignas(64) Slot { std::atomic<uint64_t> seq; char pad[56]; } slot[64];
+  double data[2][64][GPH_COMM_MAXN];
+};
+
+struct gph_comm {
+  int kind = 0;                       // 1 RCCL, 2 shm
+  int rank = 0, world = 1;
+  // shm
+  ShmSeg *seg = nullptr;
+  bool owns_mapping = false;
+  std::string shm_name;
+  uint64_t seq = 0;
+#ifndef GPH_HOSTEMU
+  // RCCL
+  ncclComm_t nccl = nullptr;
+  int device = 0;
+  hipStream_t hstream = nullptr;      // host-path collectives (the engine's own stream carries the resident ones)
+  double *d_in = nullptr, *d_out = nullptr, *h_buf = nullptr;
+#endif
+};
+
+#ifndef GPH_HOSTEMU
+namespace {
+struct Rccl {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl *rccl()
+{
+  static Rccl R;
+  static bool tried = false;
+  if (tried) return R.h ? &R : nullptr;
+  tried = true;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) if ((R.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   /* a copy this process already holds */
+  if (!R.h) for (const char *n : names) if ((R.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!R.h) { fprintf(stderr, "gphocs_hip: cannot load librccl (%s) -- several GPUs need RCCL\n", dlerror()); return nullptr; }
+  R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(R.h, "ncclGetUniqueId");
+  R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.h, "ncclCommInitRank");
+  R.AllGather = (decltype(R.AllGather))dlsym(R.h, "ncclAllGather");
+  R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.h, "ncclCommDestroy");
+  R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
+  if (!R.GetUniqueId || !R.CommInitRank || !R.AllGather || !R.CommDestroy || !R.GetErrorString) {
+    fprintf(stderr, "gphocs_hip: librccl lacks an entry point\n");
+    R.h = nullptr;
+    return nullptr;
+  }
+  return &R;
+}
+}   // namespace
+#endif
+
+extern "C" {
+
+int gph_device_count(void)
+{
+#ifdef GPH_HOSTEMU
+  return 1;
+#else
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+#endif
+}
+
+int gph_comm_unique_id(void *id128)
+{
+#ifdef GPH_HOSTEMU
+  (void)id128;
+  return 1;
+#else
+  static_assert(sizeof(ncclUniqueId) == GPH_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  Rccl *R = rccl();
+  if (!R || !id128) return 1;
+  ncclUniqueId id;
+  ncclResult_t rc = R->GetUniqueId(&id);
+  if (rc != ncclSuccess) { fprintf(stderr, "gphocs_hip: ncclGetUniqueId: %s\n", R->GetErrorString(rc)); return 1; }
+  memcpy(id128, &id, sizeof id);
+  return 0;
+#endif
+}
+
+gph_comm *gph_comm_create_rccl(const void *id128, int32_t rank, int32_t world, int32_t device)
+{
+#ifdef GPH_HOSTEMU
+  (void)id128; (void)rank; (void)world; (void)device;
+  return nullptr;
+#else
+  Rccl *R = rccl();
+  if (!R || !id128 || world < 1 || world > 64 || rank < 0 || rank >= world) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  gph_comm *c = new gph_comm();
+  c->kind = 1; c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  ncclResult_t rc = R->CommInitRank(&c->nccl, world, id, rank);
+  if (rc != ncclSuccess) {
+    fprintf(stderr, "gphocs_hip: ncclCommInitRank(rank %d of %d, device %d): %s (RCCL wants one GPU per rank)\n", rank, world, device, R->GetErrorString(rc));
+    delete c;
+    return nullptr;
+  }
+  if (hipStreamCreate(&c->hstream) != hipSuccess || hipMalloc((void **)&c->d_in, sizeof(double) * GPH_COMM_MAXN) != hipSuccess ||
+      hipMalloc((void **)&c->d_out, sizeof(double) * GPH_COMM_MAXN * world) != hipSuccess ||
+      hipHostMalloc((void **)&c->h_buf, sizeof(double) * GPH_COMM_MAXN * (world + 1), hipHostMallocDefault) != hipSuccess) {
+    gph_comm_destroy(c);
+    return nullptr;
+  }
+  return c;
+#endif
+}
+
+size_t gph_comm_shm_bytes(int32_t world) { (void)world; return sizeof(ShmSeg); }
+
+gph_comm *gph_comm_attach_shm(void *mapping, int32_t rank, int32_t world)
+{
+  if (!mapping || world < 1 || world > 64 || rank < 0 || rank >= world) return nullptr;
+  gph_comm *c = new gph_comm();
+  c->kind = 2; c->rank = rank; c->world = world;
+  c->seg = (ShmSeg *)mapping;
+  return c;
+}
+
+gph_comm *gph_comm_create_shm(const char *name, int32_t rank, int32_t world)
+{
+  if (!name || world < 1 || world > 64 || rank < 0 || rank >= world) return nullptr;
+  int fd = -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (rank == 0) {
+    shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd >= 0 && ftruncate(fd, (off_t)sizeof(ShmSeg)) != 0) { close(fd); fd = -1; }
+  } else {
+    for (;;) {   /* until rank 0 has made it */
+      fd = shm_open(name, O_RDWR, 0600);
+      struct stat st;
+      if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(ShmSeg)) break;
+      if (fd >= 0) { close(fd); fd = -1; }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) break;
+      usleep(1000);
+    }
+  }
+  if (fd < 0) { fprintf(stderr, "gphocs_hip: cannot open the shared-memory segment %s\n", name); return nullptr; }
+  void *m = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return nullptr;
+  gph_comm *c = gph_comm_attach_shm(m, rank, world);
+  if (!c) { munmap(m, sizeof(ShmSeg)); return nullptr; }
+  c->owns_mapping = true;
+  c->shm_name = name;
+  if (rank == 0) c->seg->magic.store(0x47504843u, std::memory_order_release);
+  else {
+    while (c->seg->magic.load(std::memory_order_acquire) != 0x47504843u) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) { gph_comm_destroy(c); return nullptr; }
+      usleep(200);
+    }
+  }
+  return c;
+}
+
+void gph_comm_destroy(gph_comm *c)
+{
+  if (!c) return;
+#ifndef GPH_HOSTEMU
+  if (c->kind == 1) {
+    (void)hipSetDevice(c->device);
+    if (c->nccl) { Rccl *R = rccl(); if (R) R->CommDestroy(c->nccl); }
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->h_buf) (void)hipHostFree(c->h_buf);
+    if (c->hstream) (void)hipStreamDestroy(c->hstream);
+  }
+#endif
+  if (c->kind == 2 && c->owns_mapping) {
+    munmap(c->seg, sizeof(ShmSeg));
+    if (c->rank == 0 && !c->shm_name.empty()) shm_unlink(c->shm_name.c_str());
+  }
+  delete c;
+}
+
+int gph_comm_world(const gph_comm *c) { return c ? c->world : 1; }
+int gph_comm_rank(const gph_comm *c) { return c ? c->rank : 0; }
+int gph_comm_on_stream(const gph_comm *c) { return c && c->kind == 1; }
+const char *gph_comm_kind(const gph_comm *c) { return !c ? "none" : c->kind == 1 ? "rccl" : "shm"; }
+
+int gph_comm_allgather_stream(gph_comm *c, const double *d_in, double *d_out, int32_t count, void *stream)
+{
+#ifdef GPH_HOSTEMU
+  (void)c; (void)d_in; (void)d_out; (void)count; (void)stream;
+  return 1;
+#else
+  if (!c || c->kind != 1) return 1;
+  Rccl *R = rccl();
+  ncclResult_t rc = R->AllGather(d_in, d_out, (size_t)count, ncclDouble, c->nccl, (hipStream_t)stream);
+  if (rc != ncclSuccess) { fprintf(stderr, "gphocs_hip: ncclAllGather: %s\n", R->GetErrorString(rc)); return 1; }
+  return 0;
+#endif
+}
+
+int gph_comm_allreduce_host(gph_comm *c, double *sums, int32_t nsum, double *mins, int32_t nmin)
+{
+  if (!c) return 0;
+  const int n = nsum + nmin;
+  if (n > GPH_COMM_MAXN || nsum < 0 || nmin < 0) return 1;
+  if (n == 0) return 0;
+  if (c->kind == 2) {
+    ShmSeg *s = c->seg;
+    const uint64_t k = ++c->seq;
+    double *mine = s->data[k & 1][c->rank];
+    if (nsum) memcpy(mine, sums, sizeof(double) * nsum);
+    if (nmin) memcpy(mine + nsum, mins, sizeof(double) * nmin);
+    s->slot[c->rank].seq.store(k, std::memory_order_release);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < c->world; r++) {
+      unsigned spins = 0;
+      while (s->slot[r].seq.load(std::memory_order_acquire) < k) {
+        if (s->failed.load(std::memory_order_relaxed)) return 1;
+        if ((++spins & 1023) == 0) {
+          sched_yield();
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 900.0) {
+            fprintf(stderr, "gphocs_hip: rank %d waited 900 s for rank %d in the shared-memory exchange\n", c->rank, r);
+            s->failed.store(1);
+            return 1;
+          }
+        }
+      }
+    }
+    /* rank order: the same additions on every rank */
+    for (int i = 0; i < nsum; i++) {
+      double a = s->data[k & 1][0][i];
+      for (int r = 1; r < c->world; r++) a += s->data[k & 1][r][i];
+      sums[i] = a;
+    }
+    for (int i = 0; i < nmin; i++) {
+      double a = s->data[k & 1][0][nsum + i];
+      for (int r = 1; r < c->world; r++) { const double v = s->data[k & 1][r][nsum + i]; a = v < a ? v : a; }
+      mins[i] = a;
+    }
+    return 0;
+  }
+#ifndef GPH_HOSTEMU
+  if (c->kind == 1) {
+    Rccl *R = rccl();
+    if (hipSetDevice(c->device) != hipSuccess) return 1;
+    double *hin = c->h_buf, *hout = c->h_buf + GPH_COMM_MAXN;
+    if (nsum) memcpy(hin, sums, sizeof(double) * nsum);
+    if (nmin) memcpy(hin + nsum, mins, sizeof(double) * nmin);
+    if (hipMemcpyAsync(c->d_in, hin, sizeof(double) * n, hipMemcpyHostToDevice, c->hstream) != hipSuccess) return 1;
+    if (R->AllGather(c->d_in, c->d_out, (size_t)n, ncclDouble, c->nccl, c->hstream) != ncclSuccess) return 1;
+    if (hipMemcpyAsync(hout, c->d_out, sizeof(double) * n * c->world, hipMemcpyDeviceToHost, c->hstream) != hipSuccess) return 1;
+    if (hipStreamSynchronize(c->hstream) != hipSuccess) return 1;
+    for (int i = 0; i < nsum; i++) {
+      double a = hout[i];
+      for (int r = 1; r < c->world; r++) a += hout[(size_t)r * n + i];
+      sums[i] = a;
+    }
+    for (int i = 0; i < nmin; i++) {
+      double a = hout[nsum + i];
+      for (int r = 1; r < c->world; r++) { const double v = hout[(size_t)r * n + nsum + i]; a = v < a ? v : a; }
+      mins[i] = a;
+    }
+    return 0;
+  }
+#endif
+  return 1;
+}
+
+}   // extern "C"

@@ -5,6 +5,10 @@
 // resident waves per CU is LDS-bound (160 KiB / lds_bytes) -- L >> 256 CUs x waves/CU
 // keeps every XCD busy and needs no blockIdx remap (loci are independent, nothing is
 // shared between workgroups, so L2 affinity is irrelevant).
+//
+// An MCMC iteration is ONE stream of launches (gph_engine_iteration_): per-locus kernel -> fixed-shape reduction
+// -> [RCCL all-gather of the reduced row, on the same stream] -> k_global (the decision above the loci, one
+// wavefront, gph_global.h) -> predicated commit / revert kernel -> ... and a single host synchronisation at its end.
 #include <stdio.h>
 #include <stdlib.h>
 #include <stddef.h>
@@ -12,6 +16,8 @@
 #include <vector>
 #include <algorithm>
 #include "gph_kernels.h"
+#include "gph_global.h"
+#include "gph_comm.h"
 #include "../../include/gphocs_hip.h"
 
 #ifdef GPH_HOSTEMU
@@ -19,6 +25,7 @@ thread_local char *gph_sm = nullptr;
 thread_local GphLds gph_lds;
 GphLayout g_lay;
 GphModel g_model;
+GphGlobal *gph_G_emu = nullptr;
 #define GPH_KERNEL(name, ...) static void name(int gph_blk, __VA_ARGS__)
 #define GPH_SWEEP_ATTR
 #define GPH_BLK gph_blk
@@ -33,16 +40,17 @@ GphModel g_model;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "gphocs_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return GPH_EHIP; } } while (0)
 #endif
 
-// j0 = first slot of the launch group (see GphDev)
-GPH_KERNEL(k_init, GphKargs KA, GphDev D, int j0, uint32_t seedz, const double *mutRate, int preDraws) { GphCtx lx; lx.kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0, preDraws); }
+// j0 = first slot of the launch group (see GphDev).  GphCtx reads the model from the kernel-argument segment (the host
+// knows it when it launches: the genealogy sweep at the head of an iteration, the locus-rate kernels), GphCtxG from the
+// device-resident chain state KA.G (everything launched after a decision the host has not seen yet)
+GPH_KERNEL(k_init, GphKargs KA, GphDev D, int j0, uint32_t seedz, const double *mutRate, int preDraws) { GphCtxG lx; lx.kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0, preDraws); }
 GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphKargs KA, GphDev D, int j0, int flags, double ftCoal, double ftMig) { GphCtx lx; lx.kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
-GPH_KERNEL(k_tau_eval, GphKargs KA, GphDev D, int j0, GphTauArgs A) { GphCtx lx; lx.kb_tau_eval(D, j0 + GPH_BLK, A); }
-GPH_KERNEL(k_tau_commit, GphKargs KA, GphDev D, int j0, GphTauArgs A) { GphCtx lx; lx.kb_tau_commit(D, j0 + GPH_BLK, A); }
-GPH_KERNEL(k_tau_revert, GphKargs KA, GphDev D, int j0, long long limit) { GphCtx lx; lx.kb_tau_revert(D, j0 + GPH_BLK, limit); }
-GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, double c) { GphCtx lx; lx.kb_mix_eval(D, j0 + GPH_BLK, c); }
-GPH_KERNEL(k_mix_commit, GphKargs KA, GphDev D, int j0, double c, double lnc) { GphCtx lx; lx.kb_mix_commit(D, j0 + GPH_BLK, c, lnc); }
-GPH_KERNEL(k_sync, GphKargs KA, GphDev D, int j0, int refresh) { GphCtx lx; lx.kb_sync(D, j0 + GPH_BLK, refresh); }
-GPH_KERNEL(k_check, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtx lx; lx.kb_check(D, j0 + GPH_BLK); }
+GPH_KERNEL(k_tau_eval, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_tau_eval(D, j0 + GPH_BLK, GPH_G->tau); }
+GPH_KERNEL(k_tau_finish, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_tau_finish(D, j0 + GPH_BLK); }
+GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_mix_eval(D, j0 + GPH_BLK, GPH_G->mix_c); }
+GPH_KERNEL(k_mix_finish, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_mix_finish(D, j0 + GPH_BLK); }
+GPH_KERNEL(k_sync, GphKargs KA, GphDev D, int j0, int refresh) { GphCtxG lx; lx.kb_sync(D, j0 + GPH_BLK, refresh); }
+GPH_KERNEL(k_check, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_check(D, j0 + GPH_BLK); }
 GPH_KERNEL(k_lrate_prep, GphKargs KA, GphDev D, int j0, double finetune, GphLrPre *pre) { GphCtx lx; lx.kb_lrate_prep(D, j0 + GPH_BLK, finetune, pre); }
 GPH_KERNEL(k_lrate_scan, GphKargs KA, GphDev D, int j0, GphLrArgs A) { (void)j0; GphCtx lx; lx.kb_lrate_scan(D, A); }
 GPH_KERNEL(k_lrate_apply, GphKargs KA, GphDev D, int j0, const GphLrRec *rec) { GphCtx lx; lx.kb_lrate_apply(D, j0 + GPH_BLK, rec); }
@@ -51,31 +59,45 @@ GPH_KERNEL(k_lrate_apply, GphKargs KA, GphDev D, int j0, const GphLrRec *rec) { 
 #ifndef GPH_RED_BLOCKS
 #define GPH_RED_BLOCKS 256
 #endif
-#define GPH_RED_COLS 128   // >= 2K+2B and >= GPH_OUT_SLOTS
-static_assert(2 * GPH_CAP_K + 2 * GPH_CAP_B <= 64 && GPH_OUT_SLOTS <= 64, "the reduction kernels fold at most 64 columns");
+static_assert(2 * GPH_CAP_K + 2 * GPH_CAP_B <= GPH_RED_COLS && GPH_OUT_SLOTS <= 64, "the reduction kernels fold at most GPH_RED_COLS columns");
 
-#ifndef GPH_HOSTEMU
-// UpdateTheta accepted: genLogLikelihood touch-up, GPhoCS.c:3084-3093 (one thread per locus)
-__global__ void k_apply_theta(GphKargs KA, GphDev D, int pop, double lnc, double inv_diff)
+// UpdateTheta / UpdateMigRates accepted: the genLogLikelihood touch-ups of GPhoCS.c:3084-3093 and :3192-3200, every
+// accepted proposal of the iteration in the order it was accepted (the list is in the chain state); one thread per locus
+GPH_HD void apply_list_locus(char *pg, const GphLayout &y, const GphApply *ap, int na)
 {
-  int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= D.L) return;
-  char *pg = D.pages + (size_t)g * g_lay.page_bytes;
-  double *fs = (double *)(pg + g_lay.o_fscal);
-  int nc = ((int16_t *)(pg + g_lay.o_ncoal))[pop];
-  double cs = ((double *)(pg + g_lay.o_coal))[pop];
-  fs[FS_GENLNL] -= (lnc * nc + inv_diff * cs);
+  double *fs = (double *)(pg + y.o_fscal);
+  double v = fs[FS_GENLNL];
+  for (int i = 0; i < na; i++) {
+    const int idx = ap[i].idx;
+    if (ap[i].kind == 0) {
+      const int nc = ((int16_t *)(pg + y.o_ncoal))[idx];
+      const double cs = ((double *)(pg + y.o_coal))[idx];
+      v -= (ap[i].lnc * nc + ap[i].diff * cs);
+    } else {
+      const int nm = ((int16_t *)(pg + y.o_nmig))[idx];
+      const double ms = ((double *)(pg + y.o_migst))[idx];
+      v += (ap[i].lnc * nm - ap[i].diff * ms);
+    }
+  }
+  fs[FS_GENLNL] = v;
 }
-// UpdateMigRates accepted: GPhoCS.c:3192-3200
-__global__ void k_apply_migrate(GphKargs KA, GphDev D, int band, double lnc, double rate_diff)
+#ifndef GPH_HOSTEMU
+__global__ void k_apply_list(GphKargs KA, GphDev D)
 {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= D.L) return;
-  char *pg = D.pages + (size_t)g * g_lay.page_bytes;
-  double *fs = (double *)(pg + g_lay.o_fscal);
-  int nm = ((int16_t *)(pg + g_lay.o_nmig))[band];
-  double ms = ((double *)(pg + g_lay.o_migst))[band];
-  fs[FS_GENLNL] += (lnc * nm - rate_diff * ms);
+  const int na = KA.G->napply;
+  if (g >= D.L || na == 0) return;
+  apply_list_locus(D.pages + (size_t)g * KA.lay.page_bytes, KA.lay, KA.G->apply, na);
+}
+// the stage above the loci (gph_global.h): one wavefront, every lane runs the same scalar code, lane 0's stores count
+__global__ void __launch_bounds__(64) k_global(GphKargs KA, const double *rows, int world, int stage, int arg, int iteration)
+{
+  if (threadIdx.x != 0) return;
+  GphGlobal &G = *KA.G;
+  G.iteration = iteration;
+  GphRed R;
+  R.rows = rows; R.world = world;
+  gg_stage(G, R, stage, arg);
 }
 // fixed-shape two-level reduction (deterministic run to run): block b owns a contiguous chunk of
 // loci; inside it Q = 8 * (64 / column width) sub-sequences (g = g0+q, g0+q+Q, ...) are summed in index
@@ -87,7 +109,43 @@ __global__ void __launch_bounds__(GPH_RED_SUBS * 64) k_reduce_partial(GphDev D, 
 {
   __shared__ double sh[3][GPH_RED_SUBS * 4][16];
   /* a wavefront covers 64 / cw loci at a time (cw = columns rounded up to 16, 32 or 64): every lane has work */
-  const int cw = ncols <= 16 ? 16 : ncols <= 32 ? 32 : 64, ng = 64 / cw, Q = GPH_RED_SUBS * ng;
+  const int cw = ncols <= 16 ? 16 : ncols <= 32 ? 32 : ncols <= 64 ? 64 : 128;
+  if (cw == 128) {
+    /* more than 64 columns (the largest capacity variant): two columns per lane, one locus per wavefront step */
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, b = blockIdx.x;
+    const int chunk = (D.L + GPH_RED_BLOCKS - 1) / GPH_RED_BLOCKS;
+    const int g0 = b * chunk, g1 = g0 + chunk < D.L ? g0 + chunk : D.L;
+    const double *src = mode == 0 ? D.out : D.stats;
+    const int stride = mode == 0 ? GPH_OUT_SLOTS : ncols;
+    for (int half = 0; half < 2; half++) {
+      const int col = lane + 64 * half;
+      double s = 0.0, mn = 1e300, mx = -1e300;
+      if (col < ncols)
+        for (int g = g0 + q; g < g1; g += GPH_RED_SUBS) {
+          double v = src[(size_t)g * stride + col];
+          s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+        }
+      for (int c0 = 64 * half; c0 < ncols && c0 < 64 * (half + 1); c0 += 16) {
+        __syncthreads();
+        if (col >= c0 && col < c0 + 16) { sh[0][q][col - c0] = s; sh[1][q][col - c0] = mn; sh[2][q][col - c0] = mx; }
+        __syncthreads();
+        if (threadIdx.x < 16 && c0 + (int)threadIdx.x < ncols) {
+          const int c = threadIdx.x;
+          double ts = 0.0, tmn = 1e300, tmx = -1e300;
+          for (int k = 0; k < GPH_RED_SUBS; k++) {
+            ts += sh[0][k][c];
+            tmn = sh[1][k][c] < tmn ? sh[1][k][c] : tmn;
+            tmx = sh[2][k][c] > tmx ? sh[2][k][c] : tmx;
+          }
+          part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + c0 + c] = ts;
+          part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + c0 + c] = tmn;
+          part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + c0 + c] = tmx;
+        }
+      }
+    }
+    return;
+  }
+  const int ng = 64 / cw, Q = GPH_RED_SUBS * ng;
   const int lane = threadIdx.x & 63, col = lane % cw, q = (threadIdx.x >> 6) * ng + lane / cw, b = blockIdx.x;
   const int chunk = (D.L + GPH_RED_BLOCKS - 1) / GPH_RED_BLOCKS;
   const int g0 = b * chunk, g1 = g0 + chunk < D.L ? g0 + chunk : D.L;
@@ -121,7 +179,7 @@ __global__ void __launch_bounds__(GPH_RED_SUBS * 64) k_reduce_partial(GphDev D, 
   }
 }
 // final pass: column c's block partials in block order, as GPH_RED_SUBS contiguous runs (one thread each) combined
-// in run order -- a fixed shape, so the result does not depend on scheduling
+// in run order -- a fixed shape, so the result does not depend on scheduling.  red = this section of the rank's row
 __global__ void __launch_bounds__(GPH_RED_SUBS * GPH_RED_COLS) k_reduce_final(int ncols, const double *part, double *red, const int32_t *err)
 {
   if (threadIdx.x == 0) red[3 * GPH_RED_COLS] = (double)*err;
@@ -171,9 +229,12 @@ struct gph_engine {
   gph_config cfg;
   std::vector<int32_t> samplesPerPop, popFather, popSon0, popSon1, bandSrc, bandTgt;
   GphLayout lay;
-  GphModel model;
   GphDev dev;
-  GphTauArgs tau;          // args of the pending tau proposal
+  // chain state above the loci (gph_types.h: GphGlobal): host mirror (pinned) and the copy in HBM the kernels read.
+  // Between iterations both are equal; inside an iteration the device copy leads (resident mode) or the host
+  // mirror does (host mode: a caller-supplied all-reduce hook forces a synchronisation per reduction anyway)
+  GphGlobal *G_h = nullptr, *G_d = nullptr;
+  bool G_dirty = true;               // the host mirror was changed since it was last pushed
   int64_t L = 0;
   size_t cond_bytes = 0, pages_bytes = 0, seq_bytes_total = 0;
   std::vector<uint64_t> h_cond_off;
@@ -182,8 +243,6 @@ struct gph_engine {
   struct Bucket { int j0, count, lds_bytes; };   // a launch group: slots [j0, j0+count), dynamic LDS per wave
   std::vector<Bucket> buckets;
   double *d_mutRate = nullptr;
-  std::vector<double> totals;        // coal_stats, num_coals, mig_stats, num_migs summed over ALL ranks, as of the last genealogy sweep
-  bool totals_valid = false;         // ... and nothing has changed a locus's statistics since
   int init_predraws = 0;             // rndu() draws every locus spent before its genealogy is sampled (VAR start-up: 1)
   bool var_rates = false;            // locus rates are part of the state (dumped as "R" lines)
   // UpdateLocusRate: per-slot records, input-order -> slot map, result scalars, scratch for pattern-rich loci
@@ -196,25 +255,32 @@ struct gph_engine {
   std::vector<uint64_t> h_seq_off;
   GphLrArgs lr;
   int lr_lds_bytes = 0;
-  double *d_part = nullptr, *d_red = nullptr;   // d_red: device-side address of h_red
-  double *h_red = nullptr;                       // pinned host memory mapped into the device's address space
+  // reductions: block partials, this rank's reduced row (GPH_RED_ROW doubles) and every rank's row after the all-gather
+  double *d_part = nullptr, *d_red = nullptr, *d_gather = nullptr;
+  double *h_red = nullptr;                       // pinned: this rank's row (host mode)
+  // several ranks, one process per GPU: a native communicator (RCCL all-gather on the engine's stream, or -- ranks
+  // sharing one GPU, tests only -- a host shared-memory exchange) or a caller-supplied hook
+  gph_comm *comm = nullptr;
   gph_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
+  bool force_host = false;           // GPH_HOST_DECISIONS=1: decisions on the host although nothing requires it (tests)
+  int64_t n_syncs = 0, n_collectives = 0, n_launches = 0;   // host synchronisations / cross-rank exchanges / kernel launches so far
   uint32_t seedz = 0;
   bool loaded = false, seeded = false, model_set = false, initialized = false;
   GphKargs ka;                 // first argument of every kernel: model, layout, math constants, table addresses
-  bool timing_pending = false; // HIP events of the last launch recorded, elapsed time not read yet
   bool sync_pending = false;   // synchronizeEvents of the finished iteration rides at the head of the next sweep kernel
   gph_counters counters = {0, 0, 0.0, 0};
   double last_ms[16] = {0};
-  // per kernel class: launches, summed HIP-event ms, evaluations, algorithmic bytes
-  double cls_launches[16] = {0}, cls_ms[16] = {0}, cls_evals[16] = {0}, cls_bytes[16] = {0}, cls_nodes[16] = {0};
+  // per kernel class: launches, summed HIP-event ms; evaluations / bytes / nodes live in the chain state
+  double cls_launches[16] = {0}, cls_ms[16] = {0};
+  double cls_evals0[16] = {0}, cls_bytes0[16] = {0}, cls_nodes0[16] = {0};   // offsets of the last reset
   int last_which = 0;
+  uint32_t timing_mask = 0xffffffffu;   // classes whose launches are bracketed by HIP events
 #ifndef GPH_HOSTEMU
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipEvent_t aev0 = nullptr, aev1 = nullptr;   // bracket the last launch that was NOT followed by a reduction
-  int async_which = -1;                         // its class while the elapsed time has not been read yet
+  struct Tm { hipEvent_t a, b; int which; };
+  std::vector<Tm> tm;                // event pairs of the launches since the last synchronisation
+  size_t tm_used = 0;
 #else
   std::vector<char> lds;
 #endif
@@ -251,7 +317,7 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
 
 static void build_model_static(gph_engine *e)
 {
-  GphModel &m = e->model;
+  GphModel &m = e->G_h->model;
   const gph_config &c = e->cfg;
   memset(&m, 0, sizeof m);
   for (int p = 0; p < c.K; p++) {
@@ -275,6 +341,9 @@ static void build_model_static(gph_engine *e)
     o.push_back(pop); } };
   Rec::go(e, c.rootPop, order);
   for (size_t i = 0; i < order.size(); i++) m.postOrder[i] = order[i];
+  GphGlobal &G = *e->G_h;
+  G.n = c.n; G.K = c.K; G.Kc = c.Kc; G.B = c.B; G.rootPop = c.rootPop; G.Ltot = (double)c.L_total;
+  G.tau_limit = (long long)1 << 62;
 }
 
 // ---------------------------------------------------------------- runtime shim
@@ -283,15 +352,23 @@ static int dev_alloc(void **p, size_t bytes) { *p = calloc(1, bytes ? bytes : 1)
 static void dev_free(void *p) { free(p); }
 static int h2d(gph_engine *, void *d, const void *h, size_t n) { memcpy(d, h, n); return 0; }
 static int d2h(gph_engine *, void *h, const void *d, size_t n) { memcpy(h, d, n); return 0; }
-static int upload_tables(gph_engine *e) { g_lay = e->lay; g_model = e->model; return 0; }
-#define LAUNCH(e, which, name, ...) do { g_model = (e)->model; \
-    g_lay = (e)->lay; GphKargs &ka_ = (e)->ka; ka_.model = (e)->model; ka_.lay = (e)->lay; \
+static int stream_sync(gph_engine *e) { e->n_syncs++; return 0; }
+#define LAUNCH_PRE(e) do { g_model = (e)->G_h->model; g_lay = (e)->lay; gph_G_emu = (e)->G_h; \
+    GphKargs &ka_ = (e)->ka; ka_.model = (e)->G_h->model; ka_.lay = (e)->lay; ka_.G = (e)->G_h; } while (0)
+#define LAUNCH(e, which, name, ...) do { LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
     for (auto &bk_ : (e)->buckets) { (e)->lds.assign(bk_.lds_bytes + 8 * (e)->lay.Pmax + 64, 0); /* the host form keeps per-pattern terms for every P */ gph_sm = (e)->lds.data(); \
       for (int b_ = 0; b_ < bk_.count; b_++) name(b_, ka_, (e)->dev, bk_.j0, __VA_ARGS__); } \
-    (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
+    (e)->last_which = (which); (e)->cls_launches[which] += 1; (e)->n_launches++; } while (0)
 #else
 static int dev_alloc(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess ? 0 : GPH_EHIP; }
 static void dev_free(void *p) { if (p) (void)hipFree(p); }
+static int collect_times(gph_engine *e);
+static int stream_sync(gph_engine *e)
+{
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->n_syncs++;
+  return collect_times(e);
+}
 static int h2d(gph_engine *e, void *d, const void *h, size_t n)
 {
   HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, e->stream));
@@ -304,124 +381,238 @@ static int d2h(gph_engine *e, void *h, const void *d, size_t n)
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
 }
-// model + layout tables are a by-value kernel argument (GphKargs): nothing to upload
-static int upload_tables(gph_engine *) { return 0; }
-// timed launch: HIP events on the engine's own stream bracket the kernel.  One dispatch covers every
-// locus with at most one pattern per lane (slots in decreasing P: longest wavefronts first), a second one
-// the rare loci with more (they also need the per-pattern terms array in LDS)
-#define LAUNCH(e, which, name, ...) do { \
-    GphKargs &ka_ = (e)->ka; ka_.model = (e)->model; ka_.lay = (e)->lay; \
-    HIPCHK(hipEventRecord((e)->ev0, (e)->stream)); \
-    for (auto &bk_ : (e)->buckets) { \
-      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
-      HIPCHK(hipGetLastError()); } \
-    HIPCHK(hipEventRecord((e)->ev1, (e)->stream)); \
-    (e)->last_which = (which); (e)->cls_launches[which] += 1; (e)->timing_pending = true; } while (0)   /* elapsed time is read in finish_kernel(), after the result copy has synchronised the stream */
-#endif
-
-// a launch whose per-locus outputs nobody waits for (commit / revert of a global proposal): no reduction, no host
-// synchronisation -- the stream orders it before the next kernel, an error raises the sticky flag D.err that the
-// next reduction reports, and the elapsed time is read at the next synchronisation point
-#ifdef GPH_HOSTEMU
-#define LAUNCH_ASYNC(e, which, name, ...) LAUNCH(e, which, name, __VA_ARGS__)
-static int collect_async_time(gph_engine *) { return 0; }
-#else
-static int collect_async_time(gph_engine *e)
+// elapsed times of the launches bracketed since the last synchronisation (the stream is idle: every event is complete)
+static int collect_times(gph_engine *e)
 {
-  if (e->async_which >= 0) {
+  for (size_t i = 0; i < e->tm_used; i++) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, e->aev0, e->aev1) == hipSuccess) { e->last_ms[e->async_which] = ms; e->cls_ms[e->async_which] += ms; }
-    e->async_which = -1;
+    if (hipEventElapsedTime(&ms, e->tm[i].a, e->tm[i].b) == hipSuccess) { e->last_ms[e->tm[i].which] = ms; e->cls_ms[e->tm[i].which] += ms; }
   }
+  e->tm_used = 0;
   return 0;
 }
-#define LAUNCH_ASYNC(e, which, name, ...) do { \
-    GphKargs &ka_ = (e)->ka; ka_.model = (e)->model; ka_.lay = (e)->lay; \
-    if ((e)->async_which >= 0) { (void)hipEventSynchronize((e)->aev1); collect_async_time(e); } \
-    HIPCHK(hipEventRecord((e)->aev0, (e)->stream)); \
+static int tm_begin(gph_engine *e, int which)
+{
+  if (!((e->timing_mask >> which) & 1)) return -1;
+  if (e->tm_used == e->tm.size()) {
+    gph_engine::Tm t;
+    if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return -1;
+    e->tm.push_back(t);
+  }
+  e->tm[e->tm_used].which = which;
+  (void)hipEventRecord(e->tm[e->tm_used].a, e->stream);
+  return (int)e->tm_used++;
+}
+static void tm_end(gph_engine *e, int slot) { if (slot >= 0) (void)hipEventRecord(e->tm[slot].b, e->stream); }
+// timed launch: HIP events on the engine's own stream bracket the kernel.  One dispatch covers every
+// locus with at most one pattern per lane (slots in decreasing P: longest wavefronts first), a second one
+// the rare loci with more (they also need the per-pattern terms array in LDS).  No host synchronisation here.
+#define LAUNCH_PRE(e) do { GphKargs &ka_ = (e)->ka; ka_.model = (e)->G_h->model; ka_.lay = (e)->lay; ka_.G = (e)->G_d; } while (0)
+#define LAUNCH(e, which, name, ...) do { LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
+    const int tms_ = tm_begin((e), (which)); \
     for (auto &bk_ : (e)->buckets) { \
       hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
-      HIPCHK(hipGetLastError()); } \
-    HIPCHK(hipEventRecord((e)->aev1, (e)->stream)); \
-    (e)->async_which = (which); (e)->cls_launches[which] += 1; } while (0)
+      HIPCHK(hipGetLastError()); (e)->n_launches++; } \
+    tm_end((e), tms_); \
+    (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
 #endif
 
 // one single-wave workgroup with its own dynamic-LDS size (the serial scan of UpdateLocusRate)
 #ifdef GPH_HOSTEMU
-#define LAUNCH1(e, which, name, ldsbytes, ...) do { g_model = (e)->model; \
-    g_lay = (e)->lay; GphKargs &ka_ = (e)->ka; ka_.model = (e)->model; ka_.lay = (e)->lay; \
+#define LAUNCH1(e, which, name, ldsbytes, ...) do { LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
     (e)->lds.assign((size_t)(ldsbytes) + 64, 0); gph_sm = (e)->lds.data(); \
     name(0, ka_, (e)->dev, 0, __VA_ARGS__); \
     (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
 #else
-#define LAUNCH1(e, which, name, ldsbytes, ...) do { \
-    GphKargs &ka_ = (e)->ka; ka_.model = (e)->model; ka_.lay = (e)->lay; \
-    HIPCHK(hipEventRecord((e)->ev0, (e)->stream)); \
+#define LAUNCH1(e, which, name, ldsbytes, ...) do { LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
+    const int tms_ = tm_begin((e), (which)); \
     hipLaunchKernelGGL(name, dim3(1), dim3(GPH_WAVE), (ldsbytes), (e)->stream, ka_, (e)->dev, 0, __VA_ARGS__); \
     HIPCHK(hipGetLastError()); \
-    HIPCHK(hipEventRecord((e)->ev1, (e)->stream)); \
-    (e)->last_which = (which); (e)->cls_launches[which] += 1; (e)->timing_pending = true; } while (0)
+    tm_end((e), tms_); \
+    (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
 #endif
 
-// reduce the per-locus outputs (mode 0) or page statistics (mode 1) over local loci
-static int reduce_local(gph_engine *e, int mode, int ncols)
+// host mirror -> HBM (the host changed settings or, in host mode, took a decision); a synchronous copy: the mirror
+// may be modified again as soon as this returns
+static int push_G(gph_engine *e)
+{
+  e->G_dirty = false;
+#ifdef GPH_HOSTEMU
+  return 0;
+#else
+  HIPCHK(hipMemcpyAsync(e->G_d, e->G_h, sizeof(GphGlobal), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+#endif
+}
+// HBM -> host mirror, with a host synchronisation (the end of an iteration in resident mode)
+static int pull_G(gph_engine *e)
 {
 #ifdef GPH_HOSTEMU
+  e->n_syncs++;
+  return 0;
+#else
+  HIPCHK(hipMemcpyAsync(e->G_h, e->G_d, sizeof(GphGlobal), hipMemcpyDeviceToHost, e->stream));
+  return stream_sync(e);
+#endif
+}
+#define PUSH_IF_DIRTY(e) do { if ((e)->G_dirty) { int rcp_ = push_G(e); if (rcp_) return rcp_; } } while (0)
+
+// are the decisions above the loci taken on the device?  Yes unless something forces a host synchronisation at every
+// reduction point anyway: a caller-supplied all-reduce hook, the host shared-memory exchange of ranks that share a
+// GPU, the host-emulation build, or GPH_HOST_DECISIONS=1 (tests compare the two modes)
+static bool resident(const gph_engine *e)
+{
+#ifdef GPH_HOSTEMU
+  (void)e;
+  return false;
+#else
+  if (e->force_host || e->allreduce || e->var_rates) return false;
+  if (e->comm && !gph_comm_on_stream(e->comm)) return false;
+  return true;
+#endif
+}
+static int world_of(const gph_engine *e) { return e->comm ? gph_comm_world(e->comm) : 1; }
+
+// reduce the per-locus outputs (section 0) or the page statistics (section 1) over the local loci into this rank's row
+static int reduce_local(gph_engine *e, int sec, int ncols)
+{
+#ifdef GPH_HOSTEMU
+  double *red = e->d_red + sec * GPH_RED_STRIDE;
   for (int c = 0; c < ncols; c++) {
     double s = 0, mn = 1e300, mx = -1e300;
     for (int64_t g = 0; g < e->L; g++) {
       double v;
-      if (mode == 0) v = e->dev.out[(size_t)g * GPH_OUT_SLOTS + c];
+      if (sec == 0) v = e->dev.out[(size_t)g * GPH_OUT_SLOTS + c];
       else v = e->dev.stats[(size_t)g * ncols + c];
       s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
     }
-    e->h_red[c] = s; e->h_red[GPH_RED_COLS + c] = mn; e->h_red[2 * GPH_RED_COLS + c] = mx;
+    red[c] = s; red[GPH_RED_COLS + c] = mn; red[2 * GPH_RED_COLS + c] = mx;
   }
-  e->h_red[3 * GPH_RED_COLS] = (double)*e->dev.err;
+  red[3 * GPH_RED_COLS] = (double)*e->dev.err;
   return 0;
 #else
-  hipLaunchKernelGGL(k_reduce_partial, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_SUBS * 64), 0, e->stream, e->dev, mode, ncols, e->d_part);
-  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(GPH_RED_SUBS * GPH_RED_COLS), 0, e->stream, ncols, e->d_part, e->d_red, e->dev.err);
+  hipLaunchKernelGGL(k_reduce_partial, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_SUBS * 64), 0, e->stream, e->dev, sec, ncols, e->d_part);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(GPH_RED_SUBS * GPH_RED_COLS), 0, e->stream, ncols, e->d_part, e->d_red + sec * GPH_RED_STRIDE, e->dev.err);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(e->stream));   /* the final pass wrote h_red through the mapping: no copy to wait for */
+  e->n_launches += 2;
   return 0;
 #endif
 }
-#define RSUM(e, c) ((e)->h_red[(c)])
-#define RMIN(e, c) ((e)->h_red[GPH_RED_COLS + (c)])
-#define RMAX(e, c) ((e)->h_red[2 * GPH_RED_COLS + (c)])
+static int reduce_stats(gph_engine *e) { return reduce_local(e, 1, 2 * e->cfg.K + 2 * e->cfg.B); }
 
-static int finish_kernel(gph_engine *e)
+// which columns of the reduced row a stage consumes (host mode with a caller-supplied all-reduce hook: only these
+// travel): sums / minima / maxima as (section, column) pairs; every stage that follows a locus kernel also takes the
+// counters and the error words
+struct StageCols { int ns = 0, nm = 0, nx = 0; int s[160][2], m[8][2], x[8][2]; };
+static void stage_columns(const gph_engine *e, int stage, StageCols &c)
 {
-  int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
-  if (rc) return rc;
+  const int C = 2 * e->cfg.K + 2 * e->cfg.B;
+  auto S = [&](int sec, int col) { c.s[c.ns][0] = sec; c.s[c.ns][1] = col; c.ns++; };
+  auto M = [&](int sec, int col) { c.m[c.nm][0] = sec; c.m[c.nm][1] = col; c.nm++; };
+  auto X = [&](int sec, int col) { c.x[c.nx][0] = sec; c.x[c.nx][1] = col; c.nx++; };
+  auto counters = [&]() { S(0, 8); S(0, 9); S(0, 10); S(0, 13); X(0, 11); X(0, -1); };
+  auto totals = [&]() { for (int k = 0; k < C; k++) S(1, k); };
+  switch (stage) {
+  case GS_INIT_DONE: counters(); S(0, 0); S(0, 1); totals(); break;
+  case GS_SWEEP_DONE: counters(); for (int k = 0; k < 8; k++) S(0, k); S(0, 12); M(0, 15); totals(); break;
+  case GS_TOTALS: totals(); break;
+  case GS_TAU_DECIDE: case GS_SAGE_DECIDE: counters(); S(0, 0); S(0, 1); S(0, 3); S(0, 4); M(0, 14); break;
+  case GS_MIX_DECIDE: counters(); S(0, 0); break;
+  case GS_REFRESH_DONE: counters(); M(0, 0); S(0, 1); S(0, 2); break;
+  case GS_CHECK_DONE: counters(); M(0, 0); S(0, 1); S(0, 2); totals(); break;
+  case GS_COUNT_ONLY: counters(); S(0, 0); S(0, 1); S(0, 3); S(0, 4); M(0, 14); break;   /* + what the stepwise evaluate calls return */
+  default: break;
+  }
+}
+static bool stage_reads_row(int stage)
+{
+  switch (stage) {
+  case GS_INIT_DONE: case GS_SWEEP_DONE: case GS_TOTALS: case GS_TAU_DECIDE: case GS_SAGE_DECIDE: case GS_MIX_DECIDE:
+  case GS_REFRESH_DONE: case GS_CHECK_DONE: case GS_COUNT_ONLY: return true;
+  default: return false;
+  }
+}
+static double *colp(double *row, const int sc[2], int kind)   /* kind 0 sum, 1 min, 2 max; column -1 = the error word */
+{
+  if (sc[1] < 0) return row + 3 * GPH_RED_COLS;
+  return row + sc[0] * GPH_RED_STRIDE + kind * GPH_RED_COLS + sc[1];
+}
+
+// one stage above the loci (gph_global.h: gg_stage) on the reduced row(s) of the launch(es) before it.
+// resident mode: [all-gather on the stream] + k_global, no host synchronisation.
+// host mode: synchronise, fetch this rank's row, combine it over the ranks (hook or shared-memory exchange), run
+// gg_stage on the host mirror and push the mirror.
+static int run_stage(gph_engine *e, int stage, int arg, int iteration)
+{
+  const bool reads = stage_reads_row(stage);
 #ifndef GPH_HOSTEMU
-  collect_async_time(e);
-  if (e->timing_pending) {   /* the reduction above synchronised the stream: both events are complete */
-    float ms = 0;
-    e->timing_pending = false;
-    HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    e->last_ms[e->last_which] = ms;
-    e->cls_ms[e->last_which] += ms;
+  if (resident(e)) {
+    const double *rows = e->d_red;
+    int world = 1;
+    if (e->comm && reads) {
+      int rc = gph_comm_allgather_stream(e->comm, e->d_red, e->d_gather, GPH_RED_ROW, (void *)e->stream);
+      if (rc) return GPH_EHIP;
+      e->n_collectives++;
+      rows = e->d_gather;
+      world = gph_comm_world(e->comm);
+    }
+    LAUNCH_PRE(e);
+    hipLaunchKernelGGL(k_global, dim3(1), dim3(64), 0, e->stream, e->ka, rows, world, stage, arg, iteration);
+    HIPCHK(hipGetLastError());
+    e->n_launches++;
+    return 0;
   }
 #endif
-  e->counters.evals += (int64_t)RSUM(e, 8);
-  e->counters.eval_nodes += (int64_t)RSUM(e, 9);
-  e->counters.eval_bytes += RSUM(e, 10);
-  e->counters.not_enough_migs += (int64_t)RSUM(e, 13);
-  e->cls_evals[e->last_which] += RSUM(e, 8);
-  e->cls_nodes[e->last_which] += RSUM(e, 9);
-  e->cls_bytes[e->last_which] += RSUM(e, 10);
-  if (RMAX(e, 11) != 0.0 || e->h_red[3 * GPH_RED_COLS] != 0.0) {
-    fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by a locus kernel\n", (int)(RMAX(e, 11) != 0.0 ? RMAX(e, 11) : e->h_red[3 * GPH_RED_COLS]));
+  GphRed R;
+  R.rows = e->h_red; R.world = 1;
+  if (reads) {
+#ifdef GPH_HOSTEMU
+    memcpy(e->h_red, e->d_red, sizeof(double) * GPH_RED_ROW);
+    e->n_syncs++;
+#else
+    HIPCHK(hipMemcpyAsync(e->h_red, e->d_red, sizeof(double) * GPH_RED_ROW, hipMemcpyDeviceToHost, e->stream));
+    { int rcs = stream_sync(e); if (rcs) return rcs; }
+#endif
+    if (e->allreduce || e->comm) {
+      StageCols c;
+      stage_columns(e, stage, c);
+      double sums[160], mins[16];
+      for (int k = 0; k < c.ns; k++) sums[k] = *colp(e->h_red, c.s[k], 0);
+      for (int k = 0; k < c.nm; k++) mins[k] = *colp(e->h_red, c.m[k], 1);
+      for (int k = 0; k < c.nx; k++) mins[c.nm + k] = -*colp(e->h_red, c.x[k], 2);   /* a maximum as the minimum of the negatives */
+      int rc = 0;
+      if (e->allreduce) rc = e->allreduce(e->allreduce_user, sums, c.ns, mins, c.nm + c.nx);
+      else rc = gph_comm_allreduce_host(e->comm, sums, c.ns, mins, c.nm + c.nx);
+      if (rc) return GPH_EHIP;
+      e->n_collectives++;
+      for (int k = 0; k < c.ns; k++) *colp(e->h_red, c.s[k], 0) = sums[k];
+      for (int k = 0; k < c.nm; k++) *colp(e->h_red, c.m[k], 1) = mins[k];
+      for (int k = 0; k < c.nx; k++) *colp(e->h_red, c.x[k], 2) = -mins[c.nm + k];
+    }
+  }
+  e->G_h->iteration = iteration;
+  gg_stage(*e->G_h, R, stage, arg);
+  return push_G(e);
+}
+
+// after a host synchronisation: the error the stages recorded, the counters
+static int check_error(gph_engine *e)
+{
+  const int code = e->G_h->error;
+  if (code != 0) {
+    if (code == 75) fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n");
+    else if (code == 9999) fprintf(stderr, "gphocs_hip: checkAll failed at iteration %d\n", e->G_h->iteration);
+    else fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by a locus kernel\n", code);
     return GPH_EKERNEL;
   }
   return 0;
 }
-static int xreduce(gph_engine *e, double *sums, int nsum, double *mins, int nmin)
+// the mirror is current (host mode: always; resident mode: after pull_G)
+static int finish_sync(gph_engine *e)
 {
-  if (e->allreduce) return e->allreduce(e->allreduce_user, sums, nsum, mins, nmin) ? GPH_EHIP : 0;
-  return 0;
+  if (resident(e)) { int rc = pull_G(e); if (rc) return rc; }
+  return check_error(e);
 }
 
 // run a deferred synchronizeEvents pass now (anything but the next genealogy sweep is about to touch the pages)
@@ -429,12 +620,11 @@ static int flush_sync(gph_engine *e)
 {
   if (!e->sync_pending) return 0;
   e->sync_pending = false;
-  e->totals_valid = false;
+  PUSH_IF_DIRTY(e);
   LAUNCH(e, 8, k_sync, 0);
-  int rc = finish_kernel(e);
+  int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
   if (rc) return rc;
-  if (RMIN(e, 0) < 1.0) { fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n"); return GPH_EKERNEL; }
-  return 0;
+  return run_stage(e, GS_REFRESH_DONE, 0, e->G_h->iteration);
 }
 
 // exp/log/rndu constants of gph_math.h / gph_locus.h (GphKargs::mathc) and, on the device, the addresses of the two
@@ -457,7 +647,21 @@ static int fill_math_tables(GphKargs &ka)
   ka.exp_t = (const uint64_t *)p;
   return 0;
 }
+#define SETDEV(e) do { if (hipSetDevice((e)->cfg.device) != hipSuccess) return GPH_EHIP; } while (0)
+#else
+#define SETDEV(e) ((void)0)
 #endif
+
+// a stage whose result the CALLER needs now (the stepwise entry points of the C ABI): host path whatever the mode
+static int run_stage_now(gph_engine *e, int stage, int arg)
+{
+  const bool fh = e->force_host;
+  e->force_host = true;
+  int rc = run_stage(e, stage, arg, e->G_h->iteration);
+  e->force_host = fh;
+  if (rc) return rc;
+  return check_error(e);
+}
 
 // ---------------------------------------------------------------- C ABI
 extern "C" {
@@ -465,8 +669,11 @@ extern "C" {
 int gph_engine_create(const gph_config *cfg, gph_engine **out)
 {
   if (!cfg || !out) return GPH_EARG;
+  if (cfg->n > 200 || cfg->K > 39 || cfg->B > 100)
+    fprintf(stderr, "gphocs_hip: n=%d K=%d B=%d exceed even the reference's compile-time caps (NS 200, 2*NSPECIES-1 = 39, MAX_MIG_BANDS 100: upstream src/patch.h:17-22)\n", cfg->n, cfg->K, cfg->B);
   if (cfg->n < 2 || cfg->n > GPH_CAP_LEAVES || cfg->K > GPH_CAP_K || cfg->B > GPH_CAP_B || cfg->K != 2 * cfg->Kc - 1) {
-    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (compiled capacities: n<=%d, K<=%d, B<=%d; rebuild with -DGPH_CAP_*)\n", cfg->n, cfg->K, cfg->B, GPH_CAP_LEAVES, GPH_CAP_K, GPH_CAP_B);
+    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (this library variant: n<=%d leaves, K<=%d populations, B<=%d bands; the engine's hard caps are 32 / 32 / 16 -- one genealogy node per lane, 32-bit population masks -- against the reference's 200 / 39 / 100, upstream src/patch.h:17-22; rebuild with -DGPH_CAP_* up to the hard caps)\n",
+            cfg->n, cfg->K, cfg->B, GPH_CAP_LEAVES, GPH_CAP_K, GPH_CAP_B);
     return GPH_EARG;
   }
   gph_engine *e = new gph_engine();
@@ -485,7 +692,7 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
   memset(&e->dev, 0, sizeof e->dev);
   memset(&e->ka, 0, sizeof e->ka);
   fill_math_constants(e->ka);
-  build_model_static(e);
+  if (const char *fh = getenv("GPH_HOST_DECISIONS")) e->force_host = atoi(fh) != 0;
 #ifndef GPH_HOSTEMU
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) {
@@ -498,10 +705,22 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
     delete e;
     return GPH_EHIP;
   }
-  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess ||
-      hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess ||
-      hipEventCreate(&e->aev0) != hipSuccess || hipEventCreate(&e->aev1) != hipSuccess) { delete e; return GPH_EHIP; }
+  if (hipStreamCreate(&e->stream) != hipSuccess ||
+      hipHostMalloc((void **)&e->G_h, sizeof(GphGlobal), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void **)&e->G_d, sizeof(GphGlobal)) != hipSuccess ||
+      hipHostMalloc((void **)&e->h_red, sizeof(double) * GPH_RED_ROW * 64, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void **)&e->d_red, sizeof(double) * GPH_RED_ROW) != hipSuccess ||
+      hipMemset(e->d_red, 0, sizeof(double) * GPH_RED_ROW) != hipSuccess) { gph_engine_destroy(e); return GPH_EHIP; }
+  e->d_gather = e->d_red;
+#else
+  e->G_h = (GphGlobal *)calloc(1, sizeof(GphGlobal));
+  e->G_d = e->G_h;
+  e->h_red = (double *)calloc(GPH_RED_ROW, sizeof(double));
+  e->d_red = (double *)calloc(GPH_RED_ROW, sizeof(double));
+  e->d_gather = e->d_red;
 #endif
+  memset(e->G_h, 0, sizeof(GphGlobal));
+  build_model_static(e);
   *out = e;
   return 0;
 }
@@ -513,14 +732,16 @@ void gph_engine_destroy(gph_engine *e)
   dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
   dev_free(e->d_lrec); dev_free(e->d_lpre); dev_free(e->d_slot_of); dev_free(e->d_lr_result); dev_free(e->d_lr_gscr); dev_free(e->d_ref_page); dev_free(e->d_ref_seq);
   dev_free(e->d_part); dev_free(e->dev.err);
+  if (e->d_gather != e->d_red) dev_free(e->d_gather);
+  dev_free(e->d_red);
 #ifdef GPH_HOSTEMU
   free(e->h_red);
+  free(e->G_h);
 #else
+  dev_free(e->G_d);
   if (e->h_red) (void)hipHostFree(e->h_red);
-  if (e->ev0) (void)hipEventDestroy(e->ev0);
-  if (e->ev1) (void)hipEventDestroy(e->ev1);
-  if (e->aev0) (void)hipEventDestroy(e->aev0);
-  if (e->aev1) (void)hipEventDestroy(e->aev1);
+  if (e->G_h) (void)hipHostFree(e->G_h);
+  for (auto &t : e->tm) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
 #endif
   delete e;
@@ -534,10 +755,30 @@ int gph_engine_set_allreduce(gph_engine *e, gph_allreduce_fn fn, void *user)
   return 0;
 }
 
+// native communicator (gph_comm.h): RCCL over xGMI, one rank per GPU, all-gathers queued on the engine's stream; or the
+// host shared-memory exchange for ranks that share a GPU.  The engine does not own it.
+int gph_engine_set_comm(gph_engine *e, gph_comm *c)
+{
+  if (!e) return GPH_EARG;
+  SETDEV(e);
+  e->comm = c;
+  if (e->d_gather != e->d_red) { dev_free(e->d_gather); e->d_gather = e->d_red; }
+  if (c && gph_comm_world(c) > 1 && gph_comm_on_stream(c)) {
+    if (gph_comm_world(c) > 64) return GPH_EARG;
+    if (dev_alloc((void **)&e->d_gather, sizeof(double) * GPH_RED_ROW * gph_comm_world(c))) return GPH_EHIP;
+  }
+  return 0;
+}
+
+GphGlobal *gph_engine_global_(gph_engine *e) { if (!e) return nullptr; e->G_dirty = true; return e->G_h; }
+const GphGlobal *gph_engine_global_ro_(gph_engine *e) { return e ? e->G_h : nullptr; }
+
 int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const uint8_t *leafcodes,
-                         const uint8_t *numPhases, const int32_t *counts, const double *mutRates)
+                         const uint16_t *numPhases, const int32_t *counts, const double *mutRates)
 {
   if (!e || L <= 0 || !poff || !leafcodes || !numPhases || !counts) return GPH_EARG;
+  if (e->loaded) { fprintf(stderr, "gphocs_hip: gph_engine_load_loci called twice on one engine\n"); return GPH_ESTATE; }
+  SETDEV(e);
   const int n = e->cfg.n;
   int Pmax = 1;
   for (int64_t g = 0; g < L; g++) { int P = (int)(poff[g + 1] - poff[g]); if (P > Pmax) Pmax = P; if (P < 0) return GPH_EARG; }   /* P == 0: a locus with no informative column (all N) is legal upstream */
@@ -600,7 +841,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
         if (c > 4) return GPH_EARG;
         blk[GPH_Q_LEAF + p * n + i] = (char)c;
       }
-      blk[GPH_Q_PHASES(P, n) + p] = (char)numPhases[poff[g] + p];
+      ((uint16_t *)(blk + GPH_Q_PHASES(P, n)))[p] = numPhases[poff[g] + p];
       ((int32_t *)(blk + GPH_Q_COUNT(P, n)))[p] = counts[poff[g] + p];
     }
   }
@@ -625,12 +866,6 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
 #else
   if (!rc && hipMemset(e->dev.err, 0, sizeof(int32_t)) != hipSuccess) rc = GPH_EHIP;
 #endif
-#ifdef GPH_HOSTEMU
-  if (!e->h_red) e->h_red = (double *)calloc(3 * GPH_RED_COLS + 1, sizeof(double));
-#else
-  if (!e->h_red && (hipHostMalloc((void **)&e->h_red, sizeof(double) * (3 * GPH_RED_COLS + 1), hipHostMallocMapped) != hipSuccess ||
-                    hipHostGetDevicePointer((void **)&e->d_red, e->h_red, 0) != hipSuccess)) rc = GPH_EHIP;
-#endif
   if (mutRates) rc |= dev_alloc((void **)&e->d_mutRate, sizeof(double) * L);
   if (rc) { fprintf(stderr, "gphocs_hip: device allocation failed\n"); return GPH_EHIP; }
   rc |= h2d(e, (void *)e->dev.cond_off, e->h_cond_off.data(), sizeof(uint64_t) * (L + 1));
@@ -646,8 +881,8 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   e->loaded = true;
 #ifndef GPH_HOSTEMU
   // per-locus kernels use up to the wide group's dynamic LDS size; allow > 64 KiB
-  const void *ks[] = {(const void *)k_init, (const void *)k_sweep, (const void *)k_tau_eval, (const void *)k_tau_commit,
-                      (const void *)k_tau_revert, (const void *)k_mix_eval, (const void *)k_mix_commit,
+  const void *ks[] = {(const void *)k_init, (const void *)k_sweep, (const void *)k_tau_eval, (const void *)k_tau_finish,
+                      (const void *)k_mix_eval, (const void *)k_mix_finish,
                       (const void *)k_sync, (const void *)k_check, (const void *)k_lrate_apply, (const void *)k_lrate_prep};
   for (auto k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, e->lay.lds_bytes));
 #endif
@@ -658,9 +893,11 @@ int gph_engine_set_model(gph_engine *e, const double *theta, const double *popAg
                          const double *migRate, const double *bandStart, const double *bandEnd)
 {
   if (!e || !theta || !popAge || !sampleAge) return GPH_EARG;
-  for (int p = 0; p < e->cfg.K; p++) { e->model.theta[p] = theta[p]; e->model.thetaInv[p] = 1.0 / theta[p]; e->model.popAge[p] = popAge[p]; e->model.sampleAge[p] = sampleAge[p]; }
-  for (int b = 0; b < e->cfg.B; b++) { e->model.migRate[b] = migRate[b]; e->model.bandStart[b] = bandStart[b]; e->model.bandEnd[b] = bandEnd[b]; }
+  GphModel &m = e->G_h->model;
+  for (int p = 0; p < e->cfg.K; p++) { m.theta[p] = theta[p]; m.thetaInv[p] = 1.0 / theta[p]; m.popAge[p] = popAge[p]; m.sampleAge[p] = sampleAge[p]; }
+  for (int b = 0; b < e->cfg.B; b++) { m.migRate[b] = migRate[b]; m.bandStart[b] = bandStart[b]; m.bandEnd[b] = bandEnd[b]; }
   e->model_set = true;
+  e->G_dirty = true;
   return 0;
 }
 
@@ -675,55 +912,61 @@ int gph_engine_seed(gph_engine *e, uint32_t seed)
 int gph_engine_init_genealogies(gph_engine *e, double *sumGen, double *sumData)
 {
   if (!e || !e->loaded || !e->seeded || !e->model_set) return GPH_ESTATE;
-  e->totals_valid = false;
+  SETDEV(e);
+  PUSH_IF_DIRTY(e);
   LAUNCH(e, 3, k_init, e->seedz, (const double *)e->d_mutRate, e->init_predraws);
-  int rc = finish_kernel(e);
+  int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
+  if (!rc) rc = reduce_stats(e);
   if (rc) return rc;
-  double s[2] = {RSUM(e, 0), RSUM(e, 1)};
-  rc = xreduce(e, s, 2, nullptr, 0);
-  if (sumGen) *sumGen = s[0];
-  if (sumData) *sumData = s[1];
+  e->G_h->nrec = 0;
+  e->G_h->iteration = -1;
+  if ((rc = run_stage_now(e, GS_INIT_DONE, 0))) return rc;
+  { GphRed R; R.rows = e->h_red; R.world = 1;
+    if (sumGen) *sumGen = R.sum(0, 0);
+    if (sumData) *sumData = R.sum(0, 1); }
   e->initialized = true;
   return rc;
 }
 
+// ---- the stepwise entry points: one reference proposal function each (include/gphocs_hip.h), the result is on the
+// host when the call returns.  gph_engine_iteration_() below runs the same launches without the round trips.
 int gph_engine_genealogy_sweep(gph_engine *e, int32_t flags, double ftCoal, double ftMig, gph_sweep_result *out)
 {
   if (!e || !e->initialized || !out) return GPH_ESTATE;
+  SETDEV(e);
+  PUSH_IF_DIRTY(e);
   const int with_sync = e->sync_pending ? 8 : 0;   /* flag 8: synchronizeEvents first, in the same kernel */
   e->sync_pending = false;
+  GphGlobal &G = *e->G_h;
+  const double d0 = G.dataLogLikelihood, l0 = G.logLikelihood;
+  const int64_t a0 = G.acc[0], a1 = G.acc[1], a2 = G.acc[2], a7 = G.acc[7];
   LAUNCH(e, 0, k_sweep, (int)flags | with_sync, ftCoal, ftMig);
-  int rc = finish_kernel(e);
+  int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
+  if (!rc) rc = reduce_stats(e);
   if (rc) return rc;
-  if (with_sync && RMIN(e, 15) < 1.0) { fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n"); return GPH_EKERNEL; }
-  /* the statistics totals the host asks for next (computeTotalStats, patch.c:2134) ride in the same all-reduce */
-  const int C = 2 * e->cfg.K + 2 * e->cfg.B;
-  std::vector<double> s(9 + C);
-  { const double s9[9] = {RSUM(e, 0), RSUM(e, 1), RSUM(e, 2), RSUM(e, 3), RSUM(e, 4), RSUM(e, 5), RSUM(e, 6), RSUM(e, 7), RSUM(e, 12)};
-    for (int c = 0; c < 9; c++) s[c] = s9[c]; }
-  if ((rc = reduce_local(e, 1, C))) return rc;
-  for (int c = 0; c < C; c++) s[9 + c] = RSUM(e, c);
-  rc = xreduce(e, s.data(), 9 + C, nullptr, 0);
-  e->totals.assign(s.begin() + 9, s.end());
-  e->totals_valid = rc == 0;
-  out->accepted_internal = (int64_t)s[0];
-  out->accepted_mignode = (int64_t)s[1];
-  out->accepted_spr = (int64_t)s[2];
-  out->dData_internal = s[3];
-  out->dLog_internal = s[4];
-  out->dLog_mignode = s[5];
-  out->dData_spr = s[6];
-  out->dLog_spr = s[7];
-  out->total_mig_nodes = (int64_t)s[8];
-  return rc;
+  if ((rc = run_stage_now(e, GS_SWEEP_DONE, with_sync))) return rc;
+  /* the per-class deltas, as the caller adds them (GPhoCS.c:1495-1545) */
+  GphRed R; R.rows = e->h_red; R.world = 1;
+  out->accepted_internal = G.acc[0] - a0;
+  out->accepted_mignode = G.acc[1] - a1;
+  out->accepted_spr = G.acc[2] - a2;
+  out->total_mig_nodes = G.acc[7] - a7;
+  out->dData_internal = R.sum(0, 3);
+  out->dLog_internal = R.sum(0, 4);
+  out->dLog_mignode = R.sum(0, 5);
+  out->dData_spr = R.sum(0, 6);
+  out->dLog_spr = R.sum(0, 7);
+  (void)d0; (void)l0;
+  return 0;
 }
 
 int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result *out)
 {
   if (!e || !e->initialized || !a || !out) return GPH_ESTATE;
   if (a->num_aff > 2 * GPH_MAXB) return GPH_EARG;
+  SETDEV(e);
   { int rcs = flush_sync(e); if (rcs) return rcs; }
-  GphTauArgs &A = e->tau;
+  GphTauArgs &A = e->G_h->tau;
   memset(&A, 0, sizeof A);
   A.ap = a->ap; A.son0 = a->son0; A.son1 = a->son1; A.isRoot = a->isRoot; A.num_aff = a->num_aff; A.mode = a->mode;
   A.tauold = a->tauold; A.taunew = a->taunew; A.taub0 = a->taub0; A.taub1 = a->taub1;
@@ -733,57 +976,70 @@ int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result
     A.start_or_end[i] = a->start_or_end[i];
     A.new_band_ages[i] = a->new_band_ages[i];
   }
-  LAUNCH(e, 1, k_tau_eval, A);
-  int rc = finish_kernel(e);
+  int rc = push_G(e);
   if (rc) return rc;
+  LAUNCH(e, 1, k_tau_eval, 0);
+  if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+  if ((rc = run_stage_now(e, GS_COUNT_ONLY, 1))) return rc;
   // first conflicting locus in serial (input) order: loci after it were never touched by
-  // the reference; slot 14 holds the global index of a conflicting locus
-  double s[4] = {RSUM(e, 0), RSUM(e, 1), RSUM(e, 3), RSUM(e, 4)};
-  double mn[1] = {RMAX(e, 2) > 0.0 ? RMIN(e, 14) : 1e300};
-  rc = xreduce(e, s, 4, mn, 1);
-  out->ntj0 = (int64_t)s[0];
-  out->ntj1 = (int64_t)s[1];
-  out->genDelta = s[2];
-  out->dataDelta = s[3];
-  out->first_conflict_locus = mn[0] < 1e299 ? (int64_t)mn[0] : -1;
-  return rc;
+  // the reference; slot 14 holds the global index of a conflicting locus (1e300 = none)
+  GphRed R; R.rows = e->h_red; R.world = 1;   /* the row as combined over the ranks by run_stage */
+  out->ntj0 = (int64_t)R.sum(0, 0);
+  out->ntj1 = (int64_t)R.sum(0, 1);
+  out->genDelta = R.sum(0, 3);
+  out->dataDelta = R.sum(0, 4);
+  out->first_conflict_locus = R.mn(0, 14) < 1e299 ? (int64_t)R.mn(0, 14) : -1;
+  return 0;
 }
 
 int gph_engine_tau_commit(gph_engine *e)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
-  e->totals_valid = false;
-  LAUNCH_ASYNC(e, 5, k_tau_commit, e->tau);
+  SETDEV(e);
+  e->G_h->tau_flag = 1;
+  e->G_h->tau_limit = (long long)1 << 62;
+  int rc = push_G(e);
+  if (rc) return rc;
+  LAUNCH(e, 5, k_tau_finish, 0);
   return 0;
 }
 
 int gph_engine_tau_revert(gph_engine *e, int64_t first_conflict)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
-  long long limit = first_conflict >= 0 ? (long long)first_conflict : (long long)1 << 62;
-  e->totals_valid = false;
-  LAUNCH_ASYNC(e, 6, k_tau_revert, limit);
+  SETDEV(e);
+  e->G_h->tau_flag = 0;
+  e->G_h->tau_limit = first_conflict >= 0 ? (long long)first_conflict : (long long)1 << 62;
+  int rc = push_G(e);
+  if (rc) return rc;
+  LAUNCH(e, 5, k_tau_finish, 0);
   return 0;
 }
 
 int gph_engine_mixing_evaluate(gph_engine *e, double c, double *dataDelta)
 {
   if (!e || !e->initialized || !dataDelta) return GPH_ESTATE;
+  SETDEV(e);
   { int rcs = flush_sync(e); if (rcs) return rcs; }
-  LAUNCH(e, 2, k_mix_eval, c);
-  int rc = finish_kernel(e);
+  e->G_h->mix_c = c;
+  int rc = push_G(e);
   if (rc) return rc;
-  double s[1] = {RSUM(e, 0)};
-  rc = xreduce(e, s, 1, nullptr, 0);
-  *dataDelta = s[0];
-  return rc;
+  LAUNCH(e, 2, k_mix_eval, 0);
+  if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+  if ((rc = run_stage_now(e, GS_COUNT_ONLY, 2))) return rc;
+  GphRed R; R.rows = e->h_red; R.world = 1;
+  *dataDelta = R.sum(0, 0);
+  return 0;
 }
 
 int gph_engine_mixing_commit(gph_engine *e, double c, double lnc)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
-  e->totals_valid = false;
-  LAUNCH_ASYNC(e, 7, k_mix_commit, c, lnc);
+  SETDEV(e);
+  e->G_h->mix_flag = 1; e->G_h->mix_c = c; e->G_h->mix_lnc = lnc;
+  int rc = push_G(e);
+  if (rc) return rc;
+  LAUNCH(e, 7, k_mix_finish, 0);
   return 0;
 }
 
@@ -791,72 +1047,62 @@ int gph_engine_mixing_commit(gph_engine *e, double c, double lnc)
 // the evaluated state only ever lived in the shadow pages -- nothing to do.
 int gph_engine_mixing_revert(gph_engine *e) { return e ? 0 : GPH_EARG; }
 
+static int apply_list(gph_engine *e)
+{
+#ifdef GPH_HOSTEMU
+  for (int64_t g = 0; g < e->L; g++) apply_list_locus(e->dev.pages + (size_t)g * e->lay.page_bytes, e->lay, e->G_h->apply, e->G_h->napply);
+#else
+  LAUNCH_PRE(e);
+  hipLaunchKernelGGL(k_apply_list, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, e->ka, e->dev);
+  HIPCHK(hipGetLastError());
+  e->n_launches++;
+#endif
+  return 0;
+}
+
 int gph_engine_apply_theta(gph_engine *e, int32_t pop, double lnc, double thetaold, double thetanew)
 {
   if (!e || !e->initialized || pop < 0 || pop >= e->cfg.K) return GPH_EARG;
-  double inv_diff = (1 / thetanew - 1 / thetaold);
-#ifdef GPH_HOSTEMU
-  for (int64_t g = 0; g < e->L; g++) {
-    char *pg = e->dev.pages + (size_t)g * e->lay.page_bytes;
-    double *fs = (double *)(pg + e->lay.o_fscal);
-    fs[FS_GENLNL] -= (lnc * ((int16_t *)(pg + e->lay.o_ncoal))[pop] + inv_diff * ((double *)(pg + e->lay.o_coal))[pop]);
-  }
-#else
-  int rc = upload_tables(e);
+  SETDEV(e);
+  GphGlobal &G = *e->G_h;
+  G.napply = 1;
+  G.apply[0].kind = 0; G.apply[0].idx = pop; G.apply[0].lnc = lnc; G.apply[0].diff = (1 / thetanew - 1 / thetaold);
+  int rc = push_G(e);
   if (rc) return rc;
-  { GphKargs &ka = e->ka; ka.model = e->model; ka.lay = e->lay;
-    hipLaunchKernelGGL(k_apply_theta, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, ka, e->dev, (int)pop, lnc, inv_diff); }
-  HIPCHK(hipGetLastError());
-#endif
-  return 0;
+  return apply_list(e);
 }
 
 int gph_engine_apply_migrate(gph_engine *e, int32_t band, double lnc, double old_rate, double new_rate)
 {
   if (!e || !e->initialized || band < 0 || band >= e->cfg.B) return GPH_EARG;
-  double diff = (new_rate - old_rate);
-#ifdef GPH_HOSTEMU
-  for (int64_t g = 0; g < e->L; g++) {
-    char *pg = e->dev.pages + (size_t)g * e->lay.page_bytes;
-    double *fs = (double *)(pg + e->lay.o_fscal);
-    fs[FS_GENLNL] += (lnc * ((int16_t *)(pg + e->lay.o_nmig))[band] - diff * ((double *)(pg + e->lay.o_migst))[band]);
-  }
-#else
-  int rc = upload_tables(e);
+  SETDEV(e);
+  GphGlobal &G = *e->G_h;
+  G.napply = 1;
+  G.apply[0].kind = 1; G.apply[0].idx = band; G.apply[0].lnc = lnc; G.apply[0].diff = (new_rate - old_rate);
+  int rc = push_G(e);
   if (rc) return rc;
-  { GphKargs &ka = e->ka; ka.model = e->model; ka.lay = e->lay;
-    hipLaunchKernelGGL(k_apply_migrate, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, ka, e->dev, (int)band, lnc, diff); }
-  HIPCHK(hipGetLastError());
-#endif
-  return 0;
+  return apply_list(e);
 }
 
 int gph_engine_get_totals(gph_engine *e, double *cs, double *nc, double *ms, double *nm)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
+  SETDEV(e);
   const int K = e->cfg.K, B = e->cfg.B;
-#ifndef GPH_HOSTEMU
-  int rc0 = upload_tables(e);
-  if (rc0) return rc0;
-#endif
-  int rc = 0;
-  std::vector<double> s(2 * K + 2 * B);
-  if (e->totals_valid) {
-    s = e->totals;
-  } else {
-    rc = reduce_local(e, 1, 2 * K + 2 * B);
-    if (rc) return rc;
-    for (int c = 0; c < 2 * K + 2 * B; c++) s[c] = RSUM(e, c);
-    rc = xreduce(e, s.data(), 2 * K + 2 * B, nullptr, 0);
-  }
-  for (int p = 0; p < K; p++) { cs[p] = s[p]; nc[p] = s[K + p]; }
-  for (int b = 0; b < B; b++) { ms[b] = s[2 * K + b]; nm[b] = s[2 * K + B + b]; }
+  PUSH_IF_DIRTY(e);
+  int rc = reduce_stats(e);
+  if (rc) return rc;
+  if ((rc = run_stage_now(e, GS_TOTALS, 0))) return rc;
+  const GphGlobal &G = *e->G_h;
+  for (int p = 0; p < K; p++) { if (cs) cs[p] = G.tot_coal[p]; if (nc) nc[p] = G.tot_ncoal[p]; }
+  for (int b = 0; b < B; b++) { if (ms) ms[b] = G.tot_mig[b]; if (nm) nm[b] = G.tot_nmig[b]; }
   return rc;
 }
 
 int gph_engine_synchronize(gph_engine *e, int32_t refresh, double *oldGen, double *newGen)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
+  SETDEV(e);
   if (!refresh) {
     /* nothing is returned without a refresh: the pass is deferred into the next sweep kernel (one page
      * round trip less per iteration); any other page-touching call runs it first */
@@ -866,40 +1112,51 @@ int gph_engine_synchronize(gph_engine *e, int32_t refresh, double *oldGen, doubl
     return 0;
   }
   { int rcs = flush_sync(e); if (rcs) return rcs; }
-  e->totals_valid = false;
+  PUSH_IF_DIRTY(e);
   LAUNCH(e, 8, k_sync, (int)refresh);
-  int rc = finish_kernel(e);
+  int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
   if (rc) return rc;
-  if (RMIN(e, 0) < 1.0) { fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n"); return GPH_EKERNEL; }
-  double s[2] = {RSUM(e, 1), RSUM(e, 2)};
-  rc = xreduce(e, s, 2, nullptr, 0);
-  if (oldGen) *oldGen = s[0];
-  if (newGen) *newGen = s[1];
+  const double l0 = e->G_h->logLikelihood;
+  if ((rc = run_stage_now(e, GS_REFRESH_DONE, 0))) return rc;   /* arg 0: the caller applies the difference */
+  (void)l0;
+  GphRed R; R.rows = e->h_red; R.world = 1;
+  if (oldGen) *oldGen = R.sum(0, 1);
+  if (newGen) *newGen = R.sum(0, 2);
   return rc;
 }
 
 int gph_engine_check_all(gph_engine *e, int32_t *ok, double *sumData, double *sumGen)
 {
   if (!e || !e->initialized) return GPH_ESTATE;
+  SETDEV(e);
   { int rcs = flush_sync(e); if (rcs) return rcs; }
-  e->totals_valid = false;
+  PUSH_IF_DIRTY(e);
   LAUNCH(e, 4, k_check, 0);
-  int rc = finish_kernel(e);
+  int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
+  if (!rc) rc = reduce_stats(e);
   if (rc) return rc;
-  double s[2] = {RSUM(e, 1), RSUM(e, 2)};
-  double mn[1] = {RMIN(e, 0)};
-  rc = xreduce(e, s, 2, mn, 1);
-  if (ok) *ok = mn[0] >= 1.0;
-  if (sumData) *sumData = s[0];
-  if (sumGen) *sumGen = s[1];
+  e->G_h->nrec = 0;
+  rc = run_stage_now(e, GS_CHECK_DONE, 0);
+  if (ok) *ok = e->G_h->error != 9999;
+  if (e->G_h->error == 9999) { e->G_h->error = 0; e->G_dirty = true; rc = 0; }
+  { GphRed R; R.rows = e->h_red; R.world = 1;
+    if (sumData) *sumData = R.sum(0, 1);
+    if (sumGen) *sumGen = R.sum(0, 2); }
   return rc;
 }
 
 int gph_engine_get_counters(gph_engine *e, gph_counters *out, int32_t reset)
 {
   if (!e || !out) return GPH_EARG;
-  *out = e->counters;
-  if (reset) e->counters = gph_counters{0, 0, 0.0, 0};
+  /* summed over ALL ranks (the counters ride in the reduced rows); e->counters = the values at the last reset */
+  const GphGlobal &G = *e->G_h;
+  double ev = 0, nd = 0, by = 0;
+  for (int k = 0; k < 16; k++) { ev += G.cls_evals[k]; nd += G.cls_nodes[k]; by += G.cls_bytes[k]; }
+  out->evals = (int64_t)ev - e->counters.evals;
+  out->eval_nodes = (int64_t)nd - e->counters.eval_nodes;
+  out->eval_bytes = by - e->counters.eval_bytes;
+  out->not_enough_migs = (int64_t)G.cnt_notenough - e->counters.not_enough_migs;
+  if (reset) { e->counters.evals = (int64_t)ev; e->counters.eval_nodes = (int64_t)nd; e->counters.eval_bytes = by; e->counters.not_enough_migs = (int64_t)G.cnt_notenough; }
   return 0;
 }
 
@@ -915,9 +1172,31 @@ int64_t gph_engine_num_loci(gph_engine *e) { return e ? e->L : 0; }
 int gph_engine_class_stats(gph_engine *e, int32_t which, double *out5, int32_t reset)
 {
   if (!e || !out5 || which < 0 || which >= 16) return GPH_EARG;
-  out5[0] = e->cls_launches[which]; out5[1] = e->cls_ms[which]; out5[2] = e->cls_evals[which];
-  out5[3] = e->cls_bytes[which]; out5[4] = e->cls_nodes[which];
-  if (reset) e->cls_launches[which] = e->cls_ms[which] = e->cls_evals[which] = e->cls_bytes[which] = e->cls_nodes[which] = 0;
+  const GphGlobal &G = *e->G_h;
+  out5[0] = e->cls_launches[which]; out5[1] = e->cls_ms[which]; out5[2] = G.cls_evals[which] - e->cls_evals0[which];
+  out5[3] = G.cls_bytes[which] - e->cls_bytes0[which]; out5[4] = G.cls_nodes[which] - e->cls_nodes0[which];
+  if (reset) {
+    e->cls_launches[which] = e->cls_ms[which] = 0;
+    e->cls_evals0[which] = G.cls_evals[which]; e->cls_bytes0[which] = G.cls_bytes[which]; e->cls_nodes0[which] = G.cls_nodes[which];
+  }
+  return 0;
+}
+
+// host synchronisations, cross-rank exchanges and kernel launches since the engine was created
+int gph_engine_host_stats(gph_engine *e, int64_t *syncs, int64_t *collectives, int64_t *launches, int32_t *resident_mode)
+{
+  if (!e) return GPH_EARG;
+  if (syncs) *syncs = e->n_syncs;
+  if (collectives) *collectives = e->n_collectives;
+  if (launches) *launches = e->n_launches;
+  if (resident_mode) *resident_mode = resident(e) ? 1 : 0;
+  return 0;
+}
+// classes whose launches are bracketed by HIP events (bit k = class k of gph_engine_last_kernel_ms); default all
+int gph_engine_set_timing(gph_engine *e, uint32_t class_mask)
+{
+  if (!e) return GPH_EARG;
+  e->timing_mask = class_mask;
   return 0;
 }
 
@@ -964,6 +1243,7 @@ int gph_engine_hbm_bytes(gph_engine *e, double *bytes)
 int gph_engine_set_locus_rates(gph_engine *e, const double *rates, int32_t draws, int32_t variable)
 {
   if (!e || !e->loaded || e->initialized || !rates || draws < 0) return GPH_ESTATE;
+  SETDEV(e);
   std::vector<double> r(e->L);
   for (int64_t j = 0; j < e->L; j++) r[j] = rates[e->h_orig[j]];
   if (!e->d_mutRate && dev_alloc((void **)&e->d_mutRate, sizeof(double) * e->L)) return GPH_EHIP;
@@ -976,9 +1256,19 @@ int gph_engine_set_locus_rates(gph_engine *e, const double *rates, int32_t draws
 // UpdateLocusRate (GPhoCS.c:4598-4680): a serial scan by one wavefront + a parallel write-back (gph_kernels.h)
 // one vector of doubles from the rank that owns it to every rank, through the sum all-reduce (the others add
 // zeros: exact), in pieces small enough for any caller-supplied hook (<= 24 doubles a call)
+static int xreduce(gph_engine *e, double *sums, int nsum, double *mins, int nmin)
+{
+  int rc = 0;
+  if (e->allreduce) rc = e->allreduce(e->allreduce_user, sums, nsum, mins, nmin);
+  else if (e->comm) rc = gph_comm_allreduce_host(e->comm, sums, nsum, mins, nmin);
+  else return 0;
+  e->n_collectives++;
+  return rc ? GPH_EHIP : 0;
+}
+static bool multi_rank(const gph_engine *e) { return e->allreduce || (e->comm && gph_comm_world(e->comm) > 1); }
 static int lr_share(gph_engine *e, bool mine, std::vector<double> &v)
 {
-  if (!e->allreduce) return 0;
+  if (!multi_rank(e)) return 0;
   for (size_t off = 0; off < v.size(); off += 24) {
     double buf[24];
     const int nn = (int)(v.size() - off < 24 ? v.size() - off : 24);
@@ -996,11 +1286,13 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
   io->accepted = 0;
   if (finetune <= 0.0) return 0;                       /* GPhoCS.c:4606 */
   const bool owner = e->cfg.locus_begin == 0;          /* this rank holds the reference locus (genRateRef = 0) */
-  if (!e->allreduce && (!owner || e->cfg.L_total != e->L)) {
+  SETDEV(e);
+  if (!multi_rank(e) && (!owner || e->cfg.L_total != e->L)) {
     fprintf(stderr, "gphocs_hip: UpdateLocusRate over a shard of the loci needs the all-reduce hook (gph_engine_set_allreduce)\n");
     return GPH_EARG;
   }
   { int rcs = flush_sync(e); if (rcs) return rcs; }
+  PUSH_IF_DIRTY(e);
   const GphLayout &y = e->lay;
   const int n = e->cfg.n, N = 2 * n - 1;
   int rc = 0;
@@ -1089,7 +1381,7 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
   e->lr.finetune = finetune; e->lr.alpha = alpha;
   e->lr.first = owner ? 1 : 0;
   LAUNCH(e, 11, k_lrate_prep, finetune, e->d_lpre);
-  { int rcp = finish_kernel(e); if (rcp) return rcp; }
+  { int rcp = reduce_local(e, 0, GPH_OUT_SLOTS); if (!rcp) rcp = run_stage_now(e, GS_COUNT_ONLY, 11); if (rcp) return rcp; }
   /* ---- the scan, rank after rank in locus order: state = {next locus, rref, likref, dataLogLikelihood,
    * logLikelihood, rateVar, accepted, prepared rates used}; the rank whose block starts at `next` scans and
    * publishes the state, the others add zeros */
@@ -1105,19 +1397,13 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
       LAUNCH1(e, 9, k_lrate_scan, e->lr_lds_bytes, e->lr);
       if ((rc = d2h(e, res, e->d_lr_result, sizeof res))) return rc;
 #ifndef GPH_HOSTEMU
-      if (e->timing_pending) {
-        float ms = 0;
-        e->timing_pending = false;
-        HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-        e->last_ms[9] = ms;
-        e->cls_ms[9] += ms;
-      }
+      collect_times(e);
 #endif
       if (res[4] != 0.0) { fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by the locus-rate scan\n", (int)res[4]); return GPH_EKERNEL; }
       nx[0] = (double)(e->cfg.locus_begin + e->L); nx[1] = res[13]; nx[2] = res[14];
       nx[3] = res[1]; nx[4] = res[2]; nx[5] = res[3]; nx[6] = st[6] + res[0]; nx[7] = st[7] + res[5];
     }
-    if (e->allreduce) { if ((rc = xreduce(e, nx, 8, nullptr, 0))) return rc; }
+    if (multi_rank(e)) { if ((rc = xreduce(e, nx, 8, nullptr, 0))) return rc; }
     else if (!mine) return GPH_ESTATE;
     if (nx[0] <= st[0]) { fprintf(stderr, "gphocs_hip: the ranks' locus blocks do not tile 0..L_total\n"); return GPH_EARG; }
     memcpy(st, nx, sizeof st);
@@ -1130,9 +1416,9 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     r.flag = (int32_t)st[6] << 2;
     if (h2d(e, e->d_lrec + jr, &r, sizeof r)) return GPH_EHIP;
   }
-  e->totals_valid = false;
   LAUNCH(e, 10, k_lrate_apply, (const GphLrRec *)e->d_lrec);
-  rc = finish_kernel(e);
+  rc = reduce_local(e, 0, GPH_OUT_SLOTS);
+  if (!rc) rc = run_stage_now(e, GS_COUNT_ONLY, 10);
   if (rc) return rc;
   io->accepted = (int64_t)st[6];
   io->dataLogLikelihood = st[3];
@@ -1148,11 +1434,97 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
   return 0;
 }
 
+// ---------------------------------------------------------------- one MCMC iteration, device-resident
+// The iteration body of performMCMC (GPhoCS.c:1476-1821) as ONE stream of launches: every per-locus loop is a kernel
+// over the loci, every `omp atomic` accumulation a fixed-shape reduction (+ one RCCL all-gather of the reduced row over
+// several GPUs), everything the reference does on its main thread between two loops a k_global stage (gph_global.h)
+// that reads the reduced rows in HBM and leaves the model, the pending proposal and the accept flag in the chain
+// state for the next kernel.  The host synchronises ONCE, at the end, to read the chain state back (trace writer,
+// next sweep's kernel arguments).  In host mode (caller-supplied all-reduce hook, ranks sharing a GPU, UpdateLocusRate,
+// host emulation) the same launches run with a synchronisation per stage and gg_stage on the host mirror.
+// lr: UpdateLocusRate's settings and running state (`locus-mut-rate VAR`), NULL = constant / fixed rates.
+int gph_engine_iteration_(gph_engine *e, int32_t iteration, const double *lr_alpha_finetune, int64_t *lr_accepted, double *lr_rateVar)
+{
+  if (!e || !e->initialized) return GPH_ESTATE;
+  SETDEV(e);
+  int rc;
+  GphGlobal &Gh = *e->G_h;    /* settings only: the running state is on the device until finish_sync */
+  const int K = Gh.K, Kc = Gh.Kc;
+  PUSH_IF_DIRTY(e);
+  // the three genealogy proposals run fused in one launch (GPhoCS.c:1495-1538); the deferred synchronizeEvents of the
+  // previous iteration rides at its head
+  const int with_sync = e->sync_pending ? 8 : 0;
+  e->sync_pending = false;
+  LAUNCH(e, 0, k_sweep, 7 | with_sync, Gh.ftCoalTime, Gh.ftMigTime);
+  if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+  if ((rc = reduce_stats(e))) return rc;
+  if ((rc = run_stage(e, GS_SWEEP_DONE, with_sync, iteration))) return rc;
+  if (lr_alpha_finetune) {
+    // UpdateLocusRate, GPhoCS.c:1554-1563, 4598-4680 (host-driven: resident() is false with variable rates)
+    gph_locus_rate_result R;
+    R.accepted = 0; R.dataLogLikelihood = Gh.dataLogLikelihood; R.logLikelihood = Gh.logLikelihood; R.rateVar = *lr_rateVar;
+    if ((rc = gph_engine_locus_rate_update(e, lr_alpha_finetune[1], lr_alpha_finetune[0], &R))) return rc;
+    Gh.dataLogLikelihood = R.dataLogLikelihood; Gh.logLikelihood = R.logLikelihood; *lr_rateVar = R.rateVar;
+    *lr_accepted += R.accepted;
+    gg_rec(Gh, REC_LRATE, 0, (long long)R.accepted);
+    if ((rc = push_G(e))) return rc;
+    if ((rc = reduce_stats(e))) return rc;
+    if ((rc = run_stage(e, GS_TOTALS, 0, iteration))) return rc;
+  }
+  if ((rc = run_stage(e, GS_THETA, 0, iteration))) return rc;
+  if ((rc = apply_list(e))) return rc;
+  for (int ap = Kc; ap < K; ++ap) {
+    if ((rc = run_stage(e, GS_TAU_PROPOSE, ap, iteration))) return rc;
+    LAUNCH(e, 1, k_tau_eval, 0);
+    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+    if ((rc = run_stage(e, GS_TAU_DECIDE, ap, iteration))) return rc;
+    LAUNCH(e, 5, k_tau_finish, 0);
+  }
+  if ((rc = run_stage(e, GS_TAU_END, 0, iteration))) return rc;
+  for (int pop = 0; pop < Kc; ++pop) {
+    if (!Gh.updateSampleAge[pop]) continue;
+    if ((rc = run_stage(e, GS_SAGE_PROPOSE, pop, iteration))) return rc;
+    LAUNCH(e, 1, k_tau_eval, 0);
+    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+    if ((rc = run_stage(e, GS_SAGE_DECIDE, pop, iteration))) return rc;
+    LAUNCH(e, 5, k_tau_finish, 0);
+  }
+  if ((rc = run_stage(e, GS_SAGE_END, 0, iteration))) return rc;
+  if (Gh.doMixing) {
+    if ((rc = run_stage(e, GS_MIX_PROPOSE, 0, iteration))) return rc;
+    if (Gh.ftMixing > 0.0) {
+      LAUNCH(e, 2, k_mix_eval, 0);
+      if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+      if ((rc = run_stage(e, GS_MIX_DECIDE, 0, iteration))) return rc;
+      LAUNCH(e, 7, k_mix_finish, 0);
+    }
+  }
+  if (iteration == Gh.startMig) {
+    // sampleMigRates, then the genLogLikelihood refresh of every locus (GPhoCS.c:1738-1757) inside synchronizeEvents' pass
+    if ((rc = run_stage(e, GS_STARTMIG, 0, iteration))) return rc;
+    LAUNCH(e, 8, k_sync, 1);
+    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+    if ((rc = run_stage(e, GS_REFRESH_DONE, 1, iteration))) return rc;
+  } else {
+    e->sync_pending = true;   /* synchronizeEvents (GPhoCS.c:1705-1714): at the head of the next sweep kernel */
+  }
+  if ((iteration + 1) % Gh.samplesPerLog == 0) {
+    // checkAll, patch.c:2745-2884: consistency checks + accumulator resynchronisation
+    if ((rc = flush_sync(e))) return rc;
+    LAUNCH(e, 4, k_check, 0);
+    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+    if ((rc = reduce_stats(e))) return rc;
+    if ((rc = run_stage(e, GS_CHECK_DONE, 0, iteration))) return rc;
+  }
+  return finish_sync(e);
+}
+
 // canonical text dump (same format as oracle/gphocs_oracle_io.c go_dump_state's per-locus part)
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int32_t append)
 {
   if (!e || !e->initialized || !path) return GPH_ESTATE;
-  { int rcs = flush_sync(e); if (rcs) return rcs; }
+  SETDEV(e);
+  { int rcs = flush_sync(e); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
   const GphLayout &y = e->lay;
   std::vector<char> pages(e->pages_bytes), cond(withCond ? e->cond_bytes : 0);
   int rc = d2h(e, pages.data(), e->dev.pages, e->pages_bytes);

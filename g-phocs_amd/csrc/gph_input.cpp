@@ -618,7 +618,8 @@ struct gph_loci {
   int64_t L = 0;
   int32_t n = 0;
   std::vector<int64_t> offsets;
-  std::vector<uint8_t> leafcodes, numPhases;
+  std::vector<uint8_t> leafcodes;
+  std::vector<uint16_t> numPhases;
   std::vector<int32_t> counts, unphased;   // unphased[g] = patterns before phasing
   std::vector<double> mutRates;
   std::vector<std::string> names;
@@ -634,7 +635,8 @@ struct RawLocus {
 };
 
 struct LocusOut {
-  std::vector<uint8_t> leaf, phases;
+  std::vector<uint8_t> leaf;
+  std::vector<uint16_t> phases;
   std::vector<int32_t> counts;
   int unphased = 0;
   std::string error;
@@ -782,9 +784,9 @@ void process_locus(const RawLocus &raw, int n, const std::vector<uint8_t> &isDip
     int64_t numPhases = 1;
     for (int h = 0; h < n; h++)
       if (perturb[h]) numPhases *= 2;
-    if (numPhases > 255) {
+    if (numPhases > 65535) {
       char msg[160];
-      snprintf(msg, sizeof msg, "pattern %zu has %lld phases; the engine stores phase counts in 8 bits (max 255)", p + 1, (long long)numPhases);
+      snprintf(msg, sizeof msg, "pattern %zu has %lld phases; the engine stores phase counts in 16 bits (max 65535)", p + 1, (long long)numPhases);
       out.error = msg;
       return;
     }
@@ -813,7 +815,7 @@ void process_locus(const RawLocus &raw, int n, const std::vector<uint8_t> &isDip
       out.phases.push_back(0);
       out.counts.push_back(0);
     }
-    out.phases[row0] = (uint8_t)numPhases;
+    out.phases[row0] = (uint16_t)numPhases;
     out.counts[row0] = cnt[p];
   }
 }
@@ -1041,7 +1043,7 @@ int gph_loci_read(const gph_control *c, const char *seq_path, int32_t threads, g
     const int64_t o = Lc->offsets[g];
     if (!outs[g].phases.empty()) {
       memcpy(&Lc->leafcodes[(size_t)o * n], outs[g].leaf.data(), outs[g].leaf.size());
-      memcpy(&Lc->numPhases[(size_t)o], outs[g].phases.data(), outs[g].phases.size());
+      memcpy(&Lc->numPhases[(size_t)o], outs[g].phases.data(), outs[g].phases.size() * sizeof(uint16_t));
       memcpy(&Lc->counts[(size_t)o], outs[g].counts.data(), outs[g].counts.size() * sizeof(int32_t));
     }
     Lc->unphased[g] = outs[g].unphased;
@@ -1070,7 +1072,7 @@ int gph_loci_read(const gph_control *c, const char *seq_path, int32_t threads, g
 void gph_loci_free(gph_loci *l) { delete l; }
 
 int gph_loci_arrays(const gph_loci *l, int64_t *L, int32_t *n, const int64_t **pattern_offsets, const uint8_t **leafcodes,
-                    const uint8_t **numPhases, const int32_t **counts, const double **mutRates, const int32_t **unphased)
+                    const uint16_t **numPhases, const int32_t **counts, const double **mutRates, const int32_t **unphased)
 {
   if (!l) return GPH_EARG;
   if (L) *L = l->L;

@@ -480,7 +480,7 @@ GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double f
 // loop 1 body of UpdateTau, GPhoCS.c:3491-3833.  Reads the main page, writes the
 // evaluated state to the SHADOW page (see gph_types.h); new conditionals go to the
 // non-current halves.  out: 0 ntj0, 1 ntj1, 2 conflict, 3 genDelta, 4 dataDelta
-GPH_DEV void kb_tau_eval(const GphDev &D, int g, const GphTauArgs &A)
+GPH_DEV void kb_tau_eval(const GphDev &D, int g, gph_ctau &A)
 {
   const int ap = A.ap, s0 = A.son0, s1 = A.son1;
   double age_mt, new_age = 0.0, dGen = 0, dData = 0, gd;
@@ -624,7 +624,7 @@ GPH_DEV void kb_tau_eval(const GphDev &D, int g, const GphTauArgs &A)
 }
 
 // loop 2 body (commit), GPhoCS.c:3885-3936 (+ adjustRootEvents patch.c:1808 for the root)
-GPH_DEV void kb_tau_commit(const GphDev &D, int g, const GphTauArgs &A)
+GPH_DEV void kb_tau_commit(const GphDev &D, int g, gph_ctau &A)
 {
   int dummy = 0, i, mig, nw, ev;
   double age;
@@ -677,6 +677,13 @@ GPH_DEV void kb_tau_revert(const GphDev &D, int g, long long limit)
   stage_out(D, g, D.pages, 0);
 }
 
+// commit or revert, by the flag the decision stage left in the chain state (gph_global.h: gg_tau_decide)
+GPH_DEV void kb_tau_finish(const GphDev &D, int g)
+{
+  if (RFL(GPH_G->tau_flag)) kb_tau_commit(D, g, GPH_G->tau);
+  else kb_tau_revert(D, g, GPH_G->tau_limit);
+}
+
 // ---------------------------------------------------------------- mixing
 // evaluate loop of mixing(), GPhoCS.c:4790-4801.  out: 0 dataDelta
 GPH_DEV void kb_mix_eval(const GphDev &D, int g, double c)
@@ -713,6 +720,13 @@ GPH_DEV void kb_mix_commit(const GphDev &D, int g, double c, double lnc)
   }
   out_common(D, g);
   stage_out(D, g, D.pages, 0);
+}
+
+// mixing reject (GPhoCS.c:4881-4887): revertToSaved restores every locus exactly, and the evaluated state only
+// ever lived in the shadow pages -- nothing to do
+GPH_DEV void kb_mix_finish(const GphDev &D, int g)
+{
+  if (RFL(GPH_G->mix_flag)) kb_mix_commit(D, g, GPH_G->mix_c, GPH_G->mix_lnc);
 }
 
 // ---------------------------------------------------------------- locus rates
@@ -966,7 +980,7 @@ GPH_DEVHOT double lr_ref_eval(const GphLrArgs &A, const GphRefProg &R, int P, do
   /* the root is alone in the last step, slot 0: lane p < P holds its four conditionals of pattern p.
    * Root reduction as in lik_compute / lik_private_t (LocusDataLikelihood.c:466-479) */
   double lnl = 0.0, term = 0.0;
-  const int ph = lane < P ? gu8v(q_phases, lane) : 0;
+  const int ph = lane < P ? gu16v(q_phases, lane) : 0;
   double prob = q0;
   prob += q1;
   prob += q2;
@@ -1179,7 +1193,9 @@ GPH_DEV void kb_check(const GphDev &D, int g)
   out_common(D, g);
   stage_out(D, g, D.pages, 1);
 }
-};   // struct GphCtx
+};   // struct GphCtxT
+using GphCtx = GphCtxT<false>;    // model in the kernel-argument segment (genealogy sweep, locus-rate kernels)
+using GphCtxG = GphCtxT<true>;    // model in the device-resident chain state
 using GphLrRec = GphCtx::GphLrRec;
 using GphLrPre = GphCtx::GphLrPre;
 using GphLrArgs = GphCtx::GphLrArgs;

@@ -18,7 +18,14 @@
 // vector register: a read is a v_readlane with a constant lane, a write a v_writelane -- no LDS round trip
 // (~90 cycles plus a v_readfirstlane) every time the chain logic branches on one of them.
 // load_scalars() after the page has been staged in, flush_scalars() before it is staged out.
-struct GphCtx {
+template <bool GPH_GM> struct GphCtxT {
+#ifndef GPH_HOSTEMU
+  GPH_DEV gph_cmodel &gmodel() const
+  {
+    if constexpr (GPH_GM) return *(gph_cmodel *)&(((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->G->model);
+    else return ((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->model;
+  }
+#endif
 #ifdef GPH_HOSTEMU
   int32_t r_pad[IS_COUNT + CN_COUNT + SI_COUNT] = {};
 #define GPH_PADGET(i) (r_pad[i])
@@ -831,7 +838,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     /* the root was computed last: its conditionals for pattern `lane` are q0..q3; only the further
      * phases of an unphased pattern (the following rows) come from memory */
     double term = 0.0;
-    const int ph = lane < P ? gu8v(q_phases, lane) : 0;
+    const int ph = lane < P ? gu16v(q_phases, lane) : 0;
     double prob = q0;   /* 0.0 + q0 */
     prob += q1;
     prob += q2;
@@ -861,7 +868,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   } else {
     GPH_WAVE_FENCE();
     for (int p = lane; p < P; p += GPH_NLANES) {
-      int ph = gu8v(q_phases, p);
+      int ph = gu16v(q_phases, p);
       if (ph > 0) {
         int nc = 4 * ph;
         double prob = 0.0;
@@ -872,7 +879,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     GPH_SYNC();
     U = 0;
     for (int p = 0; p < P; p++)
-      if (gu8(q_phases, p) > 0) { lnl += gf64(q_terms, p); U++; }
+      if (gu16(q_phases, p) > 0) { lnl += gf64(q_terms, p); U++; }
   }
   setFS(FS_DATALNL, lnl);
   if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (double)(96 * nord * P + 20 * N + 8 * U + 8));
@@ -939,7 +946,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     const gdbl *rc = cond_base() + cond_off(ISC(IS_ROOT), CBIT(ISC(IS_ROOT)));
     int p;
     for (p = GPH_LANE; p < P; p += GPH_NLANES) {
-      int ph = gu8v(q_phases, p);
+      int ph = gu16v(q_phases, p);
       if (ph > 0) {
         int nc = 4 * ph, c;
         double prob = 0.0;
@@ -951,7 +958,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     lnl = 0.0;
     U = 0;
     for (p = 0; p < P; p++) {
-      if (gu8(q_phases, p) > 0) { lnl += gf64(q_terms, p); U++; }
+      if (gu16(q_phases, p) > 0) { lnl += gf64(q_terms, p); U++; }
     }
   }
   setFS(FS_DATALNL, lnl);
@@ -1035,7 +1042,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
   DP rc = scr + ((root - n) * P) * 4;
   if (!wide) {
     double term = 0.0;
-    const int ph = lane < P ? gu8v(q_phases, lane) : 0;
+    const int ph = lane < P ? gu16v(q_phases, lane) : 0;
     double prob = 0.0;
     prob += q0;
     prob += q1;
@@ -1062,7 +1069,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
   } else {
     GPH_WAVE_FENCE();
     for (int p = lane; p < P; p += GPH_NLANES) {
-      int ph = gu8v(q_phases, p);
+      int ph = gu16v(q_phases, p);
       if (ph > 0) {
         int nc = 4 * ph;
         double prob = 0.0;
@@ -1072,7 +1079,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
     }
     GPH_SYNC();
     for (int p = 0; p < P; p++)
-      if (gu8(q_phases, p) > 0) lnl += gf64(q_terms, p);
+      if (gu16(q_phases, p) > 0) lnl += gf64(q_terms, p);
   }
 #ifdef GPH_LRSTAMP
   lnl = RFLD(lnl);
@@ -1114,7 +1121,7 @@ GPH_DEV double lik_private(int o_nd, int o_seq, int P, int root, double rate, in
   double lnl = 0.0;
   const double *rc = scr + ((root - n) * P) * 4;
   for (p = 0; p < P; p++) {
-    int ph = gu8v(q_phases, p);
+    int ph = gu16v(q_phases, p);
     if (ph > 0) {
       int nc = 4 * ph, c;
       double prob = 0.0;

@@ -34,10 +34,10 @@ struct Finetune {
 };
 }   // namespace
 
-extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, int32_t device, int32_t verbose,
-                                           int32_t rank, int32_t world, gph_allreduce_fn allreduce, void *user)
+static int run_control_file(const char *ctl, const char *ctl2, int32_t device, int32_t verbose,
+                            int32_t rank, int32_t world, gph_allreduce_fn allreduce, void *user, gph_comm *comm)
 {
-  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !allreduce)) return GPH_EARG;
+  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !allreduce && !comm)) return GPH_EARG;
   const bool lead = rank == 0;   /* rank 0 talks and writes the trace file; every rank runs the same chain */
   gph_control *C = nullptr;
   gph_loci *LC = nullptr;
@@ -72,7 +72,7 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
   if ((rc = gph_loci_read(C, nullptr, 0, &LC, err, sizeof err))) return fail(rc, "reading the sequence file");
   int64_t L = 0;
   int32_t n = 0;
-  const int64_t *offs; const uint8_t *leaf, *ph; const int32_t *cnt, *unph; const double *rates;
+  const int64_t *offs; const uint8_t *leaf; const uint16_t *ph; const int32_t *cnt, *unph; const double *rates;
   gph_loci_arrays(LC, &L, &n, &offs, &leaf, &ph, &cnt, &rates, &unph);
   {
     int64_t up = 0;
@@ -96,7 +96,8 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
   cfg.locus_begin = lb;
   cfg.device = device;
   if ((rc = gph_engine_create(&cfg, &E))) return fail(rc, "gph_engine_create");
-  if (world > 1 && (rc = gph_engine_set_allreduce(E, allreduce, user))) return fail(rc, "gph_engine_set_allreduce");
+  if (world > 1 && allreduce && (rc = gph_engine_set_allreduce(E, allreduce, user))) return fail(rc, "gph_engine_set_allreduce");
+  if (comm && (rc = gph_engine_set_comm(E, comm))) return fail(rc, "gph_engine_set_comm");
   /* pattern offsets are absolute indices into the pattern arrays: the shard is a window of the offset array */
   if ((rc = gph_engine_load_loci(E, le - lb, offs + lb, leaf, ph, cnt, info.mutRateMode == 2 ? rates + lb : nullptr))) return fail(rc, "gph_engine_load_loci");
   if ((rc = gph_mcmc_create(E, &cfg, &mc, &M))) return fail(rc, "gph_mcmc_create");
@@ -263,7 +264,18 @@ extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, in
   return GPH_OK;
 }
 
+extern "C" int gph_run_control_file_ranked(const char *ctl, const char *ctl2, int32_t device, int32_t verbose,
+                                           int32_t rank, int32_t world, gph_allreduce_fn allreduce, void *user)
+{
+  return run_control_file(ctl, ctl2, device, verbose, rank, world, allreduce, user, nullptr);
+}
+
+extern "C" int gph_run_control_file_comm(const char *ctl, const char *ctl2, int32_t device, int32_t verbose, gph_comm *comm)
+{
+  return run_control_file(ctl, ctl2, device, verbose, gph_comm_rank(comm), gph_comm_world(comm), nullptr, nullptr, comm);
+}
+
 extern "C" int gph_run_control_file(const char *ctl, const char *ctl2, int32_t device, int32_t verbose)
 {
-  return gph_run_control_file_ranked(ctl, ctl2, device, verbose, 0, 1, nullptr, nullptr);
+  return run_control_file(ctl, ctl2, device, verbose, 0, 1, nullptr, nullptr, nullptr);
 }

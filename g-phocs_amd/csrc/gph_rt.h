@@ -33,6 +33,10 @@ extern thread_local char *gph_sm;
 extern thread_local GphLds gph_lds;
 extern GphLayout g_lay;
 extern GphModel g_model;
+extern GphGlobal *gph_G_emu;
+typedef const GphGlobal gph_cglobal;
+typedef const GphTauArgs gph_ctau;
+#define GPH_G ((gph_cglobal *)gph_G_emu)
 #else
 #include <hip/hip_runtime.h>
 #define GPH_DEV __device__ inline
@@ -58,8 +62,15 @@ extern GphModel g_model;
 extern __shared__ __attribute__((aligned(16))) char gph_sm[];   // dynamic part: sequence block + per-pattern terms
 __shared__ GphLds gph_lds;   // static part: the locus image (gph_types.h); this header is included by one TU only
 typedef __attribute__((address_space(4))) const GphKargs gph_ckargs;
-#define g_model (((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->model)
+typedef __attribute__((address_space(4))) const GphModel gph_cmodel;
+typedef __attribute__((address_space(4))) const GphGlobal gph_cglobal;
+typedef __attribute__((address_space(4))) const GphTauArgs gph_ctau;
+// the model tables: GphCtxT<false> (the genealogy sweep) reads the copy in the kernel-argument segment, GphCtxT<true>
+// (every kernel that runs after a decision the host has not seen) the chain state in HBM, through the pointer in the
+// kernel-argument segment and the constant address space -- scalar loads either way
+#define g_model (this->gmodel())
 #define g_lay (((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->lay)
+#define GPH_G ((gph_cglobal *)(((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->G))
 #endif
 
 #ifdef GPH_HOSTEMU
@@ -124,4 +135,6 @@ GPH_DEV int gu8(int off, int i) { return RFL(((lu8 *)(GPH_SMB + off))[i]); }
 GPH_DEV void su8(int off, int i, int v) { ((lu8 *)(GPH_SMB + off))[i] = (uint8_t)v; }
 // lane-varying byte/int loads (no readfirstlane): pruning only
 GPH_DEV int gu8v(int off, int i) { return ((lu8 *)(GPH_SMB + off))[i]; }
+GPH_DEV int gu16v(int off, int i) { return ((GPH_LDS uint16_t *)(GPH_SMB + off))[i]; }
+GPH_DEV int gu16(int off, int i) { return RFL(((GPH_LDS uint16_t *)(GPH_SMB + off))[i]); }
 GPH_DEV int gi32v(int off, int i) { return ((li32 *)(GPH_SMB + off))[i]; }

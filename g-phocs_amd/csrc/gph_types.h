@@ -12,7 +12,7 @@
 //   cond   : per locus [2][n-1][P][4] fp64 conditional likelihoods of the internal
 //            nodes (double buffer, the page's condbit[node] selects the current
 //            half) -- leaves are not stored as doubles: a leaf is a base code.
-//   seq    : per locus leaf codes u8[P][n], phases u8[P], counts i32[P] (read-only).
+//   seq    : per locus leaf codes u8[P][n], phases u16[P], counts i32[P] (read-only).
 //
 // Replaces the reference's per-locus heap structures: struct LOCUS_LIKELIHOOD
 // (LocusDataLikelihood.c:40-104), Event / EVENT_CHAIN (patch.h:159-172),
@@ -69,6 +69,7 @@ struct GphLayout {
   int32_t Pmax;            // max phased patterns of any locus on this device
   int32_t lds_bytes;       // largest dynamic-LDS allocation of a launch (sequence block [+ terms])
 };
+struct GphGlobal;
 // model + layout tables travel BY VALUE as the first argument of every kernel: in the kernarg segment every
 // access is one scalar load off the (always live) kernarg pointer -- a __constant__ symbol costs a
 // pc-relative address computation (3 scalar instructions) per access and an upload per change
@@ -80,14 +81,20 @@ struct GphKargs {
   double mathc[32];
   const double *log_t;
   const uint64_t *exp_t;
+  // device-resident chain state (GphGlobal below): the kernels of the global proposals read the model and the
+  // pending proposal from HERE (they are launched before the host knows either), the genealogy sweep reads
+  // `model` above (the host knows it at every iteration boundary)
+  GphGlobal *G;
 };
 
 // Sequence block of one locus (HBM block format == dynamic-LDS image), sized by the locus' OWN number of
-// phased patterns P: leaf codes u8[P][n] | phases u8[P] | (pad to 4) counts i32[P] | (pad to 16);
-// behind it, for loci with more than one pattern per lane only, f64[P] terms of the root reduction
+// phased patterns P: leaf codes u8[P][n] | (pad to 2) phases u16[P] | (pad to 4) counts i32[P] | (pad to 16);
+// behind it, for loci with more than one pattern per lane only, f64[P] terms of the root reduction.
+// Phase counts are 16 bits: the reference keeps an int, and 8 unbroken heterozygotes in one repeated alignment
+// column already give 2^8 = 256 phases (AlignmentProcessor.c:998-1158)
 #define GPH_Q_LEAF 0
-#define GPH_Q_PHASES(P, n) ((P) * (n))
-#define GPH_Q_COUNT(P, n) (((P) * (n) + (P) + 3) & ~3)
+#define GPH_Q_PHASES(P, n) (((P) * (n) + 1) & ~1)
+#define GPH_Q_COUNT(P, n) ((GPH_Q_PHASES(P, n) + 2 * (P) + 3) & ~3)
 #define GPH_Q_BYTES(P, n) ((GPH_Q_COUNT(P, n) + 4 * (P) + 15) & ~15)
 #define GPH_Q_TERMS(P, n) GPH_Q_BYTES(P, n)
 // delta scalars (s_di[inst])
@@ -188,4 +195,63 @@ struct GphTauArgs {
   int32_t aff_bands[GPH_MAXB * 2];     // 32-bit: scalar loads (see GphModel)
   int32_t start_or_end[GPH_MAXB * 2];
   double new_band_ages[GPH_MAXB * 2];
+};
+
+// ---------------------------------------------------------------------------------------
+// Chain state above the loci: what the reference keeps in process-wide globals on its main thread
+// (dataState GPhoCS.h:35-50, mcmcSetup finetunes MCMCcontrol.h:80-99, the population tree's parameters and
+// priors PopulationTree.h:60-101, the general RNG slot utils.h:34, genetree_stats_total patch.h:121) plus
+// the pending global proposal.  ONE copy lives in HBM: the decisions of the global proposals (UpdateTheta,
+// UpdateMigRates, UpdateTau, UpdateSampleAge, mixing) are taken by a one-wavefront kernel (gph_global.h,
+// k_global) straight from the reduced vectors, and the commit / revert kernels are predicated on the flag it
+// leaves here -- an iteration is ONE stream of launches and one host synchronisation at its end.  The host
+// keeps a mirror (read back at the end of every iteration) for the trace writer and the next sweep's kernarg.
+// reduced vectors of one launch: section 0 = per-locus outputs (GPH_OUT_SLOTS columns), section 1 = the compact
+// statistics (2K+2B columns); per section sum / min / max per column + the sticky error word.  With several
+// ranks every rank's row is all-gathered (RCCL, on the engine's stream) and combined in rank order.
+#define GPH_RED_COLS 128
+#define GPH_RED_STRIDE (3 * GPH_RED_COLS + 8)
+#define GPH_RED_ROW (2 * GPH_RED_STRIDE)
+// stages of an iteration that run above the loci (gph_global.h: gg_stage)
+enum { GS_INIT_DONE = 0, GS_SWEEP_DONE, GS_TOTALS, GS_THETA, GS_TAU_PROPOSE, GS_TAU_DECIDE, GS_TAU_END, GS_SAGE_PROPOSE,
+       GS_SAGE_DECIDE, GS_SAGE_END, GS_MIX_PROPOSE, GS_MIX_DECIDE, GS_STARTMIG, GS_REFRESH_DONE, GS_CHECK_DONE,
+       GS_COUNT_ONLY };
+#define GPH_REC_MAX (16 + 3 * GPH_MAXK)
+struct GphRec { int32_t code, idx; int64_t acc; double dataLnL, logL; };
+enum { REC_INIT = 0, REC_INT, REC_MIGN, REC_SPR, REC_LRATE, REC_THETA, REC_MIGR, REC_TAU, REC_CONFLICTS, REC_SAGE,
+       REC_MIX, REC_CHECK };
+struct GphApply { int32_t kind, idx; double lnc, diff; };   // kind 0: population idx (diff = 1/new - 1/old), 1: band idx (diff = new - old rate)
+struct GphGlobal {
+  GphModel model;
+  GphTauArgs tau;                    // pending UpdateTau / UpdateSampleAge proposal
+  long long tau_limit;               // first conflicting locus (global index) or 1 << 62
+  int32_t tau_flag, mix_flag;        // 1 = accepted: the finish kernels commit, 0 = they revert
+  double mix_c, mix_lnc;
+  int32_t napply, pad0;
+  GphApply apply[GPH_MAXK + GPH_MAXB];
+  // ---- dimensions and settings
+  int32_t n, K, Kc, B, rootPop, startMig, doMixing, samplesPerLog;
+  double Ltot;
+  double thetaAlpha[GPH_MAXK], thetaBeta[GPH_MAXK], thetaStart[GPH_MAXK];
+  double ageAlpha[GPH_MAXK], ageBeta[GPH_MAXK], ageStart[GPH_MAXK], ftTaus[GPH_MAXK];
+  double mrAlpha[GPH_MAXB], mrBeta[GPH_MAXB];
+  int32_t updateSampleAge[GPH_MAXK];
+  double ftCoalTime, ftMigTime, ftTheta, ftMigRate, ftMixing;
+  // ---- running state
+  uint32_t gx, gy, gz, pad1;         // general RNG slot
+  double logLikelihood, dataLogLikelihood;
+  double tot_coal[GPH_MAXK], tot_ncoal[GPH_MAXK], tot_mig[GPH_MAXB], tot_nmig[GPH_MAXB];
+  int64_t acc[9], accTau[GPH_MAXK], rubberband_conflicts;
+  int32_t iteration, error;          // error: first fatal code seen by a stage (0 = none)
+  // pending proposal bookkeeping (between propose and decide)
+  double pend_lnacc, pend_tauold, pend_taunew, pend_taufactor0, pend_taufactor1, pend_dGen;
+  int32_t pend_pop, pend_kind;       // kind 0 none, 1 tau, 2 sample age: the model change applied AFTER the finish kernel
+  int32_t accArr[GPH_MAXK];          // accepted[] of the running UpdateTau / UpdateSampleAge call
+  // per kernel class: evaluations, recomputed nodes, algorithmic bytes, "not enough migration slots"
+  double cls_evals[16], cls_nodes[16], cls_bytes[16], cnt_notenough;
+  // migration rates as recordParamVals saw them (GPhoCS.c:1730 runs BEFORE sampleMigRates at iteration == start-mig)
+  double migRateShown[GPH_MAXB];
+  // record lines of the running iteration (printed by the host after its synchronisation)
+  int32_t nrec, shownValid;
+  GphRec rec[GPH_REC_MAX];
 };

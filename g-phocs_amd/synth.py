@@ -179,7 +179,7 @@ def make_synthetic_pack(Pack, config, L, seqlen=1000, nmask=0.002, mut_scale=1.0
         offs.append(offs[-1] + len(rows))
     p.pattern_offsets = np.array(offs, np.int64)
     p.leafcodes = np.concatenate(leaf_rows).astype(np.uint8)
-    p.numPhases = np.array(phase_rows, np.uint8)
+    p.numPhases = np.array(phase_rows, np.uint16)
     p.counts = np.array(count_rows, np.int32)
     p.mutRates = np.ones(L)
     return p

@@ -63,9 +63,33 @@ typedef struct {
 } gph_config;
 
 /* cross-rank reduction hook (one process per GPU): sums[0..nsum) are summed, mins[0..nmin)
- * minimised, in place, over all ranks.  NULL = single rank.  nsum + nmin <= 9 + 2K + 2B (<= 57 with the
- * largest compiled capacities): one call per global proposal, six per MCMC iteration. */
+ * minimised, in place, over all ranks.  NULL = single rank (or a native communicator, below).
+ * nsum + nmin <= 16 + 2K + 2B: one call per reduction point, 6 + #ancestral populations per MCMC iteration.
+ * A hook forces a host synchronisation at every reduction point; the native RCCL communicator does not. */
 typedef int (*gph_allreduce_fn)(void *user, double *sums, int32_t nsum, double *mins, int32_t nmin);
+
+/* ------------------------------------------------------------------------------------
+ * native cross-rank exchange (csrc/gph_comm.cpp), one process per GPU, loci sharded over the ranks.  Replaces the
+ * `omp atomic` accumulations of the reference's per-locus loops across GPUs:
+ *   RCCL: ncclAllGather of the reduced row over xGMI, queued on the engine's stream -- no host synchronisation;
+ *         librccl is dlopen()ed on first use.  RCCL refuses two ranks on one GPU.
+ *   shm:  host shared-memory exchange for ranks that share a GPU (tests on a 1-GPU box).
+ * rank 0 makes the id and hands it to the other ranks by any means (pipe, file, torch.distributed). */
+typedef struct gph_comm gph_comm;
+#define GPH_COMM_ID_BYTES 128
+int gph_device_count(void);   /* HIP devices this process sees (the first GPU call of a freshly forked rank) */
+int gph_comm_unique_id(void *id128);
+gph_comm *gph_comm_create_rccl(const void *id128, int32_t rank, int32_t world, int32_t device);
+gph_comm *gph_comm_create_shm(const char *name, int32_t rank, int32_t world);   /* name "/unique-per-run", same on every rank */
+gph_comm *gph_comm_attach_shm(void *zeroed_shared_mapping, int32_t rank, int32_t world);
+size_t gph_comm_shm_bytes(int32_t world);
+void gph_comm_destroy(gph_comm *c);
+int gph_comm_world(const gph_comm *c);
+int gph_comm_rank(const gph_comm *c);
+int gph_comm_on_stream(const gph_comm *c);
+const char *gph_comm_kind(const gph_comm *c);
+int gph_comm_allgather_stream(gph_comm *c, const double *d_in, double *d_out, int32_t count, void *hip_stream);
+int gph_comm_allreduce_host(gph_comm *c, double *sums, int32_t nsum, double *mins, int32_t nmin);
 
 typedef struct {
   int64_t accepted_internal, accepted_mignode, accepted_spr;
@@ -90,7 +114,7 @@ typedef struct {
   double genDelta, dataDelta;
 } gph_tau_result;
 
-typedef struct {
+typedef struct {           /* summed over ALL ranks */
   int64_t evals;          /* computeLocusDataLikelihood(useOld=1)-equivalents since last reset */
   int64_t eval_nodes;     /* recomputed internal nodes (R) */
   double eval_bytes;      /* algorithmic bytes 96*R*P + 20*N + 8*U + 8 per evaluation */
@@ -100,10 +124,12 @@ typedef struct {
 int gph_engine_create(const gph_config *cfg, gph_engine **out);
 void gph_engine_destroy(gph_engine *e);
 int gph_engine_set_allreduce(gph_engine *e, gph_allreduce_fn fn, void *user);
+/* native communicator (not owned by the engine; destroy it after the engine) */
+int gph_engine_set_comm(gph_engine *e, gph_comm *c);
 /* leafcodes: [Ptot][n] with 0..3 = T,C,A,G and 4 = N; numPhases non-zero on the first phase
- * of each unphased pattern; counts on the same rows; pattern_offsets[L+1] */
+ * of each unphased pattern (16 bits: the reference keeps an int, 2^hets); counts on the same rows; pattern_offsets[L+1] */
 int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *pattern_offsets, const uint8_t *leafcodes,
-                         const uint8_t *numPhases, const int32_t *counts, const double *mutRates);
+                         const uint16_t *numPhases, const int32_t *counts, const double *mutRates);
 int gph_engine_set_model(gph_engine *e, const double *theta, const double *popAge, const double *sampleAge,
                          const double *migRate, const double *bandStart, const double *bandEnd);
 int gph_engine_seed(gph_engine *e, uint32_t seed);
@@ -146,8 +172,14 @@ int gph_engine_get_counters(gph_engine *e, gph_counters *out, int32_t reset);
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditionals, int32_t append);
 /* timing of the last launch of a named kernel class, measured with HIP events on the
  * engine's own stream: which = 0 sweep, 1 tau_eval, 2 mix_eval, 3 init, 4 check,
- * 5 tau_commit, 6 tau_revert, 7 mix_commit, 8 sync, 9 locus-rate scan, 10 locus-rate apply */
+ * 5 tau_finish (commit or revert, by the decision flag), 7 mix_finish, 8 sync, 9 locus-rate scan, 10 locus-rate apply,
+ * 11 locus-rate prepare */
 int gph_engine_last_kernel_ms(gph_engine *e, int32_t which, double *ms);
+/* classes whose launches are bracketed by HIP events (bit k = class k); default all */
+int gph_engine_set_timing(gph_engine *e, uint32_t class_mask);
+/* host synchronisations, cross-rank exchanges and kernel launches since the engine was created; resident_mode = 1 when
+ * the decisions above the loci are taken on the device (one host synchronisation per iteration) */
+int gph_engine_host_stats(gph_engine *e, int64_t *syncs, int64_t *collectives, int64_t *launches, int32_t *resident_mode);
 /* accumulated per class: out5 = {launches, summed ms, evaluations, algorithmic bytes, recomputed nodes} */
 int gph_engine_class_stats(gph_engine *e, int32_t which, double *out5, int32_t reset);
 int64_t gph_engine_num_loci(gph_engine *e);
@@ -233,13 +265,17 @@ const char *gph_control_sample_name(const gph_control *c, int32_t slot);   /* ""
 int gph_loci_read(const gph_control *c, const char *seq_path, int32_t threads, gph_loci **out, char *err, int32_t errlen);
 void gph_loci_free(gph_loci *l);
 int gph_loci_arrays(const gph_loci *l, int64_t *L, int32_t *n, const int64_t **pattern_offsets, const uint8_t **leafcodes,
-                    const uint8_t **numPhases, const int32_t **counts, const double **mutRates, const int32_t **unphased);
+                    const uint16_t **numPhases, const int32_t **counts, const double **mutRates, const int32_t **unphased);
 int gph_run_control_file(const char *ctl_path, const char *secondary_ctl_path_or_null, int32_t device, int32_t verbose);
 /* the same chain over `world` processes, one per GPU: every rank reads the files, holds the contiguous block
  * rank*ceil(L/world) .. of the loci, runs the same host code on the same general RNG stream and combines the
  * reduced vectors through `allreduce` (see gph_engine_set_allreduce); rank 0 writes the trace file */
 int gph_run_control_file_ranked(const char *ctl_path, const char *secondary_ctl_path_or_null, int32_t device,
                                 int32_t verbose, int32_t rank, int32_t world, gph_allreduce_fn allreduce, void *user);
+/* the same with a native communicator (RCCL or shared memory): what `G-PhoCS-hip -g N <control-file>` runs in each of
+ * its N child processes */
+int gph_run_control_file_comm(const char *ctl_path, const char *secondary_ctl_path_or_null, int32_t device,
+                              int32_t verbose, gph_comm *comm);
 
 /* ------------------------------------------------------------------------------------
  * post-run summary of a trace file (host only): block means per column, the output of the reference's

@@ -15,12 +15,12 @@ HOSTEMU = os.path.join(REPO, "tests", "hostemu", "libgphocs_hostemu.so")
 
 def build_hostemu(sanitize=False):
     csrc = os.path.join(REPO, "g-phocs_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp", "gph_readtrace.cpp")]
+    srcs = [os.path.join(csrc, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp", "gph_readtrace.cpp", "gph_comm.cpp")]
     deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
     if os.path.exists(HOSTEMU) and all(os.path.getmtime(HOSTEMU) >= os.path.getmtime(d) for d in deps):
         return HOSTEMU
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
-           "-x", "c++"] + srcs + ["-o", HOSTEMU]
+           "-x", "c++"] + srcs + ["-lrt", "-o", HOSTEMU]
     if sanitize:
         cmd[1:1] = ["-fsanitize=address,undefined"]
     subprocess.run(cmd, check=True)

@@ -209,6 +209,97 @@ def test_two_ranks_sharded_on_device(G, tmp_path):
     compare_records(out + ".0", str(tmp_path / "g"))
 
 
+def _records(G, pack, iters, path, env=None, comm_factory=None):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        pk = G.Pack.load(pack)
+        lib = G.load_library(dims=(pk.n, pk.K, pk.B))
+        comm = comm_factory(lib) if comm_factory else None
+        s = G.Sampler(pk, lib=lib, comm=comm)
+        s.set_record_file(path)
+        s.initialize()
+        for it in range(iters):
+            s.iteration(it)
+        s.dump_state(path + ".state", True)
+        s.set_record_file(None)
+        hs = s.host_stats()
+        s.close()
+        if comm:
+            lib.gph_comm_destroy(comm)
+        return hs
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("name", ["m3", "a7", "m4", "z0"])
+def test_resident_decisions_equal_host_decisions(G, tmp_path, name):
+    """the decisions above the loci taken by k_global on the device (one host synchronisation per iteration) against
+    the same gg_stage code run on the host with a synchronisation per stage (GPH_HOST_DECISIONS=1): byte-identical
+    records and final state, and both equal to the real reference's golden records"""
+    iters = CASES[name]
+    pack = os.path.join(GOLDEN, name + ".gpk")
+    a, b = str(tmp_path / "res.rec"), str(tmp_path / "host.rec")
+    hs_a = _records(G, pack, iters, a)
+    hs_b = _records(G, pack, iters, b, env={"GPH_HOST_DECISIONS": "1"})
+    assert hs_a["resident"] and not hs_b["resident"]
+    assert open(a).read() == open(b).read()
+    assert open(a + ".state").read() == open(b + ".state").read()
+    compare_records(a, os.path.join(GOLDEN, name + ".rtrace"))
+    # one synchronisation per iteration (+ the initialisation and the state dump) against one per stage
+    assert hs_a["syncs"] <= iters + 8, hs_a
+    assert hs_b["syncs"] > 4 * iters, hs_b
+
+
+def test_native_rccl_communicator_single_rank(G, tmp_path):
+    """the RCCL path of the engine with the one rank this box has: ncclCommInitRank from an id passed through the C
+    ABI, the reduced row all-gathered on the engine's stream before every k_global stage, no host synchronisation
+    inside an iteration -- records equal to the golden"""
+    import ctypes
+
+    def factory(lib):
+        raw = (ctypes.c_uint8 * 128)()
+        assert lib.gph_comm_unique_id(raw) == 0
+        c = lib.gph_comm_create_rccl(bytes(raw), 0, 1, 0)
+        assert c and lib.gph_comm_kind(c) == b"rccl"
+        return c
+    iters = 60
+    out = str(tmp_path / "rccl.rec")
+    hs = _records(G, os.path.join(GOLDEN, "m3.gpk"), iters, out, comm_factory=factory)
+    assert hs["resident"] and hs["collectives"] >= 4 * iters and hs["syncs"] <= iters + 8, hs   # sweep + 2 tau + mixing per iteration
+    golden = open(os.path.join(GOLDEN, "m3.rtrace")).read().splitlines()
+    mine = open(out).read().splitlines()
+    (tmp_path / "g").write_text("\n".join(golden[:len(mine)]) + "\n")
+    compare_records(out, str(tmp_path / "g"))
+
+
+@pytest.mark.parametrize("name,ranks", [("m3", 2), ("a7", 2), ("v8", 3)])
+def test_launcher_ranks_share_the_device(tmp_path, name, ranks):
+    """`G-PhoCS-hip -g N <control-file>`: the C launcher forks N ranks before any GPU call; with one GPU on the box the
+    ranks share it and exchange through host shared memory (RCCL refuses two ranks on one GPU).  One chain, loci
+    sharded, the real reference binary's trace file"""
+    import shutil
+    exe = os.path.join(REPO, "g-phocs_amd", "G-PhoCS-hip")
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    r = subprocess.run([exe, "-g", str(ranks), "-v", name + ".ctl"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
+    got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
+    assert want[0] == got[0] and len(want) == len(got)
+    for w, g in zip(want[1:], got[1:]):
+        if w == g:
+            continue
+        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
+        assert len(wf) == len(gf) and all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
+
+
 def test_native_library_is_the_path(G):
     """the ops must come from the in-tree HIP library; without it construction fails loudly"""
     import gphocs_amd

@@ -1,0 +1,104 @@
+"""The native cross-rank exchange (csrc/gph_comm.cpp) and the `G-PhoCS-hip -g N` launcher, on the CPU: the
+host-emulation build of the engine sources + the host shared-memory transport (what ranks that share a GPU use;
+RCCL needs one GPU per rank and is covered by the -m gpu tests with a one-rank communicator and by the driver's
+multi-GPU runs).  One chain over 2 / 3 ranks must write the trace file the REAL reference binary wrote
+(tests/golden/*.trace) -- rubber-band conflicts (m3), estimated sample ages (a7) and UpdateLocusRate's scan
+chained through the ranks (v8) included."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLDEN, REPO
+
+sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
+
+
+@pytest.fixture(scope="module")
+def hostemu():
+    import run_hostemu
+    import gphocs_amd as G
+    G.build()                       # the launcher executable (g++) -- the HIP libraries are not loaded here
+    return run_hostemu.build_hostemu()
+
+
+def _same_trace(want_path, got_path):
+    want = open(want_path).read().splitlines()
+    got = open(got_path).read().splitlines()
+    assert want[0] == got[0] and len(want) == len(got)
+    ndiff = 0
+    for w, g in zip(want[1:], got[1:]):
+        if w == g:
+            continue
+        ndiff += 1
+        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
+        assert len(wf) == len(gf) and wf[0] == gf[0]
+        assert all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
+    assert ndiff <= len(want) // 10     # cross-rank sums differ from the serial order in the last printed digit at most
+
+
+@pytest.mark.parametrize("name,ranks", [("m3", 2), ("m3", 3), ("a7", 2), ("v8", 2), ("v8", 3), ("g1", 4)])
+def test_launcher_ranks_write_the_reference_trace(hostemu, tmp_path, name, ranks):
+    exe = os.path.join(REPO, "g-phocs_amd", "G-PhoCS-hip")
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    r = subprocess.run([exe, "-g", str(ranks), name + ".ctl"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GPHOCS_HIP_LIB=hostemu))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    _same_trace(os.path.join(GOLDEN, name + ".trace"), os.path.join(tmp_path, name + ".trace"))
+
+
+def test_launcher_fails_as_a_whole(hostemu, tmp_path):
+    """a rank that fails (more ranks than loci here) takes the job down with a non-zero status instead of leaving
+    the others waiting in the next exchange"""
+    exe = os.path.join(REPO, "g-phocs_amd", "G-PhoCS-hip")
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, "z0" + ext), tmp_path)
+    nloci = int(open(os.path.join(GOLDEN, "z0.seq")).read().split()[0])
+    ranks = min(nloci * 2 + 1, 40)
+    r = subprocess.run([exe, "-g", str(ranks), "z0.ctl"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GPHOCS_HIP_LIB=hostemu))
+    if ranks > nloci:
+        assert r.returncode != 0
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(repo)r)
+import gphocs_amd as G
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+lib = G.load_library(%(lib)r)
+comm = lib.gph_comm_create_shm(%(name)r.encode(), rank, world)
+assert comm
+s = G.Sampler(G.Pack.load(%(pack)r), lib=lib, rank=rank, world=world, comm=comm)
+s.set_record_file(%(out)r + ".%%d" %% rank)
+s.initialize()
+for it in range(%(iters)d):
+    s.iteration(it)
+s.set_record_file(None)
+hs = s.host_stats()
+assert hs["collectives"] > 0 and not hs["resident"]
+s.close()
+lib.gph_comm_destroy(comm)
+'''
+
+
+@pytest.mark.parametrize("name,iters", [("m3", 60), ("a6", 40)])
+def test_sampler_over_native_shm_comm(hostemu, tmp_path, name, iters):
+    """two processes, each with the engine over its shard and a gph_comm_create_shm() communicator: every rank
+    writes the single-rank golden's records"""
+    from parity_util import compare_records
+    out = str(tmp_path / "rec")
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % dict(repo=REPO, lib=hostemu, name=f"/gphocs-test-{os.getpid()}-{name}",
+                                    pack=os.path.join(GOLDEN, name + ".gpk"), out=out, iters=iters))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2"]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    assert open(out + ".0").read() == open(out + ".1").read()
+    mine = open(out + ".0").read().splitlines()
+    golden = open(os.path.join(GOLDEN, name + ".rtrace")).read().splitlines()[:len(mine)]
+    (tmp_path / "g").write_text("\n".join(golden) + "\n")
+    compare_records(out + ".0", str(tmp_path / "g"))
