@@ -59,6 +59,7 @@ static int run_control_file(const char *ctl, const char *ctl2, int32_t device, i
     return code;
   };
   if (lead) printf("Reading control settings from file %s...\n", ctl);
+  if (lead && ctl2) printf("Reading control settings from secondary file %s...\n", ctl2);   /* GPhoCS.c:157-158 */
   if ((rc = gph_control_read(ctl, ctl2, &C))) return fail(rc, "reading the control file");
   gph_control_get(C, &cfg, &mc, &info);
   if (lead) printf("Done.\n");

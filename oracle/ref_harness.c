@@ -59,6 +59,11 @@ static void startup(char *ctl)
   initGeneralInfo();
   res = readControlFile(ctl);
   if (res != 0) { fprintf(stderr, "harness: readControlFile failed\n"); exit(2); }
+  /* the optional secondary control file of main() (GPhoCS.c:154-164), named by the environment for pack / run */
+  if (getenv("GPH_REF_CTL2") && getenv("GPH_REF_CTL2")[0]) {
+    res = readSecondaryControlFile(getenv("GPH_REF_CTL2"));
+    if (res != 0) { fprintf(stderr, "harness: readSecondaryControlFile failed\n"); exit(2); }
+  }
   res = checkSettings();
   finalizeNumParameters();
   if (res > 0) { fprintf(stderr, "harness: %d control errors\n", res); exit(2); }

@@ -65,3 +65,12 @@ $RT f3.trace -b 10 -d 20 > f3.readtrace_b10_d20.txt
 # the reference binary's stdout log for the same runs (banner, title, one line per log period, finetune search):
 # G-PhoCS-hip prints the same text from "Starting MCMC" on (the elapsed-time column aside)
 for name in g1 f3 v8 a7; do timeout 900 $REF main -n 1 $name.ctl > $name.stdout 2>/dev/null; done
+
+# w2: primary + SECONDARY control file (GPhoCS.c:35-43, 154-164; readSecondaryControlFile, MCMCcontrol.c:178-210):
+# w2b.ctl (hand-written) overrides GENERAL-INFO keys (seed, iterations, log period, two finetunes, band print factor
+# and prior) and replaces the two bands of w2.ctl by three others.  pack / run take it through GPH_REF_CTL2.
+$GEN --config 3 --loci 14 --seqlen 300 --iters 60 --per-log 20 --mig-beta 0.00000004 --out w2 2>/dev/null
+GPH_REF_CTL2=w2b.ctl timeout 600 $REF pack w2.ctl w2.gpk >/dev/null
+GPH_REF_CTL2=w2b.ctl timeout 600 $REF run w2.ctl 0 w2.init.rtrace w2.init.state -1 1 >/dev/null; rm -f w2.init.rtrace
+GPH_REF_CTL2=w2b.ctl timeout 600 $REF run w2.ctl 50 w2.rtrace w2.state 49 1 >/dev/null
+timeout 900 $REF main -n 1 w2.ctl w2b.ctl > w2.stdout 2>/dev/null

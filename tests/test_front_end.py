@@ -45,11 +45,16 @@ def _in_dir(path):
     return _Cd()
 
 
-@pytest.mark.parametrize("name", CASES)
+# name -> secondary control file (the optional second command-line argument of G-PhoCS, GPhoCS.c:35-43, 154-164;
+# readSecondaryControlFile, MCMCcontrol.c:178-210: its GENERAL-INFO keys override, its MIG-BANDS module replaces)
+SECONDARY = {"w2": "w2b.ctl"}
+
+
+@pytest.mark.parametrize("name", CASES + ["w2"])
 def test_control_and_sequences_match_reference_pack(lib, name):
     ref = G.Pack.load(os.path.join(GOLDEN, name + ".gpk"))
     with _in_dir(GOLDEN):   # seq-file names in the control files are relative
-        got = G.Pack.from_control(name + ".ctl", lib=lib, threads=3)
+        got = G.Pack.from_control(name + ".ctl", lib=lib, threads=3, secondary=SECONDARY.get(name))
     for f in ("n", "Kc", "K", "B", "rootPop", "L", "seed", "startMig", "doMixing", "samplesPerLog", "mutRateMode",
               "numParameters", "burnin", "sampleSkip", "ftCoalTime", "ftMigTime", "ftTheta", "ftMigRate",
               "ftMixing", "popName") + (("varRatesAlpha", "ftLocusRate") if ref.mutRateMode == 1 else ()):
@@ -73,15 +78,18 @@ def test_thread_count_does_not_change_the_result(lib):
         assert np.array_equal(getattr(a, f), getattr(b, f))
 
 
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2"])
 def test_program_writes_the_reference_trace_file(lib, name, tmp_path):
     """same control file + sequence file -> the trace file of the real G-PhoCS binary, byte for byte
     (f3: find-finetunes TRUE -- the step-size search of performMCMC, GPhoCS.c:1896-2180, incl. its acceptance
     bookkeeping quirks, must take the same decisions for the chain to stay on the reference's trajectory)"""
     for ext in (".ctl", ".seq"):
         shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    ctl2 = SECONDARY.get(name)
+    if ctl2:
+        shutil.copy(os.path.join(GOLDEN, ctl2), tmp_path)
     with _in_dir(tmp_path):
-        assert lib.gph_run_control_file((name + ".ctl").encode(), None, 0, 0) == 0
+        assert lib.gph_run_control_file((name + ".ctl").encode(), ctl2.encode() if ctl2 else None, 0, 0) == 0
     want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
     got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
     assert want[0] == got[0]                      # header
@@ -210,7 +218,7 @@ def test_read_trace_partial_tail_and_errors(lib, tmp_path):
     assert rc == 0 and got.split("\n")[1].split() == ["2.000000", "3.500000"]
 
 
-@pytest.mark.parametrize("name", ["g1", "f3", "v8", "a7"])
+@pytest.mark.parametrize("name", ["g1", "f3", "v8", "a7", "w2"])
 def test_program_prints_the_reference_log(name, tmp_path):
     """stdout of gph_run_control_file against the real binary's stdout for the same control file (tests/golden/*.stdout):
     from "Reading control settings" on (i.e. everything but the version banner and the thread-count line) -- title, one `\\r`-refreshed line per log period with the acceptance percentages exactly as
@@ -221,12 +229,15 @@ def test_program_prints_the_reference_log(name, tmp_path):
     import subprocess
     for ext in (".ctl", ".seq"):
         shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    ctl2 = SECONDARY.get(name)
+    if ctl2:
+        shutil.copy(os.path.join(GOLDEN, ctl2), tmp_path)
     code = ("import sys, ctypes as C; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import gphocs_amd as G, run_hostemu as R\n"
             "lib = G.load_library(R.build_hostemu())\n"
             "lib.gph_run_control_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]\n"
-            "sys.exit(lib.gph_run_control_file(%r, None, 0, 0))\n") % (REPO, os.path.join(REPO, "tests", "hostemu"),
-                                                                     (name + ".ctl").encode())
+            "sys.exit(lib.gph_run_control_file(%r, %r, 0, 0))\n") % (REPO, os.path.join(REPO, "tests", "hostemu"),
+                                                                   (name + ".ctl").encode(), ctl2.encode() if ctl2 else None)
     r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
 

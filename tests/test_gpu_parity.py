@@ -16,7 +16,8 @@ from parity_util import compare_records, compare_states
 
 pytestmark = pytest.mark.gpu
 
-CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, "a7": 100, "z0": 12, "v8": 60, "v9": 60}
+CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, "a7": 100, "z0": 12, "v8": 60, "v9": 60,
+         "w2": 50}   # w2: model from a primary + a secondary control file
 
 
 @pytest.fixture(scope="module")
@@ -309,7 +310,7 @@ def test_native_library_is_the_path(G):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2"])
 def test_program_trace_file(name, tmp_path):
     """G-PhoCS-hip <control-file> on the MI355X: the trace file of the real G-PhoCS binary for the same
     control + sequence files (tests/golden/*.trace), to the printed precision (%8.5f / %.6f)."""
@@ -319,7 +320,11 @@ def test_program_trace_file(name, tmp_path):
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     for ext in (".ctl", ".seq"):
         shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
-    r = subprocess.run([exe, name + ".ctl"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    extra = []
+    if name == "w2":     # primary + secondary control file (GPhoCS.c:35-43, MCMCcontrol.c:178-210)
+        shutil.copy(os.path.join(GOLDEN, "w2b.ctl"), tmp_path)
+        extra = ["w2b.ctl"]
+    r = subprocess.run([exe, name + ".ctl"] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
     got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
