@@ -74,3 +74,6 @@ GPH_REF_CTL2=w2b.ctl timeout 600 $REF pack w2.ctl w2.gpk >/dev/null
 GPH_REF_CTL2=w2b.ctl timeout 600 $REF run w2.ctl 0 w2.init.rtrace w2.init.state -1 1 >/dev/null; rm -f w2.init.rtrace
 GPH_REF_CTL2=w2b.ctl timeout 600 $REF run w2.ctl 50 w2.rtrace w2.state 49 1 >/dev/null
 timeout 900 $REF main -n 1 w2.ctl w2b.ctl > w2.stdout 2>/dev/null
+
+# x8: the engine's hard caps -- 32 leaves, 31 populations (16 current), 16 migration bands (library variant `x`)
+gen x8 8 10 300 24 8 --mig-beta 0.00000004

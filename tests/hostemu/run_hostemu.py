@@ -19,7 +19,9 @@ def build_hostemu(sanitize=False):
     deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
     if os.path.exists(HOSTEMU) and all(os.path.getmtime(HOSTEMU) >= os.path.getmtime(d) for d in deps):
         return HOSTEMU
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+    # the engine's hard caps (library variant `x`): every golden fits, the image size does not matter on the host
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU", "-DGPH_CAP_LEAVES=32", "-DGPH_CAP_K=32", "-DGPH_CAP_B=16",
+           "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
            "-x", "c++"] + srcs + ["-lrt", "-o", HOSTEMU]
     if sanitize:
         cmd[1:1] = ["-fsanitize=address,undefined"]

@@ -120,3 +120,78 @@ def test_full_size_determinism_checkall_and_shard_invariance(G, tmp_path):
     assert open(out + ".0").read() == open(out + ".1").read()
     worst = compare_records(out + ".0", a)
     print(f"full size: {iters} iterations deterministic; two ranks vs one: worst accumulator rel diff {worst:.3e}")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the OTHER BASELINE configs at their stated sizes (configs[3] = the benchmark workload is covered above):
+#   configs[1]  10 000 loci x 1 kb, 4 diploid samples ( 8 leaves), 3-population tree, no migration bands
+#   configs[2]  40 000 loci,        6 diploid samples (12 leaves), 3-population tree + 2 migration bands, het integration
+#   configs[4] 200 000 loci,       10 diploid samples (20 leaves), 7-population tree + 4 bands, one FIXED ancient sample
+#              (mixing off: MCMCcontrol.c:903-907); library variant `l`
+FULL = {1: dict(synth=2, L=10000, n=8, K=5, B=0), 2: dict(synth=3, L=40000, n=12, K=5, B=2),
+        4: dict(synth=5, L=200000, n=20, K=13, B=4)}
+
+WORKER_SHM = r'''
+import os, sys
+sys.path.insert(0, %(repo)r)
+import gphocs_amd as G, bench
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+pk = bench.build_workload(G, %(synth)d, %(L)d, 6.5, 20261002 + %(synth)d, %(cache)r)
+pk.samplesPerLog = %(spl)d
+lib = G.load_library(dims=(pk.n, pk.K, pk.B))
+comm = lib.gph_comm_create_shm(%(name)r.encode(), rank, world)
+assert comm
+s = G.Sampler(pk, lib=lib, device=0, rank=rank, world=world, comm=comm)
+s.set_record_file(%(out)r + ".%%d" %% rank)
+s.initialize()
+for it in range(%(iters)d):
+    s.iteration(it)
+s.set_record_file(None)
+s.close()
+lib.gph_comm_destroy(comm)
+'''
+
+
+@pytest.mark.parametrize("idx", [1, 2, 4])
+def test_other_configs_at_full_size(G, oracle_cli, tmp_path, idx):
+    """(a) the first 4 iterations against the oracle run live on ALL loci (two checkAll resynchronisations): accept
+    counters exact, accumulators within 1e-10 relative; (b) run-to-run determinism and checkAll at every log period over
+    a longer trajectory; (c) shard invariance: the same chain over two ranks (two processes on this GPU, native
+    shared-memory communicator) takes identical decisions"""
+    import bench
+    from gphocs_amd_pkg import synth
+    c = FULL[idx]
+    pk = bench.build_workload(G, c["synth"], c["L"], 6.5, 20261002 + c["synth"], CACHE)
+    assert (pk.L, pk.n, pk.K, pk.B) == (c["L"], c["n"], c["K"], c["B"])
+    # (a)
+    pk.samplesPerLog = 2
+    pth = str(tmp_path / "full.gpk")
+    synth.write_pack(pk, pth)
+    mine, theirs = str(tmp_path / "hip.rec"), str(tmp_path / "oracle.rec")
+    cnt, _ = _run(G, pk, 4, mine)
+    subprocess.run([oracle_cli, "run", pth, "4", theirs], check=True, timeout=1800)
+    os.unlink(pth)
+    worst = compare_records(mine, theirs)
+    assert any(l.startswith("IT 3 CHECK") for l in open(mine).read().splitlines())
+    # (b)
+    iters, spl = 12, 4
+    pk.samplesPerLog = spl
+    a, b = str(tmp_path / "a.rec"), str(tmp_path / "b.rec")
+    cnt_a, acc_a = _run(G, pk, iters, a)
+    cnt_b, acc_b = _run(G, pk, iters, b)
+    ra = open(a).read()
+    assert ra == open(b).read() and cnt_a == cnt_b and acc_a == acc_b
+    assert sum(1 for l in ra.splitlines() if " CHECK " in l) == iters // spl
+    # (c)
+    out = str(tmp_path / "rk")
+    script = tmp_path / "w.py"
+    script.write_text(WORKER_SHM % dict(repo=REPO, synth=c["synth"], L=c["L"], cache=CACHE, spl=spl, out=out, iters=iters,
+                                        name=f"/gphocs-full-{os.getpid()}-{idx}"))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2"]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=1800) == 0
+    assert open(out + ".0").read() == open(out + ".1").read()
+    worst2 = compare_records(out + ".0", a)
+    P = __import__("numpy").diff(pk.pattern_offsets)
+    print(f"configs[{idx}]: {c['L']} loci x {c['n']} leaves, mean {P.mean():.1f} / max {P.max()} phased patterns, "
+          f"{cnt['evals']} evaluations in 4 iterations; vs oracle worst rel diff {worst:.3e}; two ranks vs one {worst2:.3e}")

@@ -17,7 +17,8 @@ from parity_util import compare_records, compare_states
 pytestmark = pytest.mark.gpu
 
 CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, "a7": 100, "z0": 12, "v8": 60, "v9": 60,
-         "w2": 50}   # w2: model from a primary + a secondary control file
+         "w2": 50,   # w2: model from a primary + a secondary control file
+         "x8": 24}   # x8: the engine's hard caps (32 leaves, 31 populations, 16 bands; library variant x)
 
 
 @pytest.fixture(scope="module")

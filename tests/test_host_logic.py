@@ -25,7 +25,7 @@ def hostemu():
     return R, G.load_library(R.build_hostemu())
 
 
-@pytest.mark.parametrize("name,iters", [("g1", 30), ("g2", 30), ("m3", 120), ("m4", 60), ("c5", 30), ("s3", 40), ("a6", 80), ("a7", 100), ("z0", 12), ("v8", 60), ("v9", 60), ("w2", 50)])
+@pytest.mark.parametrize("name,iters", [("g1", 30), ("g2", 30), ("m3", 120), ("m4", 60), ("c5", 30), ("s3", 40), ("a6", 80), ("a7", 100), ("z0", 12), ("v8", 60), ("v9", 60), ("w2", 50), ("x8", 24)])
 def test_hostemu_matches_reference_goldens(hostemu, name, iters, tmp_path):
     R, lib = hostemu
     tr, st = tmp_path / "t", tmp_path / "s"

@@ -1,17 +1,33 @@
-import os, sys, time
-sys.path.insert(0, os.getcwd())
-import gphocs_amd as G, bench
-lib = G.load_library(sys.argv[1])
-L = 50000
-pack = bench.build_workload(G, 5, L, 3.0, 20261007, "bench_cache")
-s = G.Sampler(pack, lib=lib); s.initialize()
-for it in range(3): s.iteration(it)
-s.counters(reset=True)
-for k in range(16): s.class_stats(k, reset=True)
-t0 = time.perf_counter()
-for it in range(3, 9): s.iteration(it)
-dt = time.perf_counter() - t0
-c = s.counters(); sw = s.class_stats(0)
+#!/usr/bin/env python3
+"""BASELINE configs[4] at its stated size: 200 000 loci x 1 kb, 10 diploid samples (20 leaves), 7-population tree,
+4 migration bands, one fixed ancient sample (library variant `l`).  python tools/bench_config5.py [lib.so] [loci]"""
+import json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
 import numpy as np
-print(f"{sys.argv[1]}: config5 L={L} P mean {np.diff(pack.pattern_offsets).mean():.1f}: {c['evals']/dt/1e6:.1f} M evals/s, {6/dt:.2f} it/s, sweep {sw['ms']/sw['launches']:.2f} ms")
+import gphocs_amd as G, bench
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+pack = bench.build_workload(G, 5, L, 6.5, 20261007, os.path.join(REPO, "bench_cache"))
+lib = G.load_library(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "-" else G.load_library(dims=(pack.n, pack.K, pack.B))
+s = G.Sampler(pack, lib=lib)
+s.initialize()
+for it in range(5):
+    s.iteration(it)
+s.counters(reset=True)
+for k in range(16):
+    s.class_stats(k, reset=True)
+t0 = time.perf_counter()
+N = 10
+for it in range(5, 5 + N):
+    s.iteration(it)
+dt = time.perf_counter() - t0
+c = s.counters()
+sw, te = s.class_stats(0), s.class_stats(1)
+P = np.diff(pack.pattern_offsets)
+print(json.dumps({"workload": f"BASELINE configs[4]: {L} loci, 20 leaves, 13 populations, 4 bands, fixed ancient sample",
+                  "mean_phased_patterns": float(P.mean()), "max_phased_patterns": int(P.max()),
+                  "evals_per_s": c["evals"] / dt, "iters_per_s": N / dt, "ms_per_iteration": dt / N * 1e3,
+                  "sweep_ms": sw["ms"] / sw["launches"], "sweep_algorithmic_bytes": sw["bytes"] / sw["launches"],
+                  "sweep_roofline_frac": sw["bytes"] / sw["launches"] / (sw["ms"] / sw["launches"] * 1e-3) / 8e12,
+                  "tau_eval_ms": te["ms"] / max(te["launches"], 1), "hbm_resident_bytes": s.hbm_bytes()}))
 s.close()

@@ -33,6 +33,8 @@ CONFIGS = {
     # estimated ("e") sample ages: UpdateSampleAge is live, mixing stays on
     6: dict(pops=[2, 2, 2, 1], bands=[(0, 1), (3, 2), (2, 3)], loci=1000, ancient=3, ancient_est=True),
     7: dict(pops=[2, 1, 2], bands=[(0, 1), (1, 0), (2, 1)], loci=1000, ancient=1, ancient_est=True),
+    # the engine's hard caps: 32 leaves (16 diploids, one per population), 31 populations, 16 migration bands
+    8: dict(pops=[1] * 16, bands=[(i, i + 1) for i in range(8)] + [(i + 1, i) for i in range(8)], loci=1000, tau_factor=1.3),
 }
 
 
@@ -54,7 +56,7 @@ def build_tree(cfg):
     t = 5e-6
     for i in range(kc - 1):
         taus.append(t)
-        t *= 2.0 if i < kc - 3 else 5.0 if i == kc - 3 else 1.0
+        t *= cfg.get("tau_factor", 2.0) if i < kc - 3 else 5.0 if i == kc - 3 else 1.0
     return cur, anc, taus
 
 
