@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--cpu-loci", type=int, default=5000)
     ap.add_argument("--cpu-iters", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lib", default=None, help="alternative build of the library (A/B measurements)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "hook"], help="cross-rank exchange: native RCCL all-gather on "
                     "the engine's stream (default) or the torch.distributed hook (a host round trip per reduction)")
     a = ap.parse_args()
@@ -245,7 +246,7 @@ def main():
     pack = build_shard(G, a.config, L_total, begin, end, a.mut_scale, 20261002 + a.config, os.path.join(REPO, "bench_cache"))
     if a.samples_per_log > 0:
         pack.samplesPerLog = a.samples_per_log
-    lib = G.load_library(dims=(pack.n, pack.K, pack.B))
+    lib = G.load_library(a.lib) if a.lib else G.load_library(dims=(pack.n, pack.K, pack.B))
     if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm (bench bookkeeping only)

@@ -894,8 +894,8 @@ int gph_engine_set_model(gph_engine *e, const double *theta, const double *popAg
 {
   if (!e || !theta || !popAge || !sampleAge) return GPH_EARG;
   GphModel &m = e->G_h->model;
-  for (int p = 0; p < e->cfg.K; p++) { m.theta[p] = theta[p]; m.thetaInv[p] = 1.0 / theta[p]; m.popAge[p] = popAge[p]; m.sampleAge[p] = sampleAge[p]; }
-  for (int b = 0; b < e->cfg.B; b++) { m.migRate[b] = migRate[b]; m.bandStart[b] = bandStart[b]; m.bandEnd[b] = bandEnd[b]; }
+  for (int p = 0; p < e->cfg.K; p++) { gg_set_theta(*e->G_h, p, theta[p]); m.popAge[p] = popAge[p]; m.sampleAge[p] = sampleAge[p]; }
+  for (int b = 0; b < e->cfg.B; b++) { gg_set_mig(*e->G_h, b, migRate[b]); m.bandStart[b] = bandStart[b]; m.bandEnd[b] = bandEnd[b]; }
   e->model_set = true;
   e->G_dirty = true;
   return 0;

@@ -135,7 +135,11 @@ GPH_HD void gg_compute_band_times(GphGlobal &G)
     if (M.bandStart[b] >= M.bandEnd[b]) M.bandStart[b] = M.bandEnd[b] = M.popAge[M.bandTgt[b]];
   }
 }
-GPH_HD void gg_set_theta(GphGlobal &G, int pop, double v) { G.model.theta[pop] = v; G.model.thetaInv[pop] = 1.0 / v; }
+GPH_HD void gg_set_theta(GphGlobal &G, int pop, double v)
+{
+  G.model.theta[pop] = v; G.model.thetaInv[pop] = 1.0 / v; G.model.logTwoTheta[pop] = gph_log(2 / v);
+}
+GPH_HD void gg_set_mig(GphGlobal &G, int b, double v) { G.model.migRate[b] = v; G.model.logMigRate[b] = gph_log(v); }
 
 GPH_HD void gg_rec(GphGlobal &G, int code, int idx, long long acc)
 {
@@ -167,7 +171,7 @@ GPH_HD void gg_sample_pop_parameters(GphGlobal &G)
       queue[tail++] = M.popSon1[pop];
     }
   }
-  for (int b = 0; b < G.B; b++) M.migRate[b] = 0.0;
+  for (int b = 0; b < G.B; b++) gg_set_mig(G, b, 0.0);
   gg_compute_band_times(G);
 }
 
@@ -257,7 +261,7 @@ GPH_HD void gg_theta_and_mig_rates(GphGlobal &G)
           accepted++;
           GphApply &a = G.apply[G.napply++];
           a.kind = 1; a.idx = b; a.lnc = lnc; a.diff = (new_rate - old_rate);
-          M.migRate[b] = new_rate;
+          gg_set_mig(G, b, new_rate);
           G.logLikelihood += dLL / G.Ltot;
         }
       }
@@ -469,7 +473,8 @@ GPH_HD void gg_mix_propose(GphGlobal &G)
   }
   for (b = 0; b < G.B; b++) {
     xold = M.migRate[b];
-    M.migRate[b] = xnew = xold / c;
+    xnew = xold / c;
+    gg_set_mig(G, b, xnew);
     lnacc += -lnc * (G.mrAlpha[b] - 1) - (xnew - xold) * G.mrBeta[b];
     M.bandStart[b] *= c;
     M.bandEnd[b] *= c;
@@ -503,7 +508,7 @@ GPH_HD void gg_mix_decide(GphGlobal &G, const GphRed &R)
     if (pop < G.Kc && M.sampleAge[pop] > 0.0) M.sampleAge[pop] /= c;
   }
   for (b = 0; b < G.B; b++) {
-    M.migRate[b] *= c;
+    gg_set_mig(G, b, M.migRate[b] * c);
     M.bandStart[b] /= c;
     M.bandEnd[b] /= c;
   }
@@ -540,7 +545,7 @@ GPH_HD void gg_stage(GphGlobal &G, const GphRed &R, int stage, int arg)
     G.shownValid = 1;
     for (int b = 0; b < G.B; b++) {
       double mean = G.mrAlpha[b] / G.mrBeta[b];
-      G.model.migRate[b] = mean * (0.9 + 0.2 * gg_rndu(G));
+      gg_set_mig(G, b, mean * (0.9 + 0.2 * gg_rndu(G)));
     }
     break;
   case GS_REFRESH_DONE:   /* genLogLikelihood refresh, GPhoCS.c:1749-1757: out 0 ok, 1 old, 2 new genLnL */

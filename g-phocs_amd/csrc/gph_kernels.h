@@ -155,13 +155,13 @@ GPH_DEV void out_common(const GphDev &D, int g)
     o[8] = CNT(CN_EVALS);
     o[9] = CNT(CN_NODES);
     o[10] = gf64(&GphLds::s_cntf, 0);
-    o[11] = CNT(CN_ERROR);
+    o[11] = gph_errcode();
     o[13] = CNT(CN_NOTENOUGH);
-    if (CNT(CN_ERROR) != 0) {
+    if (gph_errcode() != 0) {
 #ifdef GPH_HOSTEMU
-      if (*D.err == 0) *D.err = CNT(CN_ERROR);
+      if (*D.err == 0) *D.err = gph_errcode();
 #else
-      atomicMax(D.err, CNT(CN_ERROR));
+      atomicMax(D.err, gph_errcode());
 #endif
     }
   }
@@ -1107,7 +1107,7 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
   if (GPH_LANE == 0) {
     /* the reference locus's own record is written by the host once every rank's block has been scanned */
     A.result[13] = rref; A.result[14] = likref;
-    A.result[0] = accepted; A.result[1] = dataLnL; A.result[2] = logL; A.result[3] = rateVar; A.result[4] = CNT(CN_ERROR);
+    A.result[0] = accepted; A.result[1] = dataLnL; A.result[2] = logL; A.result[3] = rateVar; A.result[4] = gph_errcode();
     A.result[5] = hits;
 #ifndef GPH_HOSTEMU
     A.result[6] = (double)(__builtin_readcyclecounter() - clk0);            /* shader-clock cycles of the scan */

@@ -226,6 +226,8 @@ GPH_DEVHOT GphEvS ld_ev(int ev)
 #endif
 GPH_DEV void gph_fail(int code) { if (CNT(CN_ERROR) == 0) setCNT(CN_ERROR, code); }
 GPH_DEV int gph_failed() { return CNT(CN_ERROR) != 0; }
+GPH_DEV int gph_errcode() { return CNT(CN_ERROR); }
+
 GPH_DEV void load_scalars()
 {
 #ifdef GPH_HOSTEMU
@@ -656,8 +658,34 @@ GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1,
   f3 = Sp + s3 * qm;
 }
 
+// factors of a child that is NOT in the registers: a leaf (base code) or an internal node's array at cb + off
+template <class DP, class DP2>
+GPH_DEVHOT void child_generic4(int child, DP cb, int off, double pe, double qe, bool act, double &f0, double &f1, double &f2,
+                               double &f3, int q_leaf)
+{
+  child_factor4<DP, DP2>(child, cb + off, false, 0.0, 0.0, 0.0, 0.0, pe, qe, act, f0, f1, f2, f3, q_leaf);
+}
+// factors of the child whose conditionals are still in the registers, in place
+GPH_DEVHOT void child_inplace4(double &s0, double &s1, double &s2, double &s3, double pe, double qe)
+{
+  double S = s0;
+  S += s1;
+  S += s2;
+  S += s3;
+  const bool miss = S >= 4;
+  const double Sp = miss ? 1.0 : S * pe;
+  const double qm = miss ? 0.0 : qe;
+  s0 = Sp + s0 * qm;
+  s1 = Sp + s1 * qm;
+  s2 = Sp + s2 * qm;
+  s3 = Sp + s3 * qm;
+}
+
 // recompute node `node`; on entry q* hold node `prev`'s conditionals (prev < 0: nothing), on exit
-// this node's.  po / lo / ro = offsets (in doubles) of the node's and its children's current arrays
+// this node's.  po / lo / ro = offsets (in doubles) of the node's and its children's current arrays.
+// Three straight code paths -- left child in the registers, right child in the registers, neither -- so that the
+// forwarded conditionals are used where they are (no register copies to pick an operand); f_right * f_left is
+// f_left * f_right bit for bit (IEEE multiplication commutes).
 template <class DP, class DP2>
 GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo, int ro,
                              int P, DP cb, int prev,
@@ -668,19 +696,24 @@ GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo,
   const int lane = GPH_LANE;
   const bool act = lane < P;
   DP pc = cb + po;
-  DP lc = cb + lo;
-  DP rc = cb + ro;
-  const bool fl = l == prev, fr = r == prev;
   /* a child recomputed earlier in this evaluation is re-read after its stores: memory operations of one
    * wavefront are performed in order, only the compiler must not reorder them (no instruction) */
   GPH_WAVE_FENCE();
-  double f0, f1, f2, f3, g0, g1, g2, g3;
-  child_factor4<DP, DP2>(l, lc, fl, q0, q1, q2, q3, pl, ql, act, f0, f1, f2, f3, q_leaf);
-  child_factor4<DP, DP2>(r, rc, fr, q0, q1, q2, q3, pr, qr, act, g0, g1, g2, g3, q_leaf);
-  q0 = f0 * g0;
-  q1 = f1 * g1;
-  q2 = f2 * g2;
-  q3 = f3 * g3;
+  double g0, g1, g2, g3;
+  if (l == prev) {
+    child_inplace4(q0, q1, q2, q3, pl, ql);
+    child_generic4<DP, DP2>(r, cb, ro, pr, qr, act, g0, g1, g2, g3, q_leaf);
+  } else if (r == prev) {
+    child_inplace4(q0, q1, q2, q3, pr, qr);
+    child_generic4<DP, DP2>(l, cb, lo, pl, ql, act, g0, g1, g2, g3, q_leaf);
+  } else {
+    child_generic4<DP, DP2>(l, cb, lo, pl, ql, act, q0, q1, q2, q3, q_leaf);
+    child_generic4<DP, DP2>(r, cb, ro, pr, qr, act, g0, g1, g2, g3, q_leaf);
+  }
+  q0 = q0 * g0;
+  q1 = q1 * g1;
+  q2 = q2 * g2;
+  q3 = q3 * g3;
   if (act) {
     DP2 o2 = (DP2)(pc + 4 * lane);
     gph_d2 a = {q0, q1}, b = {q2, q3};
@@ -768,11 +801,14 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     if (off >= 0) (void)*(const volatile GPH_GLB int *)((const GPH_GLB char *)cb + off);
   }
   STAMPB_END(2);
-  for (int guard = 0; todo != 0; guard++) {
-    if (wide) {
+  /* the two mappings are separate loops (the choice is per locus): the per-pattern one keeps the conditionals of the
+   * node just computed in registers from step to step, and its loop must stay simple enough for that */
+  bool failed = false;
+  if (wide) {
+    for (int guard = 0; todo != 0; guard++) {
       bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
       uint64_t rmask = __ballot(rdy);
-      if (rmask == 0 || guard > N) { gph_fail(100); return FS(FS_DATALNL); }
+      if (rmask == 0 || guard > N) { failed = true; break; }
       while (rmask) {
         const int node = __builtin_ctzll(rmask);
         const uint64_t bit = (uint64_t)1 << node;
@@ -784,10 +820,13 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
         STAMP_END(7);
         todo &= ~bit;
       }
-    } else {
-      /* one node per step.  Usual case: a dirty path is a chain, the next node is the father of the one just
-       * computed (whose conditionals are still in registers) -- three lane reads and a bit test.  Otherwise
-       * (start, or the father waits for its other subtree) any node whose recomputed children are done. */
+    }
+  } else {
+    /* one node per step.  Usual case: a dirty path is a chain, the next node is the father of the one just
+     * computed (whose conditionals are still in registers) -- three lane reads and a bit test.  Otherwise
+     * (start, or the father waits for its other subtree) any node whose recomputed children are done. */
+    int guard = 0;
+    while (todo != 0) {
       int node = -1, l = 0, r = 0;
       if (prev >= 0) {
         const int f = __builtin_amdgcn_readlane(fal, prev);
@@ -801,7 +840,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       if (node < 0) {
         bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
         const uint64_t rmask = __ballot(rdy);
-        if (rmask == 0 || guard > N) { gph_fail(100); return FS(FS_DATALNL); }
+        if (rmask == 0 || ++guard > N) { failed = true; break; }
         node = __builtin_ctzll(rmask);
         l = __builtin_amdgcn_readlane(le, node);
         r = __builtin_amdgcn_readlane(ri, node);
@@ -815,6 +854,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       prev = node;
     }
   }
+  if (failed) { gph_fail(100); return FS(FS_DATALNL); }
   setCNT(CN_NODES, CNT(CN_NODES) + nord);
   STAMPB_BEGIN(3);
   /* write the dirty / current-buffer sets back, append the newly marked nodes to the list */
@@ -1392,11 +1432,11 @@ GPH_DEV double gtree_lnl()
   double lnLd = 0, theta, rate;
   for (pop = 0; pop < g_lay.K; pop++) {
     theta = g_model.theta[pop];
-    lnLd += NCOAL(pop) * gph_log_u(2 / theta) - COALS(pop) / (theta);
+    lnLd += NCOAL(pop) * g_model.logTwoTheta[pop] - COALS(pop) / (theta);
   }
   for (b = 0; b < g_lay.B; b++) {
     rate = g_model.migRate[b];
-    if (rate > 0.0) lnLd += NMIGB(b) * gph_log_u(rate) - MIGST(b) * rate;
+    if (rate > 0.0) lnLd += NMIGB(b) * g_model.logMigRate[b] - MIGST(b) * rate;
   }
   return lnLd;
 }
@@ -1893,7 +1933,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
     if (RECONNECT) lnld -= rate * t;
     else lnld -= (mig_rate + gph_div_by(2 * nlin, theta, thinv)) * t;
     if (mig_source >= 0) {
-      lnld += gph_log_u(g_model.migRate[b]);
+      lnld += g_model.logMigRate[b];
       ev = mig_source;
       setDCOAL(inst, pop, dcoal);
       pop = g_model.bandSrc[b];
@@ -1921,7 +1961,7 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
     ev = (ev == ev0) ? R.next : ENEXT(ev);   /* nothing is inserted AFTER the interval within a step */
   }
   setDCOAL(inst, pop, dcoal);
-  lnld += gph_log_u(2 / theta);
+  lnld += g_model.logTwoTheta[pop];
   setDI(inst, DI_NEV, nev);
   setSPRLN(RECONNECT, lnld);
   return 0;

@@ -38,6 +38,10 @@ enum { GPH_COAL = 0, GPH_IN_MIG, GPH_OUT_MIG, GPH_MIG_BAND_START, GPH_MIG_BAND_E
 struct GphModel {
   double theta[GPH_MAXK], popAge[GPH_MAXK], sampleAge[GPH_MAXK];
   double thetaInv[GPH_MAXK];           // RN(1/theta), host division: see gph_div_theta()
+  // log(2 / theta[pop]) and log(migRate[band]) (gph_math.h's log: bit-identical on host and device): both are added
+  // once per lineage walk / migration event of the SPR (patch.c:1325, :1268) -- a table entry instead of a division
+  // and a ~50-instruction wave-uniform logarithm twice per proposal.  Kept current by gg_set_theta / gg_set_mig.
+  double logTwoTheta[GPH_MAXK], logMigRate[GPH_MAXB];
   double migRate[GPH_MAXB], bandStart[GPH_MAXB], bandEnd[GPH_MAXB];
   uint32_t isAnc[GPH_MAXK];            // bit d of isAnc[a]: a is ancestral to (or is) d
   // 32-bit entries: a scalar load cannot fetch 16 bits, and a 16-bit table would be read with vector loads

@@ -9,10 +9,10 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/warm.json" 2> "$OUT/warm.err"   # fills bench_cache/
+python3 bench.py --steps 2 --warmup 1 --preroll 0 --no-cpu-baseline > "$OUT/warm.json" 2> "$OUT/warm.err"   # fills bench_cache/
 pass() { # name counters...
   local name=$1; shift
-  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" -d "$OUT/$name" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/$name.log" 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" -d "$OUT/$name" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --preroll 0 --no-cpu-baseline > "$OUT/$name.log" 2>&1)
   echo "pass $name rc=$?"
 }
 pass insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM
