@@ -618,13 +618,14 @@ typedef GPH_GLB gph_d2 gdbl2;
 // LocusDataLikelihood.c:1650-1673; same operations in the same order as child_factor())
 template <class CP, class CP2>
 GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1, double q2, double q3,
-                              double pe, double qe, bool act, double &f0, double &f1, double &f2, double &f3,
+                              double pe, double qe, int lc, double &f0, double &f1, double &f2, double &f3,
                               int q_leaf)
 {
-  const int lane = GPH_LANE;
+  /* lc = min(lane, P - 1): lanes beyond the last pattern repeat its (unconditional, in-range) loads -- their results
+   * are never stored or summed, and no execution mask / fill value is needed around the loads */
   if (child < g_lay.n) {
     /* leaf: one-hot (or N).  S = 1 exactly, so S*pe = pe and sa*qe is qe or 0: bit-identical shortcut */
-    const int code = act ? (int)gu8v(q_leaf, lane * g_lay.n + child) : 4;
+    const int code = (int)gu8v(q_leaf, lc * g_lay.n + child);
     const double hit = pe + qe;
     const double other = code == 4 ? 1.0 : pe;   /* N: every base gets 1.0 (no code matches below) */
     f0 = code == 0 ? hit : other;
@@ -635,12 +636,8 @@ GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1,
   }
   double s0 = q0, s1 = q1, s2 = q2, s3 = q3;
   if (!fwd) {
-    gph_d2 a = {1.0, 1.0}, b = {1.0, 1.0};
-    if (act) {
-      CP2 c2 = (CP2)(cnd + 4 * lane);
-      a = c2[0];
-      b = c2[1];
-    }
+    CP2 c2 = (CP2)(cnd + 4 * lc);
+    const gph_d2 a = c2[0], b = c2[1];
     s0 = a.x; s1 = a.y; s2 = b.x; s3 = b.y;
   }
   double S = s0;     /* 0.0 + s0: conditionals are never -0.0 */
@@ -660,10 +657,10 @@ GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1,
 
 // factors of a child that is NOT in the registers: a leaf (base code) or an internal node's array at cb + off
 template <class DP, class DP2>
-GPH_DEVHOT void child_generic4(int child, DP cb, int off, double pe, double qe, bool act, double &f0, double &f1, double &f2,
+GPH_DEVHOT void child_generic4(int child, DP cb, int off, double pe, double qe, int lc, double &f0, double &f1, double &f2,
                                double &f3, int q_leaf)
 {
-  child_factor4<DP, DP2>(child, cb + off, false, 0.0, 0.0, 0.0, 0.0, pe, qe, act, f0, f1, f2, f3, q_leaf);
+  child_factor4<DP, DP2>(child, cb + off, false, 0.0, 0.0, 0.0, 0.0, pe, qe, lc, f0, f1, f2, f3, q_leaf);
 }
 // factors of the child whose conditionals are still in the registers, in place
 GPH_DEVHOT void child_inplace4(double &s0, double &s1, double &s2, double &s3, double pe, double qe)
@@ -688,7 +685,7 @@ GPH_DEVHOT void child_inplace4(double &s0, double &s1, double &s2, double &s3, d
 // f_left * f_right bit for bit (IEEE multiplication commutes).
 template <class DP, class DP2>
 GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo, int ro,
-                             int P, DP cb, int prev,
+                             int P, int lc, DP cb, int prev,
                              double &q0, double &q1, double &q2, double &q3, int q_leaf = GPH_Q_LEAF)
 {
   const double ql = 1 - 4.0 * pl;
@@ -702,13 +699,13 @@ GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo,
   double g0, g1, g2, g3;
   if (l == prev) {
     child_inplace4(q0, q1, q2, q3, pl, ql);
-    child_generic4<DP, DP2>(r, cb, ro, pr, qr, act, g0, g1, g2, g3, q_leaf);
+    child_generic4<DP, DP2>(r, cb, ro, pr, qr, lc, g0, g1, g2, g3, q_leaf);
   } else if (r == prev) {
     child_inplace4(q0, q1, q2, q3, pr, qr);
-    child_generic4<DP, DP2>(l, cb, lo, pl, ql, act, g0, g1, g2, g3, q_leaf);
+    child_generic4<DP, DP2>(l, cb, lo, pl, ql, lc, g0, g1, g2, g3, q_leaf);
   } else {
-    child_generic4<DP, DP2>(l, cb, lo, pl, ql, act, q0, q1, q2, q3, q_leaf);
-    child_generic4<DP, DP2>(r, cb, ro, pr, qr, act, g0, g1, g2, g3, q_leaf);
+    child_generic4<DP, DP2>(l, cb, lo, pl, ql, lc, q0, q1, q2, q3, q_leaf);
+    child_generic4<DP, DP2>(r, cb, ro, pr, qr, lc, g0, g1, g2, g3, q_leaf);
   }
   q0 = q0 * g0;
   q1 = q1 * g1;
@@ -777,6 +774,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   const bool wide = P > GPH_WAVE;   /* more than one pattern per lane: generic (pattern, base) mapping */
   double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
   int prev = -1;
+  const int lc = lane < P ? lane : P - 1;
   /* copyNodeConditionals (LocusDataLikelihood.c:1889) of every node that is going to be recomputed, all at once:
    * a node not yet dirty in this proposal switches to its other array */
   if (useOld) { const uint64_t flip = todo & ~dirty; dirty |= flip; cbit ^= flip; newly |= flip; }
@@ -847,7 +845,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       }
       STAMP_BEGIN(7);
       prune_node_q<gdbl *, gdbl2 *>(l, r, rdlane64(pe, l), rdlane64(pe, r), __builtin_amdgcn_readlane(coff, node),
-                                    __builtin_amdgcn_readlane(coff, l), __builtin_amdgcn_readlane(coff, r), P, cb, prev,
+                                    __builtin_amdgcn_readlane(coff, l), __builtin_amdgcn_readlane(coff, r), P, lc, cb, prev,
                                     q0, q1, q2, q3);
       STAMP_END(7);
       todo &= ~((uint64_t)1 << node);
@@ -1067,7 +1065,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
       const uint64_t bit = (uint64_t)1 << node;
       const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
       prune_node_q<DP, DP2>(l, r, rdlane64(pe, l), rdlane64(pe, r), (node - n) * P * 4, l >= n ? (l - n) * P * 4 : 0,
-                            r >= n ? (r - n) * P * 4 : 0, P, scr, prev, q0, q1, q2, q3, q_leaf);
+                            r >= n ? (r - n) * P * 4 : 0, P, lane < P ? lane : P - 1, scr, prev, q0, q1, q2, q3, q_leaf);
       todo &= ~bit;
       prev = node;
     }
