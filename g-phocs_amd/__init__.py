@@ -155,6 +155,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_comm_unique_id", "gph_comm_create_rccl", "gph_comm_create_shm", "gph_comm_attach_shm", "gph_comm_shm_bytes",
     "gph_comm_destroy", "gph_comm_world", "gph_comm_rank", "gph_comm_on_stream", "gph_comm_kind",
     "gph_comm_allgather_stream", "gph_comm_allreduce_host", "gph_run_control_file_comm", "gph_device_count",
+    "gph_engine_unit",
 ]
 
 
@@ -233,6 +234,7 @@ def _load_library(path):
     lib.gph_engine_host_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                           C.POINTER(C.c_int32)]
     lib.gph_engine_set_timing.argtypes = [C.c_void_p, C.c_uint32]
+    lib.gph_engine_unit.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]
     lib.gph_run_control_file_comm.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
     return lib
 
@@ -530,6 +532,13 @@ class Sampler:
 
     def set_timing(self, mask):
         self._chk(self.lib.gph_engine_set_timing(self.engine, mask), "set_timing")
+
+    def unit(self, op, arg=0):
+        """kernel-level fixture calls (gph_engine_unit): rows = local loci in input order"""
+        stride = max(4, 3 * (self.pack.n - 1))
+        out = np.zeros((self.end - self.begin, stride))
+        self._chk(self.lib.gph_engine_unit(self.engine, op, arg, out.ctypes.data_as(C.POINTER(C.c_double)), stride), "unit")
+        return out
 
     def hbm_bytes(self):
         b = C.c_double()

@@ -51,6 +51,7 @@ GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, int unused) { (void)unused
 GPH_KERNEL(k_mix_finish, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_mix_finish(D, j0 + GPH_BLK); }
 GPH_KERNEL(k_sync, GphKargs KA, GphDev D, int j0, int refresh) { GphCtxG lx; lx.kb_sync(D, j0 + GPH_BLK, refresh); }
 GPH_KERNEL(k_check, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_check(D, j0 + GPH_BLK); }
+GPH_KERNEL(k_unit, GphKargs KA, GphDev D, int j0, int op, double *out, int stride) { GphCtxG lx; lx.kb_unit(D, j0 + GPH_BLK, op, out, stride); }
 GPH_KERNEL(k_lrate_prep, GphKargs KA, GphDev D, int j0, double finetune, GphLrPre *pre) { GphCtx lx; lx.kb_lrate_prep(D, j0 + GPH_BLK, finetune, pre); }
 GPH_KERNEL(k_lrate_scan, GphKargs KA, GphDev D, int j0, GphLrArgs A) { (void)j0; GphCtx lx; lx.kb_lrate_scan(D, A); }
 GPH_KERNEL(k_lrate_apply, GphKargs KA, GphDev D, int j0, const GphLrRec *rec) { GphCtx lx; lx.kb_lrate_apply(D, j0 + GPH_BLK, rec); }
@@ -883,7 +884,8 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   // per-locus kernels use up to the wide group's dynamic LDS size; allow > 64 KiB
   const void *ks[] = {(const void *)k_init, (const void *)k_sweep, (const void *)k_tau_eval, (const void *)k_tau_finish,
                       (const void *)k_mix_eval, (const void *)k_mix_finish,
-                      (const void *)k_sync, (const void *)k_check, (const void *)k_lrate_apply, (const void *)k_lrate_prep};
+                      (const void *)k_sync, (const void *)k_check, (const void *)k_lrate_apply, (const void *)k_lrate_prep,
+                      (const void *)k_unit};
   for (auto k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, e->lay.lds_bytes));
 #endif
   return 0;
@@ -1517,6 +1519,56 @@ int gph_engine_iteration_(gph_engine *e, int32_t iteration, const double *lr_alp
     if ((rc = run_stage(e, GS_CHECK_DONE, 0, iteration))) return rc;
   }
   return finish_sync(e);
+}
+
+// kernel-level fixtures (gph_kernels.h: kb_unit): single calls of the per-locus functions on the current chain state,
+// every call undone.  out: [local loci][stride] doubles in input order, stride >= 3 (n - 1).
+//   op 0: per internal node tnew, lnLd, dprior;  op 1: full recompute value;  op 2: rubber band (pre) of ancestral
+//   population `arg`: delta, n0, n1, lik -- the proposal (bounds, factors) is derived from the model exactly as
+//   oracle/ref_harness.c `unit` derives it
+int gph_engine_unit(gph_engine *e, int32_t op, int32_t arg, double *out, int32_t stride)
+{
+  if (!e || !e->initialized || !out || op < 0 || op > 2 || stride < 3 * (e->cfg.n - 1) || stride < 4) return GPH_EARG;
+  SETDEV(e);
+  { int rcs = flush_sync(e); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
+  if (op == 2) {
+    if (arg < e->cfg.Kc || arg >= e->cfg.K) return GPH_EARG;
+    GphGlobal &G = *e->G_h;
+    const GphModel &M = G.model;
+    GphTauArgs &A = G.tau;
+    memset(&A, 0, sizeof A);
+    const int ap = arg, s0 = M.popSon0[ap], s1 = M.popSon1[ap], isRoot = ap == e->cfg.rootPop;
+    const double tauold = M.popAge[ap];
+    double taub0 = gg_max2(M.popAge[s0], M.popAge[s1]);
+    taub0 = gg_max2(taub0, M.sampleAge[s0]);
+    taub0 = gg_max2(taub0, M.sampleAge[s1]);
+    const double taub1 = isRoot ? GG_OLDAGE : M.popAge[M.popFather[ap]];
+    const double taunew = taub0 + 0.55 * (gg_min2(taub1, tauold * 1.4) - taub0);
+    A.ap = ap; A.son0 = s0; A.son1 = s1; A.isRoot = isRoot;
+    A.tauold = tauold; A.taunew = taunew; A.taub0 = taub0; A.taub1 = taub1;
+    A.taufactor0 = (taunew - taub0) / (tauold - taub0);
+    A.taufactor1 = isRoot ? A.taufactor0 : (taunew - taub1) / (tauold - taub1);
+    e->G_dirty = true;
+  }
+  PUSH_IF_DIRTY(e);
+  double *d_out = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)stride * e->L;
+  if (dev_alloc((void **)&d_out, bytes)) return GPH_EHIP;
+  int rc = 0;
+#ifdef GPH_HOSTEMU
+  memset(d_out, 0, bytes);
+#else
+  if (hipMemsetAsync(d_out, 0, bytes, e->stream) != hipSuccess) rc = GPH_EHIP;
+#endif
+  if (!rc) {
+    auto launch = [&]() -> int { LAUNCH(e, 12, k_unit, (int)op, d_out, (int)stride); return 0; };
+    rc = launch();
+  }
+  if (!rc) rc = reduce_local(e, 0, GPH_OUT_SLOTS);
+  if (!rc) rc = run_stage_now(e, GS_COUNT_ONLY, 12);
+  if (!rc) rc = d2h(e, out, d_out, bytes);
+  dev_free(d_out);
+  return rc;
 }
 
 // canonical text dump (same format as oracle/gphocs_oracle_io.c go_dump_state's per-locus part)

@@ -1193,6 +1193,64 @@ GPH_DEV void kb_check(const GphDev &D, int g)
   out_common(D, g);
   stage_out(D, g, D.pages, 1);
 }
+// ---------------------------------------------------------------- kernel-level fixtures
+// Single calls of the per-locus functions with deterministic arguments, every one undone afterwards (the locus is not
+// written back): what oracle/ref_harness.c `unit` does with the real reference's functions on the same chain state
+// (tests/golden/*.unit).  A parity break shows up as ONE differing line.
+//   op 0  per internal node: adjustGenNodeAge + computeLocusDataLikelihood(useOld=1) + considerEventMove
+//         (body of UpdateGB_InternalNode, GPhoCS.c:2316-2381) -> uo[3 (inode - n) + {0,1,2}] = tnew, lnLd, dprior
+//   op 1  computeLocusDataLikelihood(useOld=0) -> uo[0]
+//   op 2  rubberBand(pre) x3 of the ancestral population in the chain state's pending proposal + evaluation
+//         (UpdateTau loop 1 without the ripple, GPhoCS.c:3705-3831) -> uo[0..3] = delta, n0, n1, lik
+GPH_DEV void kb_unit(const GphDev &D, int g, int op, double *out, int stride)
+{
+  double *uo = out + (size_t)D.orig[g] * stride;
+  stage_in(D, g, D.pages, 1);
+  if (op == 0) {
+    for (int inode = g_lay.n; inode < g_lay.N; inode++) {
+      const GphNodeS me = ld_node(inode);
+      const double t = me.age;
+      const int pop = me.npop;
+      double tb0 = g_model.popAge[pop], tb1;
+      if (pop != g_lay.rootPop) tb1 = g_model.popAge[g_model.popFather[pop]];
+      else tb1 = GPH_OLDAGE;
+      int mig = find_first_mig(inode, -1);
+      if (mig >= 0) tb1 = gmin2(tb1, MAGE(mig));
+      else if (inode != ISC(IS_ROOT)) tb1 = gmin2(tb1, AGE(me.father));
+      for (int i = 0; i < 2; i++) {
+        const int son = i == 0 ? me.left : me.right;
+        mig = find_last_mig(son, -1);
+        if (mig >= 0) tb0 = gmax2(tb0, MAGE(mig));
+        else tb0 = gmax2(tb0, AGE(son));
+      }
+      const double hi = gmin2(tb1, t * 1.5 + 1e-7);
+      const double tnew = tb0 + 0.61803 * (hi - tb0);
+      lik_adjust_age(inode, tnew);
+      double lnLd = -FS(FS_DATALNL);
+      lnLd += lik_compute(1);
+      const double dprior = consider_event_move(0, NEV(inode), pop, t, pop, tnew);
+      reject_event_chain_changes(0);
+      lik_revert();
+      if (GPH_LANE == 0) { uo[3 * (inode - g_lay.n)] = tnew; uo[3 * (inode - g_lay.n) + 1] = lnLd; uo[3 * (inode - g_lay.n) + 2] = dprior; }
+    }
+  } else if (op == 1) {
+    const double v = lik_compute(0);
+    lik_reset_saved();
+    if (GPH_LANE == 0) uo[0] = v;
+  } else {
+    gph_ctau &A = GPH_G->tau;
+    int n0 = 0, n1 = 0;
+    double d, lik = 0.0;
+    if (A.isRoot) d = rubber_band(A.ap, A.taub0, A.tauold, A.taufactor1, 0, &n1);
+    else d = rubber_band(A.ap, A.taub1, A.tauold, A.taufactor1, 0, &n1);
+    d += rubber_band(A.son0, A.taub0, A.tauold, A.taufactor0, 0, &n0);
+    d += rubber_band(A.son1, A.taub0, A.tauold, A.taufactor0, 0, &n0);
+    if (n0 + n1) { lik = -FS(FS_DATALNL); lik += lik_compute(1); }
+    lik_revert();
+    if (GPH_LANE == 0) { uo[0] = d; uo[1] = n0; uo[2] = n1; uo[3] = lik; }
+  }
+  out_common(D, g);
+}
 };   // struct GphCtxT
 using GphCtx = GphCtxT<false>;    // model in the kernel-argument segment (genealogy sweep, locus-rate kernels)
 using GphCtxG = GphCtxT<true>;    // model in the device-resident chain state

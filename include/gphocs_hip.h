@@ -170,6 +170,13 @@ int gph_engine_check_all(gph_engine *e, int32_t *ok, double *sumDataLnL, double 
 int gph_engine_get_counters(gph_engine *e, gph_counters *out, int32_t reset);
 /* debug / parity: canonical text dump of every local locus (same format as the oracle's) */
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditionals, int32_t append);
+/* debug / parity, kernel level: single calls of the per-locus functions with deterministic arguments on the current
+ * chain state, every call undone -- what oracle/ref_harness.c `unit` does with the reference's own functions
+ * (tests/golden/ *.unit).  out[local loci][stride] in input order.  op 0: per internal node i (stride >= 3 (n-1)):
+ * tnew, lnLd, dprior of adjustGenNodeAge + computeLocusDataLikelihood(1) + considerEventMove (GPhoCS.c:2316-2381);
+ * op 1: computeLocusDataLikelihood(useOld=0); op 2: rubberBand(pre) x3 of ancestral population arg + evaluation
+ * (GPhoCS.c:3705-3831): delta, n0, n1, lik */
+int gph_engine_unit(gph_engine *e, int32_t op, int32_t arg, double *out, int32_t stride);
 /* timing of the last launch of a named kernel class, measured with HIP events on the
  * engine's own stream: which = 0 sweep, 1 tau_eval, 2 mix_eval, 3 init, 4 check,
  * 5 tau_finish (commit or revert, by the decision flag), 7 mix_finish, 8 sync, 9 locus-rate scan, 10 locus-rate apply,

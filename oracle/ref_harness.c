@@ -329,6 +329,93 @@ static int cmd_run(int argc, char **argv)
   return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* kernel-level fixtures: after `iters` iterations, SINGLE calls of the reference's
+ * per-locus functions with deterministic arguments, every output as a hex float; each call is undone
+ * (rejectEventChainChanges / revertToSaved), so the calls are independent.  The HIP engine replays the same calls
+ * (gph_engine_unit) on the same chain state; a parity break is then located by one diff instead of a bisection.
+ *   A g inode tnew lnLd dprior   adjustGenNodeAge + computeLocusDataLikelihood(useOld=1) + considerEventMove
+ *                                (the body of UpdateGB_InternalNode, GPhoCS.c:2316-2381, with tnew = a fixed point
+ *                                of the window instead of a random draw)
+ *   B g lnl                      computeLocusDataLikelihood(useOld=0): full recompute
+ *   C g ap d n0 n1 lik           rubberBand(pre) x3 of one ancestral population + computeLocusDataLikelihood(1)
+ *                                (UpdateTau loop 1 without the migration ripple, GPhoCS.c:3705-3831) */
+static int cmd_unit(int argc, char **argv)
+{
+  char *ctl = argv[2];
+  int iters = atoi(argv[3]);
+  FILE *of = fopen(argv[4], "w");
+  int it, gen, inode, i, son, mig, pop, ap, n = 0, N, *acceptCountArray;
+  PopulationTree *pt;
+  if (!of) { perror(argv[4]); return 2; }
+  startup(ctl);
+  pt = dataSetup.popTree;
+  n = dataSetup.numSamples; N = 2 * n - 1;
+  acceptCountArray = (int *)calloc(pt->numPops, sizeof(int));
+  misc_stats.rubberband_mig_conflicts = 0;
+  misc_stats.not_enough_migs = 0;
+  initializeMCMC();
+  { FILE *nul = fopen("/dev/null", "w"); for (it = 0; it < iters; it++) one_iteration(nul, it, acceptCountArray, 1); fclose(nul); }
+  for (gen = 0; gen < dataSetup.numLoci; gen++) {
+    LocusData *ld = dataState.lociData[gen];
+    for (inode = n; inode < N; inode++) {
+      double t = getNodeAge(ld, inode), tb[2], hi, tnew, lnLd, dprior;
+      pop = nodePops[gen][inode];
+      tb[0] = pt->pops[pop]->age;
+      tb[1] = pop != pt->rootPop ? pt->pops[pop]->father->age : OLDAGE;
+      mig = findFirstMig(gen, inode, -1);
+      if (mig >= 0) tb[1] = min2(tb[1], genetree_migs[gen].mignodes[mig].age);
+      else if (inode != getLocusRoot(ld)) tb[1] = min2(tb[1], getNodeAge(ld, getNodeFather(ld, inode)));
+      for (i = 0; i < 2; i++) {
+        son = getNodeSon(ld, inode, i);
+        mig = findLastMig(gen, son, -1);
+        if (mig >= 0) tb[0] = max2(tb[0], genetree_migs[gen].mignodes[mig].age);
+        else tb[0] = max2(tb[0], getNodeAge(ld, son));
+      }
+      hi = min2(tb[1], t * 1.5 + 1e-7);
+      tnew = tb[0] + 0.61803 * (hi - tb[0]);
+      adjustGenNodeAge(ld, inode, tnew);
+      lnLd = -getLocusDataLikelihood(ld);
+      lnLd += computeLocusDataLikelihood(ld, 1);
+      dprior = considerEventMove(gen, 0, nodeEvents[gen][inode], pop, t, pop, tnew);
+      rejectEventChainChanges(gen, 0);
+      revertToSaved(ld);
+      fprintf(of, "A %d %d %a %a %a\n", gen, inode, tnew, lnLd, dprior);
+    }
+  }
+  for (ap = pt->numCurPops; ap < pt->numPops; ap++) {
+    int isRoot = ap == pt->rootPop, s0 = pt->pops[ap]->sons[0]->id, s1 = pt->pops[ap]->sons[1]->id;
+    double tauold = pt->pops[ap]->age, taub[2], taunew, tf[2];
+    taub[0] = max2(pt->pops[s0]->age, pt->pops[s1]->age);
+    taub[0] = max2(taub[0], pt->pops[s0]->sampleAge);
+    taub[0] = max2(taub[0], pt->pops[s1]->sampleAge);
+    taub[1] = isRoot ? OLDAGE : pt->pops[ap]->father->age;
+    taunew = taub[0] + 0.55 * (min2(taub[1], tauold * 1.4) - taub[0]);
+    tf[0] = (taunew - taub[0]) / (tauold - taub[0]);
+    tf[1] = isRoot ? tf[0] : (taunew - taub[1]) / (tauold - taub[1]);
+    for (gen = 0; gen < dataSetup.numLoci; gen++) {
+      LocusData *ld = dataState.lociData[gen];
+      int n0 = 0, n1 = 0;
+      double d, lik = 0.0;
+      if (isRoot) d = rubberBand(gen, ap, taub[0], tauold, tf[1], 0, &n1);
+      else d = rubberBand(gen, ap, taub[1], tauold, tf[1], 0, &n1);
+      d += rubberBand(gen, s0, taub[0], tauold, tf[0], 0, &n0);
+      d += rubberBand(gen, s1, taub[0], tauold, tf[0], 0, &n0);
+      if (n0 + n1) { lik = -getLocusDataLikelihood(ld); lik += computeLocusDataLikelihood(ld, 1); }
+      revertToSaved(ld);
+      fprintf(of, "C %d %d %a %d %d %a\n", gen, ap, d, n0, n1, lik);
+    }
+  }
+  for (gen = 0; gen < dataSetup.numLoci; gen++) {
+    LocusData *ld = dataState.lociData[gen];
+    double v = computeLocusDataLikelihood(ld, 0);
+    resetSaved(ld);
+    fprintf(of, "B %d %a\n", gen, v);
+  }
+  fclose(of);
+  return 0;
+}
+
 static double now_s(void)
 {
   struct timespec ts;
@@ -420,6 +507,7 @@ int main(int argc, char **argv)
   if (argc < 2) { fprintf(stderr, "usage: gphocs_ref pack|run|time|rng|reflect|main ...\n"); return 1; }
   if (!strcmp(argv[1], "pack") && argc >= 4) return cmd_pack(argv[2], argv[3]);
   if (!strcmp(argv[1], "run") && argc >= 5) return cmd_run(argc, argv);
+  if (!strcmp(argv[1], "unit") && argc >= 5) return cmd_unit(argc, argv);
   if (!strcmp(argv[1], "time") && argc >= 4) return cmd_time(argc, argv);
   if (!strcmp(argv[1], "ingest") && argc >= 3) return cmd_ingest(argv[2]);
   if (!strcmp(argv[1], "rng") && argc >= 4) return cmd_rng(argc, argv);

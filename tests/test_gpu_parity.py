@@ -302,6 +302,17 @@ def test_launcher_ranks_share_the_device(tmp_path, name, ranks):
         assert len(wf) == len(gf) and all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
 
 
+@pytest.mark.parametrize("name", ["m4", "a7", "g2"])
+def test_kernel_level_fixtures(G, name):
+    """single calls of computeLocusDataLikelihood / considerEventMove / rubberBand(pre) on the device
+    (gph_engine_unit) against the outputs of the real reference's own functions for the same chain state
+    (tests/golden/*.unit, oracle/ref_harness.c `unit`): every value bit for bit"""
+    import unit_fixture
+    pk = G.Pack.load(os.path.join(GOLDEN, name + ".gpk"))
+    lib = G.load_library(dims=(pk.n, pk.K, pk.B))
+    assert unit_fixture.check_unit(G, lib, GOLDEN, name) > 100
+
+
 def test_native_library_is_the_path(G):
     """the ops must come from the in-tree HIP library; without it construction fails loudly"""
     import gphocs_amd

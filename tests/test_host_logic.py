@@ -85,3 +85,12 @@ def test_locus_rate_edge_cases_against_live_oracle(hostemu, oracle_cli, tmp_path
     subprocess.run([oracle_cli, "run", pth, "12", str(ot), str(os_), "11", "1"], check=True, timeout=300)
     assert compare_records(tr, ot) < 1e-12
     compare_states(st, os_)
+
+
+@pytest.mark.parametrize("name", ["m4", "a7", "g2"])
+def test_kernel_level_fixtures_hostemu(hostemu, name):
+    """single calls of the per-locus functions against the real reference's (tests/golden/*.unit), host-emulation build"""
+    import gphocs_amd as G
+    import unit_fixture
+    _, lib = hostemu
+    assert unit_fixture.check_unit(G, lib, GOLDEN, name) > 100
