@@ -1813,16 +1813,14 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
   }
   mig_source = -1;
   proceed = 1;
-  int guard = 0;
   /* per step every field of the current interval is read ONCE into registers (the LDS image is only
    * re-read when the walk steps to another event); the coalescence-statistic delta of the population
    * being crossed accumulates in a register and is written back when the walk leaves it -- same values,
    * same order of additions */
   const int fev_old = RECONNECT ? -1 : SPRI(SI_FEV_OLD);
-  const int guard_max = 4 * g_lay.E;
   double dcoal = DCOAL(inst, pop);
   while (proceed) {
-    if (++guard > guard_max) { gph_fail(96); break; }
+    if (nev >= GPH_CAP_E) { gph_fail(96); break; }   /* every step lists one event: a corrupted chain cannot spin */
     if (ev < 0) {
       if (g_model.popFather[pop] < 0) {
         if (RECONNECT) { setDCOAL(inst, pop, dcoal); setDI(inst, DI_NEV, nev); setSPRLN(RECONNECT, lnld); return -1; }

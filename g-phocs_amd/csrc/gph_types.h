@@ -225,7 +225,7 @@ struct GphRec { int32_t code, idx; int64_t acc; double dataLnL, logL; };
 enum { REC_INIT = 0, REC_INT, REC_MIGN, REC_SPR, REC_LRATE, REC_THETA, REC_MIGR, REC_TAU, REC_CONFLICTS, REC_SAGE,
        REC_MIX, REC_CHECK };
 struct GphApply { int32_t kind, idx; double lnc, diff; };   // kind 0: population idx (diff = 1/new - 1/old), 1: band idx (diff = new - old rate)
-struct GphGlobal {
+struct alignas(16) GphGlobal {
   GphModel model;
   GphTauArgs tau;                    // pending UpdateTau / UpdateSampleAge proposal
   long long tau_limit;               // first conflicting locus (global index) or 1 << 62

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Counter passes for the benchmark workload on the GPU box (run through gpurun from the repo root):
 #   bash tools/pmc_collect.sh <tag>      -> gpurun_out/pmc_<tag>/*.csv + gpurun_out/pmc_<tag>.json
+# every pass runs the chain 200 iterations first (as the bench does) and sums the counters over ALL k_sweep dispatches of the
+# process; per-dispatch and per-wave figures divide by the dispatch / wave counts of the same pass
 # Each pass is its own rocprofv3 run with --pmc only (no tracing flags), the program directly after `--`.
 # FETCH_SIZE and WRITE_SIZE get separate passes (MI355X_MICROARCH.md, HBM section).
 set -u
@@ -12,7 +14,7 @@ export TMPDIR=/tmp
 python3 bench.py --steps 2 --warmup 1 --preroll 0 --no-cpu-baseline > "$OUT/warm.json" 2> "$OUT/warm.err"   # fills bench_cache/
 pass() { # name counters...
   local name=$1; shift
-  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" -d "$OUT/$name" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --preroll 0 --no-cpu-baseline > "$OUT/$name.log" 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" -d "$OUT/$name" -o p --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --preroll 200 --no-cpu-baseline > "$OUT/$name.log" 2>&1)
   echo "pass $name rc=$?"
 }
 pass insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Copy the outputs of tools/profile_round.sh <tag> from gpurun_out/ into profiles/ (the committed evidence):
-bench line (with the measured HBM traffic filled in), kernel stats, counter summary, traffic_k_sweep.json."""
+bench line (with the measured HBM traffic filled in), kernel stats, counter summary, traffic_k_sweep.json.
+   python3 tools/profile_publish.py <tag> [round-prefix, default r02]"""
 import json
 import shutil
 import sys
 
 tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 d = json.load(open(f"gpurun_out/pmc_{tag}.json"))
 k = [x for x in d if "k_sweep" in x][0]
 s = d[k]
@@ -17,14 +19,20 @@ print("k_sweep dispatches", nd, "fetch GB %.2f write GB %.2f" % (fetch / 1e9, wr
 for c in sorted(s):
     print("%-22s per wave %12.1f" % (c, s[c]["sum"] / n))
 json.dump({"kernel": "k_sweep", "loci": 100000, "hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch,
-           "write_bytes": write,
+           "write_bytes": write, "build": f"{rnd} {tag}, library variant s",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_collect.sh): "
                      "FETCH_SIZE(KB)*1024*2 (gfx950 correction) + WRITE_SIZE(KB)*1024 per k_sweep dispatch (one "
-                     f"dispatch per sweep), averaged over {nd} dispatches; {tag} build (variant s)"},
+                     f"dispatch per sweep), averaged over the {nd} dispatches of a 200-iteration pre-roll + 4 iterations"},
           open("profiles/traffic_k_sweep.json", "w"), indent=1)
-shutil.copy(f"gpurun_out/pmc_{tag}.json", f"profiles/r01_pmc_{tag}.json")
-shutil.copy(f"gpurun_out/kstats_{tag}/k_kernel_stats.csv", f"profiles/r01_bench_kernel_stats_{tag}.csv")
+shutil.copy(f"gpurun_out/pmc_{tag}.json", f"profiles/{rnd}_pmc_{tag}.json")
+shutil.copy(f"gpurun_out/kstats_{tag}/k_kernel_stats.csv", f"profiles/{rnd}_bench_kernel_stats_{tag}.csv")
 b = json.load(open(f"gpurun_out/bench_{tag}.json"))
 b["roofline"]["traffic"] = fetch + write
-json.dump(b, open(f"profiles/r01_bench_{tag}.json", "w"), indent=1)
-print(json.dumps({k2: b[k2] for k2 in ("value", "ms_per_step", "mcmc_iters_per_sec")}), b["roofline"]["frac"], b["cpu_baseline"]["value"], b["cpu_baseline"].get("openmp_all_cores"))
+b["roofline"]["traffic_source"] = f"profiles/traffic_k_sweep.json ({rnd} {tag}: rocprofv3 --pmc passes of the same command on the same box)"
+b["roofline"]["hbm_counter_frac"] = (fetch + write) / (b["roofline"]["avg_launch_ms"] * 1e-3) / 8e12
+json.dump(b, open(f"profiles/{rnd}_bench_{tag}.json", "w"), indent=1)
+try:
+    shutil.copy(f"gpurun_out/bench_{tag}_12500.json", f"profiles/{rnd}_bench_{tag}_12500loci.json")
+except OSError:
+    pass
+print(json.dumps({k2: b[k2] for k2 in ("value", "ms_per_step", "mcmc_iters_per_sec")}), b["roofline"]["frac"], b.get("cpu_baseline", {}).get("value"))
