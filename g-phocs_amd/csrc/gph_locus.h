@@ -1819,14 +1819,149 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
    * same order of additions */
   const int fev_old = RECONNECT ? -1 : SPRI(SI_FEV_OLD);
   double dcoal = DCOAL(inst, pop);
+  if constexpr (RECONNECT != 0) {
+    /* The prior-sampling walk as two nested loops: a TIGHT inner loop over the intervals the lineage passes through
+     * (three of four), with one exit for "an event falls inside this interval", and the rare work -- creating the
+     * migration events, or the coalescence that ends the walk -- outside it.  Same operations in the same order as
+     * the single loop below (which the pruning walk still uses); the point is what the register allocator makes of
+     * it: the single loop carried a dozen scalars across six merging paths and paid for the merges with copies
+     * (a quarter of its instructions). */
+    int status = 0;          /* 1 coalesced, -1 end of the root chain (no event sampled), 2 no migration slot left */
+    for (;;) {
+      double et = 0.0;
+      int nlin = 0, evnext = -1;
+      for (;;) {
+        if (nev >= GPH_CAP_E) { gph_fail(96); status = 3; break; }
+        if (ev < 0) {
+          if (g_model.popFather[pop] < 0) { status = -1; break; }
+          setDCOAL(inst, pop, dcoal);
+          pop = g_model.popFather[pop];
+          dcoal = DCOAL(inst, pop);
+          theta = g_model.theta[pop];
+          thinv = g_model.thetaInv[pop];
+          ev = FIRSTEV(pop);
+          mig_rate = 0.0;
+          if (fabs(age / g_model.popAge[pop] - 1) > 0.01) { gph_fail(8); status = 3; break; }
+          age = g_model.popAge[pop];
+        }
+        const GphEvS R = ld_ev(ev);
+        nlin = R.nlin;
+        et = R.time;
+        evnext = R.next;
+        rate = mig_rate + gph_div_by(2 * nlin, theta, thinv);
+        bool through;     /* the sampled waiting time reaches the end of the interval (patch.c:1075-1082) */
+        if (UNI(rate <= 0)) {
+          through = true;
+        } else {
+          const double u = l_rndu(rng);
+#ifndef GPH_HOSTEMU
+          /* t = -(1/rate) log(u) is only USED when it falls inside the interval.  -log(u) >= y + y^2/2 for
+           * y = 1 - u in (0, 1]: when that bound clears rate*et with a margin far above the rounding errors of
+           * either side (each a few 1e-16 relative), t >= et is certain and neither the logarithm nor the
+           * reciprocal is evaluated -- about three of four draws of a walk pass through their interval */
+          const double y = 1.0 - u;
+          through = UNI(y + 0.5 * y * y >= (rate * et) * (1.0 + 1e-9));
+          if (!through)
+#endif
+          {
+            t = -(1 / rate) * gph_log_u(u);
+            through = UNI(t >= et);
+          }
+        }
+        if (!through) break;
+        t = et;
+        age += t;
+        dcoal += 2 * nlin * t;
+        for (i = 0; i < live.n; i++) setDMIG(inst, ll_get(live, i), DMIG(inst, ll_get(live, i)) + t);
+        setDEV(inst, nev, ev);
+        nev++;
+        lnld -= rate * t;
+        if (R.type == GPH_MIG_BAND_START) {
+          mig_rate += g_model.migRate[R.node];
+          ll_push(live, R.node);
+        } else if (R.type == GPH_MIG_BAND_END) {
+          mig_rate -= g_model.migRate[R.node];
+          if (live.n == 1) mig_rate = 0.0;
+          i = ll_find(live, R.node);
+          if (i < live.n) ll_swap_remove(live, i);
+        }
+        ev = evnext;
+      }
+      if (status) break;
+      /* an event at age + t, inside the interval of `ev` */
+      age += t;
+      event_sample = rate * l_rndu(rng);
+      if (UNI(event_sample < mig_rate)) {
+        int k = SPRI(SI_NNEW);
+        if (GPH_MAX_MIGS <= ISC(IS_NUM_MIGS) + k - SPRI(SI_NOLD)) {
+          setCNT(CN_NOTENOUGH, CNT(CN_NOTENOUGH) + 1);
+          status = 2;
+          break;
+        }
+        for (i = 0; event_sample >= 0 && i < live.n; i++) event_sample -= g_model.migRate[ll_get(live, i)];
+        if (i <= 0) { gph_fail(9); status = 3; break; }
+        b = ll_get(live, i - 1);
+        setSPRA(SA_NEWBAND, k, b);
+        if (g_model.bandTgt[b] != pop) { gph_fail(9); status = 3; break; }
+        setSPRAGE(k, age);
+        const int nw = create_event_before(pop, ev, t);   /* the new interval: same lineage count, type DUMMY */
+        setSPRA(SA_NEWIN, k, nw);
+        mig_source = create_event(g_model.bandSrc[b], age);
+        setSPRA(SA_NEWOUT, k, mig_source);
+        if (mig_source < 0) { gph_fail(10); status = 3; break; }
+        setSPRI(SI_NNEW, k + 1);
+        dcoal += 2 * nlin * t;
+        for (i = 0; i < live.n; i++) setDMIG(inst, ll_get(live, i), DMIG(inst, ll_get(live, i)) + t);
+        setDEV(inst, nev, nw);
+        nev++;
+        lnld -= rate * t;
+        lnld += g_model.logMigRate[b];
+        setDCOAL(inst, pop, dcoal);
+        pop = g_model.bandSrc[b];
+        dcoal = DCOAL(inst, pop);
+        theta = g_model.theta[pop];
+        thinv = g_model.thetaInv[pop];
+        mig_rate = 0.0;
+        live.n = 0;
+        for (b = 0; b < g_lay.B; b++) {
+          if (g_model.bandTgt[b] == pop && g_model.bandStart[b] <= age && g_model.bandEnd[b] > age) {
+            mig_rate += g_model.migRate[b];
+            ll_push(live, b);
+          }
+        }
+        ev = ENEXT(mig_source);
+        mig_source = -1;
+      } else {
+        num_targets = edges_for_time_pop((age - t) + et / 2, pop, node);
+        if (num_targets != nlin) { gph_fail(11); status = 3; break; }
+        i = (int)((event_sample - mig_rate) * theta / 2);
+        target = gi16(&GphLds::s_targets, i);
+        lik_spr(node, target, age);
+        setSPRI(SI_FPOP_NEW, pop);
+        setSPRI(SI_TARGET, target);
+        const int nw = create_event_before(pop, ev, t);
+        setSPRI(SI_FEV_NEW, nw);
+        dcoal += 2 * nlin * t;
+        for (i = 0; i < live.n; i++) setDMIG(inst, ll_get(live, i), DMIG(inst, ll_get(live, i)) + t);
+        setDEV(inst, nev, nw);
+        nev++;
+        lnld -= rate * t;
+        status = 1;
+        break;
+      }
+    }
+    if (status == -1 || status == 2) { setDCOAL(inst, pop, dcoal); setDI(inst, DI_NEV, nev); setSPRLN(RECONNECT, lnld); return -1; }
+    setDCOAL(inst, pop, dcoal);
+    lnld += g_model.logTwoTheta[pop];
+    setDI(inst, DI_NEV, nev);
+    setSPRLN(RECONNECT, lnld);
+    return 0;
+  }
+  /* RECONNECT == 0: the pruning walk along the existing edge (no sampling, no new events) */
   while (proceed) {
     if (nev >= GPH_CAP_E) { gph_fail(96); break; }   /* every step lists one event: a corrupted chain cannot spin */
     if (ev < 0) {
-      if (g_model.popFather[pop] < 0) {
-        if (RECONNECT) { setDCOAL(inst, pop, dcoal); setDI(inst, DI_NEV, nev); setSPRLN(RECONNECT, lnld); return -1; }
-        gph_fail(6);
-        break;
-      }
+      if (g_model.popFather[pop] < 0) { gph_fail(6); break; }
       setDCOAL(inst, pop, dcoal);
       pop = g_model.popFather[pop];
       dcoal = DCOAL(inst, pop);
@@ -1838,105 +1973,33 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
       age = g_model.popAge[pop];
     }
     const GphEvS R = ld_ev(ev);
-    const int ev0 = ev;
     node_id = R.node;
-    int nlin = R.nlin, ty = R.type;
-    const double et = R.time;
-    if (!RECONNECT) {
-      nlin -= 1;
-      setENLIN(ev, nlin);
-      t = et;
-      age += t;
-      proceed = (ev != fev_old);
-      if (ty == GPH_IN_MIG) {
-        if (MG(node_id, MG_BRANCH) == node) {
-          int k = SPRI(SI_NOLD);
-          b = MG(node_id, MG_BAND);
-          mig_source = MG(node_id, MG_SEV);
-          setSPRA(SA_OLD, k, node_id);
-          setSPRI(SI_NOLD, k + 1);
-        }
-      }
-    } else {
-      rate = mig_rate + gph_div_by(2 * nlin, theta, thinv);
-      bool through;     /* the sampled waiting time reaches the end of the interval (patch.c:1075-1082) */
-      if (UNI(rate <= 0)) {
-        through = true;
-      } else {
-        const double u = l_rndu(rng);
-#ifndef GPH_HOSTEMU
-        /* t = -(1/rate) log(u) is only USED when it falls inside the interval.  -log(u) >= y + y^2/2 for
-         * y = 1 - u in (0, 1]: when that bound clears rate*et with a margin far above the rounding errors of
-         * either side (each a few 1e-16 relative), t >= et is certain and neither the logarithm nor the
-         * reciprocal is evaluated -- about three of four draws of a walk pass through their interval */
-        const double y = 1.0 - u;
-        through = UNI(y + 0.5 * y * y >= (rate * et) * (1.0 + 1e-9));
-        if (!through)
-#endif
-        {
-          t = -(1 / rate) * gph_log_u(u);
-          through = UNI(t >= et);
-        }
-      }
-      if (through) {
-        t = et;
-        age += t;
-      } else {
-        age += t;
-        event_sample = rate * l_rndu(rng);
-        if (UNI(event_sample < mig_rate)) {
-          int k = SPRI(SI_NNEW);
-          if (GPH_MAX_MIGS <= ISC(IS_NUM_MIGS) + k - SPRI(SI_NOLD)) {
-            setCNT(CN_NOTENOUGH, CNT(CN_NOTENOUGH) + 1);
-            setDCOAL(inst, pop, dcoal);
-            setDI(inst, DI_NEV, nev);
-            setSPRLN(RECONNECT, lnld);
-            return -1;
-          }
-          for (i = 0; event_sample >= 0 && i < live.n; i++) event_sample -= g_model.migRate[ll_get(live, i)];
-          if (i <= 0) { gph_fail(9); break; }
-          b = ll_get(live, i - 1);
-          setSPRA(SA_NEWBAND, k, b);
-          if (g_model.bandTgt[b] != pop) { gph_fail(9); break; }
-          setSPRAGE(k, age);
-          ev = create_event_before(pop, ev, t);   /* the new interval: same lineage count, type DUMMY */
-          ty = GPH_DUMMY;
-          setSPRA(SA_NEWIN, k, ev);
-          mig_source = create_event(g_model.bandSrc[b], age);
-          setSPRA(SA_NEWOUT, k, mig_source);
-          if (mig_source < 0) { gph_fail(10); break; }
-          setSPRI(SI_NNEW, k + 1);
-        } else {
-          num_targets = edges_for_time_pop((age - t) + et / 2, pop, node);
-          if (num_targets != nlin) { gph_fail(11); break; }
-          i = (int)((event_sample - mig_rate) * theta / 2);
-          target = gi16(&GphLds::s_targets, i);
-          lik_spr(node, target, age);
-          setSPRI(SI_FPOP_NEW, pop);
-          setSPRI(SI_TARGET, target);
-          ev = create_event_before(pop, ev, t);
-          ty = GPH_DUMMY;
-          setSPRI(SI_FEV_NEW, ev);
-          proceed = 0;
-        }
+    const int nlin = R.nlin - 1;
+    setENLIN(ev, nlin);
+    t = R.time;
+    age += t;
+    proceed = (ev != fev_old);
+    if (R.type == GPH_IN_MIG) {
+      if (MG(node_id, MG_BRANCH) == node) {
+        int k = SPRI(SI_NOLD);
+        b = MG(node_id, MG_BAND);
+        mig_source = MG(node_id, MG_SEV);
+        setSPRA(SA_OLD, k, node_id);
+        setSPRI(SI_NOLD, k + 1);
       }
     }
     dcoal += 2 * nlin * t;
     for (i = 0; i < live.n; i++) setDMIG(inst, ll_get(live, i), DMIG(inst, ll_get(live, i)) + t);
     setDEV(inst, nev, ev);
     nev++;
-    /* RECONNECT: the interval's rate was just computed (a split interval keeps its lineage count) */
-    if (RECONNECT) lnld -= rate * t;
-    else lnld -= (mig_rate + gph_div_by(2 * nlin, theta, thinv)) * t;
+    lnld -= (mig_rate + gph_div_by(2 * nlin, theta, thinv)) * t;
     if (mig_source >= 0) {
       lnld += g_model.logMigRate[b];
-      ev = mig_source;
       setDCOAL(inst, pop, dcoal);
       pop = g_model.bandSrc[b];
       dcoal = DCOAL(inst, pop);
       theta = g_model.theta[pop];
       thinv = g_model.thetaInv[pop];
-      mig_source = -1;
       mig_rate = 0.0;
       live.n = 0;
       for (b = 0; b < g_lay.B; b++) {
@@ -1945,16 +2008,20 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
           ll_push(live, b);
         }
       }
-    } else if (ty == GPH_MIG_BAND_START) {
-      mig_rate += g_model.migRate[node_id];
-      ll_push(live, node_id);
-    } else if (ty == GPH_MIG_BAND_END) {
-      mig_rate -= g_model.migRate[node_id];
-      if (live.n == 1) mig_rate = 0.0;
-      i = ll_find(live, node_id);
-      if (i < live.n) ll_swap_remove(live, i);
+      ev = ENEXT(mig_source);
+      mig_source = -1;
+    } else {
+      if (R.type == GPH_MIG_BAND_START) {
+        mig_rate += g_model.migRate[node_id];
+        ll_push(live, node_id);
+      } else if (R.type == GPH_MIG_BAND_END) {
+        mig_rate -= g_model.migRate[node_id];
+        if (live.n == 1) mig_rate = 0.0;
+        i = ll_find(live, node_id);
+        if (i < live.n) ll_swap_remove(live, i);
+      }
+      ev = R.next;
     }
-    ev = (ev == ev0) ? R.next : ENEXT(ev);   /* nothing is inserted AFTER the interval within a step */
   }
   setDCOAL(inst, pop, dcoal);
   lnld += g_model.logTwoTheta[pop];
