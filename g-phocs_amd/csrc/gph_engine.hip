@@ -91,59 +91,69 @@ __global__ void k_apply_list(GphKargs KA, GphDev D)
   apply_list_locus(D.pages + (size_t)g * KA.lay.page_bytes, KA.lay, KA.G->apply, na);
 }
 // the stage above the loci (gph_global.h): one wavefront, every lane runs the same scalar code, lane 0's stores count
-// The chain state (a few KB) is staged through LDS by the whole wavefront -- two coalesced copies instead of a chain
-// of dependent HBM round trips of a lone thread (10 -> 4 us per stage, 14 stages per iteration) -- and so are the
-// reduced rows of the ranks.
-__global__ void __launch_bounds__(64) k_global(GphKargs KA, const double *rows, int world, int stage, int arg, int iteration)
+// ---- the stage(s) above the loci (gph_global.h) and the reductions that feed them, as ONE launch.
+// The chain state (12 KB) and the ranks' reduced rows are staged through LDS by the whole block -- coalesced copies
+// instead of a chain of dependent HBM round trips of a lone thread; thread 0 runs the stages in order.
+struct GphStageList { int n; int stage[6]; int arg[6]; };
+#define GPH_RED_SUBS 8
+#define GPH_RED_THREADS (GPH_RED_SUBS * 64)
+struct alignas(16) GphStageShared {
+  char g[sizeof(GphGlobal)];
+  double r[GPH_RED_ROW];
+};
+__device__ void stages_body(GphKargs &KA, const double *rows, int world, const GphStageList &SL, int iteration, GphStageShared &sh)
 {
   typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
   static_assert(sizeof(GphGlobal) % 16 == 0, "the chain state is copied in 16-byte units");
-  __shared__ __attribute__((aligned(16))) char g_sh[sizeof(GphGlobal)];
-  __shared__ __attribute__((aligned(16))) double r_sh[GPH_RED_ROW];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
   const gu32x4 *src = (const gu32x4 *)KA.G;
-  gu32x4 *dst = (gu32x4 *)g_sh;
-  for (int i = lane; i < (int)(sizeof(GphGlobal) / 16); i += 64) dst[i] = src[i];
-  /* the ranks' rows combined in rank order (GphRed's order), one column per lane step */
-  for (int c = lane; c < GPH_RED_ROW; c += 64) {
+  gu32x4 *dst = (gu32x4 *)sh.g;
+  for (int i = tid; i < (int)(sizeof(GphGlobal) / 16); i += nt) dst[i] = src[i];
+  /* the ranks' rows combined in rank order (the same additions on every rank), one column per thread step */
+  for (int c = tid; c < GPH_RED_ROW; c += nt) {
     const int within = c % GPH_RED_STRIDE, kind = within < 3 * GPH_RED_COLS ? within / GPH_RED_COLS : 3;
     double v = rows[c];
     for (int r = 1; r < world; r++) {
       const double w = rows[(size_t)r * GPH_RED_ROW + c];
       v = kind == 0 ? v + w : kind == 1 ? (w < v ? w : v) : (w > v ? w : v);
     }
-    r_sh[c] = v;
+    sh.r[c] = v;
   }
   __syncthreads();
-  if (lane == 0) {
-    GphGlobal &G = *(GphGlobal *)g_sh;
+  if (tid == 0) {
+    GphGlobal &G = *(GphGlobal *)sh.g;
     G.iteration = iteration;
     GphRed R;
-    R.rows = r_sh; R.world = 1;
-    gg_stage(G, R, stage, arg);
+    R.rows = sh.r; R.world = 1;
+    for (int k = 0; k < SL.n; k++) gg_stage(G, R, SL.stage[k], SL.arg[k]);
   }
   __syncthreads();
   gu32x4 *out = (gu32x4 *)KA.G;
-  for (int i = lane; i < (int)(sizeof(GphGlobal) / 16); i += 64) out[i] = dst[i];
+  for (int i = tid; i < (int)(sizeof(GphGlobal) / 16); i += nt) out[i] = dst[i];
 }
+__global__ void __launch_bounds__(GPH_RED_THREADS) k_global(GphKargs KA, const double *rows, int world, GphStageList SL, int iteration)
+{
+  __shared__ __attribute__((aligned(16))) GphStageShared sh;
+  stages_body(KA, rows, world, SL, iteration, sh);
+}
+
 // fixed-shape two-level reduction (deterministic run to run): block b owns a contiguous chunk of
 // loci; inside it Q = 8 * (64 / column width) sub-sequences (g = g0+q, g0+q+Q, ...) are summed in index
 // order and combined in sub-sequence order; the final pass adds the 256 block partials in a fixed shape.
 // mode 0 = per-locus outputs (GPH_OUT_SLOTS columns), mode 1 = compact statistics (2K+2B columns)
-// part: [3][GPH_RED_BLOCKS][GPH_RED_COLS] (sum, min, max)
-#define GPH_RED_SUBS 8
-__global__ void __launch_bounds__(GPH_RED_SUBS * 64) k_reduce_partial(GphDev D, int mode, int ncols, double *part)
+// part: [3][GPH_RED_BLOCKS][GPH_RED_COLS] (sum, min, max) per section
+__device__ void reduce_partial_body(const GphDev &D, int mode, int ncols, double *part, double (*sh)[GPH_RED_SUBS * 4][16])
 {
-  __shared__ double sh[3][GPH_RED_SUBS * 4][16];
   /* a wavefront covers 64 / cw loci at a time (cw = columns rounded up to 16, 32 or 64): every lane has work */
   const int cw = ncols <= 16 ? 16 : ncols <= 32 ? 32 : ncols <= 64 ? 64 : 128;
+  const int b = blockIdx.x;
+  const int chunk = (D.L + GPH_RED_BLOCKS - 1) / GPH_RED_BLOCKS;
+  const int g0 = b * chunk, g1 = g0 + chunk < D.L ? g0 + chunk : D.L;
+  const double *src = mode == 0 ? D.out : D.stats;
+  const int stride = mode == 0 ? GPH_OUT_SLOTS : ncols;
   if (cw == 128) {
     /* more than 64 columns (the largest capacity variant): two columns per lane, one locus per wavefront step */
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, b = blockIdx.x;
-    const int chunk = (D.L + GPH_RED_BLOCKS - 1) / GPH_RED_BLOCKS;
-    const int g0 = b * chunk, g1 = g0 + chunk < D.L ? g0 + chunk : D.L;
-    const double *src = mode == 0 ? D.out : D.stats;
-    const int stride = mode == 0 ? GPH_OUT_SLOTS : ncols;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     for (int half = 0; half < 2; half++) {
       const int col = lane + 64 * half;
       double s = 0.0, mn = 1e300, mx = -1e300;
@@ -170,14 +180,11 @@ __global__ void __launch_bounds__(GPH_RED_SUBS * 64) k_reduce_partial(GphDev D, 
         }
       }
     }
+    __syncthreads();
     return;
   }
   const int ng = 64 / cw, Q = GPH_RED_SUBS * ng;
-  const int lane = threadIdx.x & 63, col = lane % cw, q = (threadIdx.x >> 6) * ng + lane / cw, b = blockIdx.x;
-  const int chunk = (D.L + GPH_RED_BLOCKS - 1) / GPH_RED_BLOCKS;
-  const int g0 = b * chunk, g1 = g0 + chunk < D.L ? g0 + chunk : D.L;
-  const double *src = mode == 0 ? D.out : D.stats;
-  const int stride = mode == 0 ? GPH_OUT_SLOTS : ncols;
+  const int lane = threadIdx.x & 63, col = lane % cw, q = (threadIdx.x >> 6) * ng + lane / cw;
   double s = 0.0, mn = 1e300, mx = -1e300;
   if (col < ncols)
     for (int g = g0 + q; g < g1; g += Q) {
@@ -204,36 +211,61 @@ __global__ void __launch_bounds__(GPH_RED_SUBS * 64) k_reduce_partial(GphDev D, 
       part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + c0 + c] = tmx;
     }
   }
-}
-// final pass: column c's block partials in block order, as GPH_RED_SUBS contiguous runs (one thread each) combined
-// in run order -- a fixed shape, so the result does not depend on scheduling.  red = this section of the rank's row
-__global__ void __launch_bounds__(GPH_RED_SUBS * GPH_RED_COLS) k_reduce_final(int ncols, const double *part, double *red, const int32_t *err)
-{
-  if (threadIdx.x == 0) red[3 * GPH_RED_COLS] = (double)*err;
-  __shared__ double sh[3][GPH_RED_SUBS][GPH_RED_COLS];
-  const int col = threadIdx.x % GPH_RED_COLS, sub = threadIdx.x / GPH_RED_COLS;
-  const int per = GPH_RED_BLOCKS / GPH_RED_SUBS;
-  double s = 0.0, mn = 1e300, mx = -1e300;
-  if (col < ncols)
-    for (int b = sub * per; b < (sub + 1) * per; b++) {
-      s += part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
-      double v = part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
-      mn = v < mn ? v : mn;
-      v = part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
-      mx = v > mx ? v : mx;
-    }
-  sh[0][sub][col] = s; sh[1][sub][col] = mn; sh[2][sub][col] = mx;
   __syncthreads();
-  if (sub != 0 || col >= ncols) return;
-  s = 0.0; mn = 1e300; mx = -1e300;
-  for (int k = 0; k < GPH_RED_SUBS; k++) {
-    s += sh[0][k][col];
-    mn = sh[1][k][col] < mn ? sh[1][k][col] : mn;
-    mx = sh[2][k][col] > mx ? sh[2][k][col] : mx;
+}
+// final pass: column c's block partials in block order, as GPH_RED_SUBS contiguous runs combined in run order -- a
+// fixed shape, so the result does not depend on scheduling.  512 threads: thread (h, c) sums runs h and h + 4.
+__device__ void reduce_final_body(int ncols, const double *part, double *red, double (*sh)[GPH_RED_SUBS][GPH_RED_COLS])
+{
+  const int col = threadIdx.x % GPH_RED_COLS, h = threadIdx.x / GPH_RED_COLS;
+  const int per = GPH_RED_BLOCKS / GPH_RED_SUBS;
+  for (int sub = h; sub < GPH_RED_SUBS; sub += GPH_RED_THREADS / GPH_RED_COLS) {
+    double s = 0.0, mn = 1e300, mx = -1e300;
+    if (col < ncols)
+      for (int b = sub * per; b < (sub + 1) * per; b++) {
+        s += part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
+        double v = part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
+        mn = v < mn ? v : mn;
+        v = part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
+        mx = v > mx ? v : mx;
+      }
+    sh[0][sub][col] = s; sh[1][sub][col] = mn; sh[2][sub][col] = mx;
   }
-  red[col] = s;
-  red[GPH_RED_COLS + col] = mn;
-  red[2 * GPH_RED_COLS + col] = mx;
+  __syncthreads();
+  if (h == 0 && col < ncols) {
+    double s = 0.0, mn = 1e300, mx = -1e300;
+    for (int k = 0; k < GPH_RED_SUBS; k++) {
+      s += sh[0][k][col];
+      mn = sh[1][k][col] < mn ? sh[1][k][col] : mn;
+      mx = sh[2][k][col] > mx ? sh[2][k][col] : mx;
+    }
+    red[col] = s;
+    red[GPH_RED_COLS + col] = mn;
+    red[2 * GPH_RED_COLS + col] = mx;
+  }
+  __syncthreads();
+}
+// reduction of section 0 (nc0 columns of the per-locus outputs) and / or section 1 (nc1 columns of the statistics) into
+// this rank's row; the LAST block to finish its partials (ticket) does the final pass and -- single rank -- runs the
+// stages that consume the row in the same launch
+__global__ void __launch_bounds__(GPH_RED_THREADS) k_reduce_stage(GphKargs KA, GphDev D, int nc0, int nc1, double *part, unsigned *ticket, double *red,
+                                                                  int do_stage, GphStageList SL, int iteration)
+{
+  __shared__ union { double p[3][GPH_RED_SUBS * 4][16]; double f[3][GPH_RED_SUBS][GPH_RED_COLS]; GphStageShared st; } sh;
+  __shared__ int s_last;
+  if (nc0 > 0) reduce_partial_body(D, 0, nc0, part, sh.p);
+  if (nc1 > 0) reduce_partial_body(D, 1, nc1, part + 3 * GPH_RED_BLOCKS * GPH_RED_COLS, sh.p);
+  __syncthreads();
+  /* ONE release per block (thread 0, after the block barrier: cumulative over the block's stores) -- an agent-scope
+   * fence writes the L2 back, and 2048 wavefronts doing it cost more than the reduction itself */
+  if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(ticket, 1u) == gridDim.x - 1; if (s_last) __threadfence(); }
+  __syncthreads();
+  if (!s_last) return;
+  if (nc0 > 0) reduce_final_body(nc0, part, red, sh.f);
+  if (nc1 > 0) reduce_final_body(nc1, part + 3 * GPH_RED_BLOCKS * GPH_RED_COLS, red + GPH_RED_STRIDE, sh.f);
+  if (threadIdx.x == 0) { red[3 * GPH_RED_COLS] = (double)*D.err; *ticket = 0; }
+  __syncthreads();
+  if (do_stage) stages_body(KA, red, 1, SL, iteration, sh.st);
 }
 #endif
 
@@ -284,6 +316,14 @@ struct gph_engine {
   int lr_lds_bytes = 0;
   // reductions: block partials, this rank's reduced row (GPH_RED_ROW doubles) and every rank's row after the all-gather
   double *d_part = nullptr, *d_red = nullptr, *d_gather = nullptr;
+#ifndef GPH_HOSTEMU
+  unsigned *d_ticket = nullptr;                  // last-block ticket of the fused reduction
+  // resident mode: reductions and stages requested since the last launch; they go out as ONE kernel when the next
+  // per-locus kernel is launched (or the host needs the result)
+  int pend_nc0 = 0, pend_nc1 = 0;
+  GphStageList pend_sl = {0, {0}, {0}};
+  int pend_iteration = 0;
+#endif
   double *h_red = nullptr;                       // pinned: this rank's row (host mode)
   // several ranks, one process per GPU: a native communicator (RCCL all-gather on the engine's stream, or -- ranks
   // sharing one GPU, tests only -- a host shared-memory exchange) or a caller-supplied hook
@@ -390,6 +430,7 @@ static int stream_sync(gph_engine *e) { e->n_syncs++; return 0; }
 static int dev_alloc(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess ? 0 : GPH_EHIP; }
 static void dev_free(void *p) { if (p) (void)hipFree(p); }
 static int collect_times(gph_engine *e);
+static int flush_pending(gph_engine *e);
 static int stream_sync(gph_engine *e)
 {
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -435,7 +476,7 @@ static void tm_end(gph_engine *e, int slot) { if (slot >= 0) (void)hipEventRecor
 // locus with at most one pattern per lane (slots in decreasing P: longest wavefronts first), a second one
 // the rare loci with more (they also need the per-pattern terms array in LDS).  No host synchronisation here.
 #define LAUNCH_PRE(e) do { GphKargs &ka_ = (e)->ka; ka_.model = (e)->G_h->model; ka_.lay = (e)->lay; ka_.G = (e)->G_d; } while (0)
-#define LAUNCH(e, which, name, ...) do { LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
+#define LAUNCH(e, which, name, ...) do { { int rcf_ = flush_pending(e); if (rcf_) return rcf_; } LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
     const int tms_ = tm_begin((e), (which)); \
     for (auto &bk_ : (e)->buckets) { \
       hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
@@ -451,7 +492,7 @@ static void tm_end(gph_engine *e, int slot) { if (slot >= 0) (void)hipEventRecor
     name(0, ka_, (e)->dev, 0, __VA_ARGS__); \
     (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
 #else
-#define LAUNCH1(e, which, name, ldsbytes, ...) do { LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
+#define LAUNCH1(e, which, name, ldsbytes, ...) do { { int rcf_ = flush_pending(e); if (rcf_) return rcf_; } LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
     const int tms_ = tm_begin((e), (which)); \
     hipLaunchKernelGGL(name, dim3(1), dim3(GPH_WAVE), (ldsbytes), (e)->stream, ka_, (e)->dev, 0, __VA_ARGS__); \
     HIPCHK(hipGetLastError()); \
@@ -501,6 +542,46 @@ static bool resident(const gph_engine *e)
 }
 static int world_of(const gph_engine *e) { return e->comm ? gph_comm_world(e->comm) : 1; }
 
+#ifdef GPH_HOSTEMU
+static int flush_pending(gph_engine *) { return 0; }
+#else
+// resident mode: everything requested since the last per-locus launch -- the reduction(s) of its outputs and the stages
+// above the loci -- as one kernel (single rank), or reduction -> RCCL all-gather -> stages (several ranks)
+static int flush_pending(gph_engine *e)
+{
+  const bool red = e->pend_nc0 > 0 || e->pend_nc1 > 0;
+  if (!red && e->pend_sl.n == 0) return 0;
+  const GphStageList sl = e->pend_sl;
+  const int nc0 = e->pend_nc0, nc1 = e->pend_nc1;
+  e->pend_nc0 = e->pend_nc1 = 0;
+  e->pend_sl.n = 0;
+  const bool multi = e->comm && gph_comm_world(e->comm) > 1;
+  LAUNCH_PRE(e);
+  if (red) {
+    const int fuse = sl.n > 0 && !multi;
+    hipLaunchKernelGGL(k_reduce_stage, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_THREADS), 0, e->stream, e->ka, e->dev, nc0, nc1, e->d_part, e->d_ticket,
+                       e->d_red, fuse, sl, e->pend_iteration);
+    HIPCHK(hipGetLastError());
+    e->n_launches++;
+    if (multi) {
+      if (gph_comm_allgather_stream(e->comm, e->d_red, e->d_gather, GPH_RED_ROW, (void *)e->stream)) return GPH_EHIP;
+      e->n_collectives++;
+    } else if (e->comm) {
+      e->n_collectives++;   /* a one-rank communicator: the row is already everybody's */
+      if (gph_comm_allgather_stream(e->comm, e->d_red, e->d_gather, GPH_RED_ROW, (void *)e->stream)) return GPH_EHIP;
+    }
+    if (fuse) return 0;
+  }
+  if (sl.n > 0) {
+    const double *rows = e->comm ? e->d_gather : e->d_red;
+    hipLaunchKernelGGL(k_global, dim3(1), dim3(GPH_RED_THREADS), 0, e->stream, e->ka, rows, world_of(e), sl, e->pend_iteration);
+    HIPCHK(hipGetLastError());
+    e->n_launches++;
+  }
+  return 0;
+}
+#endif
+
 // reduce the per-locus outputs (section 0) or the page statistics (section 1) over the local loci into this rank's row
 static int reduce_local(gph_engine *e, int sec, int ncols)
 {
@@ -519,10 +600,19 @@ static int reduce_local(gph_engine *e, int sec, int ncols)
   red[3 * GPH_RED_COLS] = (double)*e->dev.err;
   return 0;
 #else
-  hipLaunchKernelGGL(k_reduce_partial, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_SUBS * 64), 0, e->stream, e->dev, sec, ncols, e->d_part);
-  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(GPH_RED_SUBS * GPH_RED_COLS), 0, e->stream, ncols, e->d_part, e->d_red + sec * GPH_RED_STRIDE, e->dev.err);
+  if (resident(e)) {
+    /* lazily: fused with the stages that consume the row (flush_pending) */
+    if (e->pend_sl.n > 0) { int rcf = flush_pending(e); if (rcf) return rcf; }
+    if (sec == 0) e->pend_nc0 = ncols; else e->pend_nc1 = ncols;
+    return 0;
+  }
+  { int rcf = flush_pending(e); if (rcf) return rcf; }
+  GphStageList none = {0, {0}, {0}};
+  LAUNCH_PRE(e);
+  hipLaunchKernelGGL(k_reduce_stage, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_THREADS), 0, e->stream, e->ka, e->dev, sec == 0 ? ncols : 0, sec == 1 ? ncols : 0,
+                     e->d_part, e->d_ticket, e->d_red, 0, none, 0);
   HIPCHK(hipGetLastError());
-  e->n_launches += 2;
+  e->n_launches += 1;
   return 0;
 #endif
 }
@@ -575,21 +665,16 @@ static int run_stage(gph_engine *e, int stage, int arg, int iteration)
   const bool reads = stage_reads_row(stage);
 #ifndef GPH_HOSTEMU
   if (resident(e)) {
-    const double *rows = e->d_red;
-    int world = 1;
-    if (e->comm && reads) {
-      int rc = gph_comm_allgather_stream(e->comm, e->d_red, e->d_gather, GPH_RED_ROW, (void *)e->stream);
-      if (rc) return GPH_EHIP;
-      e->n_collectives++;
-      rows = e->d_gather;
-      world = gph_comm_world(e->comm);
-    }
-    LAUNCH_PRE(e);
-    hipLaunchKernelGGL(k_global, dim3(1), dim3(64), 0, e->stream, e->ka, rows, world, stage, arg, iteration);
-    HIPCHK(hipGetLastError());
-    e->n_launches++;
+    /* queued: goes out fused with the reduction before it (and the stages next to it) at the next launch */
+    if (e->pend_sl.n == 6) { int rcf = flush_pending(e); if (rcf) return rcf; }
+    e->pend_sl.stage[e->pend_sl.n] = stage;
+    e->pend_sl.arg[e->pend_sl.n] = arg;
+    e->pend_sl.n++;
+    e->pend_iteration = iteration;
+    (void)reads;
     return 0;
   }
+  { int rcf = flush_pending(e); if (rcf) return rcf; }
 #endif
   GphRed R;
   R.rows = e->h_red; R.world = 1;
@@ -638,6 +723,7 @@ static int check_error(gph_engine *e)
 // the mirror is current (host mode: always; resident mode: after pull_G)
 static int finish_sync(gph_engine *e)
 {
+  { int rcf = flush_pending(e); if (rcf) return rcf; }
   if (resident(e)) { int rc = pull_G(e); if (rc) return rc; }
   return check_error(e);
 }
@@ -737,7 +823,8 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
       hipMalloc((void **)&e->G_d, sizeof(GphGlobal)) != hipSuccess ||
       hipHostMalloc((void **)&e->h_red, sizeof(double) * GPH_RED_ROW * 64, hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void **)&e->d_red, sizeof(double) * GPH_RED_ROW) != hipSuccess ||
-      hipMemset(e->d_red, 0, sizeof(double) * GPH_RED_ROW) != hipSuccess) { gph_engine_destroy(e); return GPH_EHIP; }
+      hipMemset(e->d_red, 0, sizeof(double) * GPH_RED_ROW) != hipSuccess ||
+      hipMalloc((void **)&e->d_ticket, 64) != hipSuccess || hipMemset(e->d_ticket, 0, 64) != hipSuccess) { gph_engine_destroy(e); return GPH_EHIP; }
   e->d_gather = e->d_red;
 #else
   e->G_h = (GphGlobal *)calloc(1, sizeof(GphGlobal));
@@ -766,6 +853,7 @@ void gph_engine_destroy(gph_engine *e)
   free(e->G_h);
 #else
   dev_free(e->G_d);
+  dev_free(e->d_ticket);
   if (e->h_red) (void)hipHostFree(e->h_red);
   if (e->G_h) (void)hipHostFree(e->G_h);
   for (auto &t : e->tm) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -886,7 +974,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   rc |= dev_alloc((void **)&e->dev.orig, sizeof(int32_t) * L);
   rc |= dev_alloc((void **)&e->dev.out, sizeof(double) * GPH_OUT_SLOTS * L);
   rc |= dev_alloc((void **)&e->dev.stats, sizeof(double) * (2 * e->cfg.K + 2 * e->cfg.B) * L);
-  rc |= dev_alloc((void **)&e->d_part, sizeof(double) * 3 * GPH_RED_BLOCKS * GPH_RED_COLS);
+  rc |= dev_alloc((void **)&e->d_part, sizeof(double) * 2 * 3 * GPH_RED_BLOCKS * GPH_RED_COLS);
   rc |= dev_alloc((void **)&e->dev.err, sizeof(int32_t));
 #ifdef GPH_HOSTEMU
   if (e->dev.err) *e->dev.err = 0;
@@ -1080,6 +1168,7 @@ static int apply_list(gph_engine *e)
 #ifdef GPH_HOSTEMU
   for (int64_t g = 0; g < e->L; g++) apply_list_locus(e->dev.pages + (size_t)g * e->lay.page_bytes, e->lay, e->G_h->apply, e->G_h->napply);
 #else
+  { int rcf = flush_pending(e); if (rcf) return rcf; }
   LAUNCH_PRE(e);
   hipLaunchKernelGGL(k_apply_list, dim3((unsigned)((e->L + 255) / 256)), dim3(256), 0, e->stream, e->ka, e->dev);
   HIPCHK(hipGetLastError());
@@ -1500,9 +1589,12 @@ int gph_engine_iteration_(gph_engine *e, int32_t iteration, const double *lr_alp
     if ((rc = run_stage(e, GS_TOTALS, 0, iteration))) return rc;
   }
   if ((rc = run_stage(e, GS_THETA, 0, iteration))) return rc;
+  /* the first tau proposal touches no locus: its stage rides in the launch of the stages before it, ahead of the
+   * per-locus touch-ups of the accepted theta / migration-rate proposals */
+  if (Kc < K && (rc = run_stage(e, GS_TAU_PROPOSE, Kc, iteration))) return rc;
   if ((rc = apply_list(e))) return rc;
   for (int ap = Kc; ap < K; ++ap) {
-    if ((rc = run_stage(e, GS_TAU_PROPOSE, ap, iteration))) return rc;
+    if (ap > Kc && (rc = run_stage(e, GS_TAU_PROPOSE, ap, iteration))) return rc;
     LAUNCH(e, 1, k_tau_eval, 0);
     if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
     if ((rc = run_stage(e, GS_TAU_DECIDE, ap, iteration))) return rc;

@@ -66,7 +66,21 @@ GPH_HD double gg_rndu(GphGlobal &G)
   G.gx = 171u * (G.gx % 177u) - 2u * (G.gx / 177u);
   G.gy = 172u * (G.gy % 176u) - 35u * (G.gy / 176u);
   G.gz = 170u * (G.gz % 178u) - 63u * (G.gz / 178u);
+#if defined(__HIP_DEVICE_COMPILE__)
+  /* the stage runs on ONE lane of a lone wavefront: instruction count is its time.  IEEE-exact quotients without the
+   * divide expansion, as in the locus streams (gph_locus.h: l_rndu; exhaustively verified for all 32-bit x) */
+  {
+    const double rx = 1.0 / 30269.0, ry = 1.0 / 30307.0, rz = 1.0 / 30323.0;
+    const double xd = (double)G.gx, yd = (double)G.gy, zd = (double)G.gz;
+    double q;
+    q = xd * rx; const double qx = __builtin_fma(__builtin_fma(-q, 30269.0, xd), rx, q);
+    q = yd * ry; const double qy = __builtin_fma(__builtin_fma(-q, 30307.0, yd), ry, q);
+    q = zd * rz; const double qz = __builtin_fma(__builtin_fma(-q, 30323.0, zd), rz, q);
+    r = qx + qy + qz;
+  }
+#else
   r = G.gx / 30269.0 + G.gy / 30307.0 + G.gz / 30323.0;
+#endif
   r = (r - (int)r);
   return r;
 }
