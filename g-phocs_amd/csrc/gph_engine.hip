@@ -1704,7 +1704,10 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
   if (!f) return GPH_EARG;
   std::vector<int32_t> slot_of(e->L);
   for (int64_t j = 0; j < e->L; j++) slot_of[e->h_orig[j]] = (int32_t)j;
+  /* GPH_DUMP_STRIDE=k: every k-th locus (global index) only -- full-size parity runs */
+  const int dstride = getenv("GPH_DUMP_STRIDE") && atoi(getenv("GPH_DUMP_STRIDE")) > 0 ? atoi(getenv("GPH_DUMP_STRIDE")) : 1;
   for (int64_t go = 0; go < e->L; go++) {
+    if ((go + e->cfg.locus_begin) % dstride != 0) continue;
     const int64_t g = slot_of[go];
     const char *pg = pages.data() + (size_t)g * y.page_bytes;
     const double *fs = (const double *)(pg + y.o_fscal);

@@ -193,7 +193,9 @@ void go_dump_state(go_state *s, FILE *f, int withCond)
   for (pop = 0; pop < m->K; pop++) fprintf(f, " %a %d", s->tot_coal_stats[pop], s->tot_num_coals[pop]);
   for (b = 0; b < m->B; b++) fprintf(f, " %a %d", s->tot_mig_stats[b], s->tot_num_migs[b]);
   fprintf(f, "\n");
-  for (g = 0; g < s->L; g++) {
+  /* GPH_DUMP_STRIDE=k: every k-th locus only (full-size parity runs: 100 000 loci would be a 300-MB dump) */
+  const int dstride = getenv("GPH_DUMP_STRIDE") && atoi(getenv("GPH_DUMP_STRIDE")) > 0 ? atoi(getenv("GPH_DUMP_STRIDE")) : 1;
+  for (g = 0; g < s->L; g += dstride) {
     go_locus *q = &s->loc[g];
     fprintf(f, "LOCUS %d root %d dataLnL %a genLnL %a rng %u %u %u\n", g, q->root, q->dataLnL, q->genLnL,
             q->rx, q->ry, q->rz);

@@ -60,9 +60,27 @@ def test_full_size_against_live_oracle(G, oracle_cli, tmp_path):
     pth = str(tmp_path / "full.gpk")
     synth.write_pack(pk, pth)
     mine, theirs = str(tmp_path / "hip.rec"), str(tmp_path / "oracle.rec")
-    cnt, _ = _run(G, pk, iters, mine)
-    subprocess.run([oracle_cli, "run", pth, str(iters), theirs], check=True, timeout=1500)
+    # per-locus state too (genealogy, event chains with ids and lineage counts, statistics, RNG slots) of every 50th
+    # locus after the last iteration: 2 000 loci, field by field
+    os.environ["GPH_DUMP_STRIDE"] = "50"
+    try:
+        s = G.Sampler(pk)
+        s.set_record_file(mine)
+        s.initialize()
+        for it in range(iters):
+            s.iteration(it)
+        s.dump_state(mine + ".state", False)
+        s.set_record_file(None)
+        cnt = s.counters()
+        s.close()
+        subprocess.run([oracle_cli, "run", pth, str(iters), theirs, theirs + ".state", str(iters - 1), "0"], check=True,
+                       timeout=1500)
+    finally:
+        os.environ.pop("GPH_DUMP_STRIDE", None)
     worst = compare_records(mine, theirs)
+    from parity_util import compare_states
+    compare_states(mine + ".state", theirs + ".state")
+    assert sum(1 for l in open(mine + ".state") if l.startswith("LOCUS ")) == L_FULL // 50
     assert any(l.startswith(f"IT {iters - 1} CHECK") for l in open(mine).read().splitlines())
     assert cnt["evals"] > 45 * L_FULL * iters
     print(f"full size: {L_FULL} loci x {iters} iterations, {cnt['evals']} evaluations, worst accumulator rel diff "

@@ -80,9 +80,15 @@ def main():
         lib = G.load_library(dims=dims)
     rc = lib.gph_run_control_file_ranked(os.fsencode(a.ctl), os.fsencode(a.ctl2) if a.ctl2 else None, local_rank if gpu else 0,
                                          int(a.verbose), rank, world, cb, None)
+    if rc:
+        # a failed rank must not enter another collective: its peers are blocked in the all-gather of the reduction
+        # point it never reached, and a barrier here would only wait for the backend's timeout.  Exiting non-zero
+        # makes torch.distributed.run tear the job down.
+        sys.stderr.write(f"rank {rank}: gph_run_control_file_ranked failed with status {rc}\n")
+        os._exit(1)
     dist.barrier()
     dist.destroy_process_group()
-    sys.exit(1 if rc else 0)
+    sys.exit(0)
 
 
 if __name__ == "__main__":
