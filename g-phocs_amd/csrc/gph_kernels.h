@@ -32,45 +32,10 @@ struct GphDev {            // device pointers (passed by value to every kernel)
 // pattern-rich loci no longer dictate the occupancy of all the others.
 
 // ---------------------------------------------------------------- staging
-GPH_DEV void copy16_g2l(int lds_off, const char *src, int bytes)
-{
-  int i, n16 = bytes >> 4;
-#ifdef GPH_HOSTEMU
-  memcpy(gph_sm + lds_off, src, bytes);
-  (void)i; (void)n16;
-#else
-  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
-  typedef GPH_LDS gu32x4 luint4;
-  const gu32x4 *s = (const gu32x4 *)src;
-  luint4 *d = (luint4 *)(GPH_SMB + lds_off);
-  for (i = GPH_LANE; i < n16; i += GPH_NLANES) d[i] = s[i];
-#endif
-}
+GPH_DEV void copy16_g2l(int lds_off, const char *src, int bytes) { gph_copy16_in(GPH_SMB + lds_off, src, bytes >> 4); }
 // HBM page <-> page part of the static LDS image: identical layout, one coalesced copy
-GPH_DEV void page_in(const char *page)
-{
-#ifdef GPH_HOSTEMU
-  memcpy((char *)&gph_lds, page, g_lay.page_bytes);
-#else
-  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
-  typedef GPH_LDS gu32x4 luint4;
-  const gu32x4 *s = (const gu32x4 *)page;
-  luint4 *d = (luint4 *)&gph_lds;
-  for (int i = GPH_LANE; i < (g_lay.page_bytes >> 4); i += GPH_NLANES) d[i] = s[i];
-#endif
-}
-GPH_DEV void page_out(char *page)
-{
-#ifdef GPH_HOSTEMU
-  memcpy(page, (const char *)&gph_lds, g_lay.page_bytes);
-#else
-  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
-  typedef GPH_LDS gu32x4 luint4;
-  gu32x4 *d = (gu32x4 *)page;
-  const luint4 *s = (const luint4 *)&gph_lds;
-  for (int i = GPH_LANE; i < (g_lay.page_bytes >> 4); i += GPH_NLANES) d[i] = s[i];
-#endif
-}
+GPH_DEV void page_in(const char *page) { gph_copy16_in(GPH_LDSP(&gph_lds), page, g_lay.page_bytes >> 4); }
+GPH_DEV void page_out(char *page) { gph_copy16_out(page, GPH_LDSP(&gph_lds), g_lay.page_bytes >> 4); }
 
 GPH_DEV void scratch_init(const GphDev &D, int g, int P, uint64_t cond_off)
 {
@@ -93,38 +58,13 @@ GPH_DEV void scratch_init(const GphDev &D, int g, int P, uint64_t cond_off)
 // of the lifetime of a wavefront of the short kernels (tau / mixing evaluate, commit).
 GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withSeq)
 {
-#ifdef GPH_HOSTEMU
-  const int P_ = D.P[g];
-  const uint64_t co_ = D.cond_off[g];
-  page_in(pages + (size_t)g * g_lay.page_bytes);
-  if (withSeq) copy16_g2l(0, D.seq + D.seq_off[g], (int)(D.seq_off[g + 1] - D.seq_off[g]));
-#else
-  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
-  typedef GPH_LDS gu32x4 luint4;
   constexpr int PCH = (int)((offsetof(GphLds, s_dcoal) + 1023) / 1024);   /* 1 KB chunks of the page part */
   constexpr int SCH = 2;                                                   /* first 2 KB of the sequence block */
-  const int lane = GPH_LANE;
-  const gu32x4 *ps = (const gu32x4 *)(pages + (size_t)g * g_lay.page_bytes);
-  const int pn = g_lay.page_bytes >> 4;
   uint64_t o0 = 0, o1 = 0;
   if (withSeq) { o0 = D.seq_off[g]; o1 = D.seq_off[g + 1]; }
   const int P_ = D.P[g];                   /* per-locus table entries: scalar loads, in flight with everything else */
   const uint64_t co_ = D.cond_off[g];
-  gu32x4 pr[PCH], sr[SCH];
-#pragma unroll
-  for (int k = 0; k < PCH; k++) if (lane + 64 * k < pn) pr[k] = ps[lane + 64 * k];
-  const gu32x4 *ss = (const gu32x4 *)(D.seq + o0);
-  const int sn = (int)(o1 - o0) >> 4;
-#pragma unroll
-  for (int k = 0; k < SCH; k++) if (lane + 64 * k < sn) sr[k] = ss[lane + 64 * k];
-  luint4 *pd = (luint4 *)&gph_lds;
-#pragma unroll
-  for (int k = 0; k < PCH; k++) if (lane + 64 * k < pn) pd[lane + 64 * k] = pr[k];
-  luint4 *sd = (luint4 *)(GPH_SMB);
-#pragma unroll
-  for (int k = 0; k < SCH; k++) if (lane + 64 * k < sn) sd[lane + 64 * k] = sr[k];
-  for (int i = lane + 64 * SCH; i < sn; i += GPH_NLANES) sd[i] = ss[i];   /* pattern-rich loci */
-#endif
+  gph_copy16_in2<PCH, SCH>(GPH_LDSP(&gph_lds), pages + (size_t)g * g_lay.page_bytes, g_lay.page_bytes >> 4, GPH_SMB, D.seq + o0, (int)(o1 - o0) >> 4);
   GPH_SYNC();
   load_scalars();
   scratch_init(D, g, P_, co_);
@@ -158,11 +98,7 @@ GPH_DEV void out_common(const GphDev &D, int g)
     o[11] = gph_errcode();
     o[13] = CNT(CN_NOTENOUGH);
     if (gph_errcode() != 0) {
-#ifdef GPH_HOSTEMU
-      if (*D.err == 0) *D.err = gph_errcode();
-#else
-      atomicMax(D.err, gph_errcode());
-#endif
+      gph_raise(D.err, gph_errcode());
     }
   }
 }
@@ -409,21 +345,11 @@ GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
         setNCOAL(fpn, NCOAL(fpn) + 1);
       }
       replace_mig_nodes(node);
-#ifdef GPH_HOSTEMU
-      for (i = 0; i < DI(1, DI_NEV); ++i) {
-        ev = DEV(1, i);
-        setENLIN(ev, ENLIN(ev) + 1);
-      }
-      for (b = 0; b < g_lay.B; ++b) setMIGST(b, MIGST(b) + (DMIG(1, b) - DMIG(0, b)));
-      for (pop = 0; pop < g_lay.K; pop++) setCOALS(pop, COALS(pop) + (DCOAL(1, pop) - DCOAL(0, pop)));
-#else
-      {   /* one lane per list entry / band / population (entries are distinct) */
-        const int lane = GPH_LANE;
-        for (int k = lane; k < DI(1, DI_NEV); k += GPH_NLANES) { const int q = gph_lds.s_dev[1][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + 1); }
-        if (lane < g_lay.B) gph_lds.migst[lane] = gph_lds.migst[lane] + (gph_lds.s_dmig[1][lane] - gph_lds.s_dmig[0][lane]);
-        if (lane < g_lay.K) gph_lds.coal[lane] = gph_lds.coal[lane] + (gph_lds.s_dcoal[1][lane] - gph_lds.s_dcoal[0][lane]);
-      }
-#endif
+      /* one lane per list entry / band / population (entries are distinct) */
+      (void)ev; (void)b; (void)pop;
+      GPH_EACH(k, DI(1, DI_NEV)) { const int q = gph_lds.s_dev[1][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + 1); }
+      GPH_EACH1(k, g_lay.B) gph_lds.migst[k] = gph_lds.migst[k] + (gph_lds.s_dmig[1][k] - gph_lds.s_dmig[0][k]);
+      GPH_EACH1(k, g_lay.K) gph_lds.coal[k] = gph_lds.coal[k] + (gph_lds.s_dcoal[1][k] - gph_lds.s_dcoal[0][k]);
       lik_reset_saved();
       STAMPC_END(2);
     } else {
@@ -433,14 +359,7 @@ GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
         remove_event(SPRA(SA_NEWIN, i));
         remove_event(SPRA(SA_NEWOUT, i));
       }
-#ifdef GPH_HOSTEMU
-      for (i = 0; i < DI(0, DI_NEV); ++i) {
-        ev = DEV(0, i);
-        setENLIN(ev, ENLIN(ev) + 1);
-      }
-#else
-      for (int k = GPH_LANE; k < DI(0, DI_NEV); k += GPH_NLANES) { const int q = gph_lds.s_dev[0][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + 1); }
-#endif
+      GPH_EACH(k, DI(0, DI_NEV)) { const int q = gph_lds.s_dev[0][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + 1); }
       lik_revert();
       STAMPC_END(3);
     }
@@ -804,13 +723,8 @@ GPH_DEV void kb_lrate_prep(const GphDev &D, int g, double finetune, GphLrPre *pr
 
 GPH_DEV void lr_load(const char *pg, const char *seqp, int seqbytes, int o_nd, int o_seq, int &root, double &rate, double &lnl, GphRng &rng)
 {
-#ifdef GPH_HOSTEMU
-  memcpy(gph_sm + o_nd, pg + g_lay.o_nd, (size_t)g_lay.N * sizeof(GphNode));
-#else
-  typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
-  typedef GPH_LDS gu32x4 luint4;
-  if (GPH_LANE < g_lay.N) ((luint4 *)(GPH_SMB + o_nd))[GPH_LANE] = ((const gu32x4 *)(pg + g_lay.o_nd))[GPH_LANE];
-#endif
+  static_assert(sizeof(GphNode) == 16, "one 16-byte word per node");
+  gph_copy16_in1(GPH_SMB + o_nd, pg + g_lay.o_nd, g_lay.N);
   copy16_g2l(o_seq, seqp, seqbytes);
   const double *fs = (const double *)(pg + g_lay.o_fscal);
   const int32_t *is = (const int32_t *)(pg + g_lay.o_iscal);
@@ -1041,19 +955,12 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
     const GphLrPre pm = A.pre[mine];
     const int nb = D.L - base < GPH_NLANES ? D.L - base : GPH_NLANES;
     for (int i = 0; i < nb; i++) {
-#ifdef GPH_HOSTEMU
-      const GphLrPre &q = pm;
-      const double cand = q.cand, rspec = q.rspec, lspec = q.lspec, rold = q.rold, likold = q.likold;
-      const int j = q.slot;
-      rng.x = q.rx; rng.y = q.ry; rng.z = q.rz;
-#else
-      const double cand = rdlane64(pm.cand, i), rspec = rdlane64(pm.rspec, i), lspec = rdlane64(pm.lspec, i),
-                   rold = rdlane64(pm.rold, i), likold = rdlane64(pm.likold, i);
-      const int j = __builtin_amdgcn_readlane(pm.slot, i);
-      rng.x = (uint32_t)__builtin_amdgcn_readlane((int)pm.rx, i);
-      rng.y = (uint32_t)__builtin_amdgcn_readlane((int)pm.ry, i);
-      rng.z = (uint32_t)__builtin_amdgcn_readlane((int)pm.rz, i);
-#endif
+      const double cand = GPH_LANEVAL64(pm.cand, i), rspec = GPH_LANEVAL64(pm.rspec, i), lspec = GPH_LANEVAL64(pm.lspec, i),
+                   rold = GPH_LANEVAL64(pm.rold, i), likold = GPH_LANEVAL64(pm.likold, i);
+      const int j = GPH_LANEVAL32(pm.slot, i);
+      rng.x = (uint32_t)GPH_LANEVAL32(pm.rx, i);
+      rng.y = (uint32_t)GPH_LANEVAL32(pm.ry, i);
+      rng.z = (uint32_t)GPH_LANEVAL32(pm.rz, i);
       const double rnew = l_reflect(cand, 0, rold + rref);
       const double rrefnew = rref + rold - rnew;
       /* Dirichlet(alpha) prior ratio; with alpha = 1 and both rates positive and finite the term is a signed zero that

@@ -26,15 +26,7 @@ template <bool GPH_GM> struct GphCtxT {
     else return ((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->model;
   }
 #endif
-#ifdef GPH_HOSTEMU
-  int32_t r_pad[IS_COUNT + CN_COUNT + SI_COUNT] = {};
-#define GPH_PADGET(i) (r_pad[i])
-#define GPH_PADSET(i, v) (r_pad[i] = (v))
-#else
-  int32_t r_pad = 0;      /* lane i of this vector register holds scalar i */
-#define GPH_PADGET(i) __builtin_amdgcn_readlane(r_pad, (i))
-#define GPH_PADSET(i, v) do { const int pv_ = RFL(v); asm("v_writelane_b32 %0, %1, %2" : "+v"(r_pad) : "s"(pv_), "i"(i)); } while (0)
-#endif
+  GphPad<IS_COUNT + CN_COUNT + SI_COUNT> r_pad;     /* GPH_PADGET / GPH_PADSET, gph_rt.h */
 
 // ---------------------------------------------------------------- accessors
 #define AGE(i) (gph_lds.nd[i].age)
@@ -147,12 +139,7 @@ struct GphNodeS { double age; int father, left, right, npop; };
 GPH_DEVHOT GphNodeS ld_node(int node)
 {
   GphNodeS r;
-#ifdef GPH_HOSTEMU
-  r.age = gph_lds.nd[node].age; r.father = gph_lds.nd[node].father; r.left = gph_lds.nd[node].left;
-  r.right = gph_lds.nd[node].right; r.npop = gph_lds.nd[node].npop;
-#else
-  typedef uint32_t gph_u4 __attribute__((ext_vector_type(4)));
-  const gph_u4 w = *(const GPH_LDS gph_u4 *)&gph_lds.nd[node];
+  const gph_w4 w = gph_ld16(&gph_lds.nd[node]);
   union { double d; uint32_t u[2]; } t;
   t.u[0] = w.x; t.u[1] = w.y;
   const int w2 = RFL((int)w.z), w3 = RFL((int)w.w);
@@ -161,7 +148,6 @@ GPH_DEVHOT GphNodeS ld_node(int node)
   r.left = w2 >> 16;
   r.right = (int)(int16_t)w3;
   r.npop = w3 >> 16;
-#endif
   return r;
 }
 // every field of one event with ONE LDS access (ds_read_b128 of the GphEv record)
@@ -169,12 +155,7 @@ struct GphEvS { double time; int next, prev, node, nlin, type; };
 GPH_DEVHOT GphEvS ld_ev(int ev)
 {
   GphEvS r;
-#ifdef GPH_HOSTEMU
-  r.time = gph_lds.ev[ev].time; r.next = gph_lds.ev[ev].next; r.prev = gph_lds.ev[ev].prev;
-  r.node = gph_lds.ev[ev].node; r.nlin = gph_lds.ev[ev].nlin; r.type = gph_lds.ev[ev].type;
-#else
-  typedef uint32_t gph_u4 __attribute__((ext_vector_type(4)));
-  const gph_u4 w = *(const GPH_LDS gph_u4 *)&gph_lds.ev[ev];
+  const gph_w4 w = gph_ld16(&gph_lds.ev[ev]);
   union { double d; uint32_t u[2]; } t;
   t.u[0] = w.x; t.u[1] = w.y;
   const int w2 = RFL((int)w.z), w3 = RFL((int)w.w);
@@ -184,7 +165,6 @@ GPH_DEVHOT GphEvS ld_ev(int ev)
   r.node = (int)(int16_t)w3;
   r.nlin = (int)(int8_t)(w3 >> 16);
   r.type = (int)((uint32_t)w3 >> 24);
-#endif
   return r;
 }
 
@@ -228,60 +208,13 @@ GPH_DEV void gph_fail(int code) { if (CNT(CN_ERROR) == 0) setCNT(CN_ERROR, code)
 GPH_DEV int gph_failed() { return CNT(CN_ERROR) != 0; }
 GPH_DEV int gph_errcode() { return CNT(CN_ERROR); }
 
-GPH_DEV void load_scalars()
-{
-#ifdef GPH_HOSTEMU
-  for (int k = 0; k < IS_COUNT + CN_COUNT + SI_COUNT; k++) r_pad[k] = k < IS_COUNT ? gph_lds.iscal[k] : 0;
-#else
-  const int lane = GPH_LANE;
-  r_pad = lane < IS_COUNT ? gph_lds.iscal[lane] : 0;
-#endif
-}
-GPH_DEV void flush_scalars()
-{
-#ifdef GPH_HOSTEMU
-  for (int k = 0; k < IS_COUNT; k++) gph_lds.iscal[k] = r_pad[k];
-#else
-  const int lane = GPH_LANE;
-  if (lane < IS_COUNT) gph_lds.iscal[lane] = r_pad;
-#endif
-}
+GPH_DEV void load_scalars() { r_pad.load(gph_lds.iscal, IS_COUNT); }
+GPH_DEV void flush_scalars() { r_pad.store(gph_lds.iscal, IS_COUNT); }
 
-// IEEE-exact quotients a / theta[pop] and a / 3 without the ~12-instruction divide expansion: with
-// y = RN(1/b) (computed by a true division, on the host for theta), q0 = a*y, r = fma(-q0, b, a) (exact),
-// q = fma(r, y, q0) is the correctly rounded a/b (Markstein); tools/verify_fma_div*.c compare it with the
-// hardware division on 1.4e9 operands, all-ones significands of b included.  The host form divides.
-GPH_DEV double gph_div_theta(double a, int pop)
-{
-#ifdef GPH_HOSTEMU
-  return a / g_model.theta[pop];
-#else
-  const double b = g_model.theta[pop], y = g_model.thetaInv[pop];
-  const double q0 = a * y;
-  return __builtin_fma(__builtin_fma(-q0, b, a), y, q0);
-#endif
-}
-// same with the caller holding b = theta[pop] and y = thetaInv[pop] in registers
-GPH_DEV double gph_div_by(double a, double b, double y)
-{
-#ifdef GPH_HOSTEMU
-  (void)y;
-  return a / b;
-#else
-  const double q0 = a * y;
-  return __builtin_fma(__builtin_fma(-q0, b, a), y, q0);
-#endif
-}
-GPH_DEV double gph_div3(double a)
-{
-#ifdef GPH_HOSTEMU
-  return a / 3.0;
-#else
-  const double y = 1.0 / 3.0;
-  const double q0 = a * y;
-  return __builtin_fma(__builtin_fma(-q0, 3.0, a), y, q0);
-#endif
-}
+// exact quotients a / theta[pop], a / b with y = 1/b at hand, a / 3 (gph_quot, gph_rt.h)
+GPH_DEV double gph_div_theta(double a, int pop) { return gph_quot(a, g_model.theta[pop], g_model.thetaInv[pop]); }
+GPH_DEV double gph_div_by(double a, double b, double y) { return gph_quot(a, b, y); }
+GPH_DEV double gph_div3(double a) { return gph_quot(a, 3.0, 1.0 / 3.0); }
 
 // ---------------------------------------------------------------- RNG
 // rndu, utils.c:498-513: unsigned 32-bit Wichmann-Hill without the sign fix-up
@@ -408,12 +341,8 @@ GPH_DEV void lik_reset_saved()
   setISC(IS_NCHANGEDC, 0);
   setISC(IS_SV_ROOT, -1);
   setFS(FS_SV_DATALNL, FS(FS_DATALNL));
-#ifdef GPH_HOSTEMU
-  for (i = 0; i < g_lay.N; i++) setDIRTY(i, 0);
-#else
   (void)i;
-  if (GPH_LANE < g_lay.N) gph_lds.dirty[GPH_LANE] = 0;   /* one lane per node */
-#endif
+  GPH_EACH1(k, g_lay.N) gph_lds.dirty[k] = 0;   /* one lane per node */
 }
 // revertToSaved, LocusDataLikelihood.c:768-841 (value semantics: a node's saved
 // record and its previous conditional array are restored)
@@ -547,14 +476,6 @@ GPH_DEV void prune_node(int node)
 }
 
 #ifndef GPH_HOSTEMU
-GPH_DEV double rdlane64(double v, int l)
-{
-  union { double d; int32_t i[2]; } u;
-  u.d = v;
-  u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
-  u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
-  return u.d;
-}
 GPH_DEV double bperm64(int byteaddr, double v)
 {
   union { double d; int32_t i[2]; } u;
@@ -569,8 +490,8 @@ GPH_DEV double bperm64(int byteaddr, double v)
 GPH_DEVHOT double ordered_sum64(double term, int P)
 {
   double s = 0.0;
-#define GPH_ADD8(b) s += rdlane64(term, (b) + 0); s += rdlane64(term, (b) + 1); s += rdlane64(term, (b) + 2); s += rdlane64(term, (b) + 3); \
-                    s += rdlane64(term, (b) + 4); s += rdlane64(term, (b) + 5); s += rdlane64(term, (b) + 6); s += rdlane64(term, (b) + 7);
+#define GPH_ADD8(b) s += gph_readlane64(term, (b) + 0); s += gph_readlane64(term, (b) + 1); s += gph_readlane64(term, (b) + 2); s += gph_readlane64(term, (b) + 3); \
+                    s += gph_readlane64(term, (b) + 4); s += gph_readlane64(term, (b) + 5); s += gph_readlane64(term, (b) + 6); s += gph_readlane64(term, (b) + 7);
   GPH_ADD8(0)
   if (P > 8) { GPH_ADD8(8)
   if (P > 16) { GPH_ADD8(16)
@@ -813,7 +734,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
         rmask &= rmask - 1;
         const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
         STAMP_BEGIN(7);
-        prune_node_r<gdbl *>(node, l, r, rdlane64(pe, l), rdlane64(pe, r), (int)((cbit >> node) & 1),
+        prune_node_r<gdbl *>(node, l, r, gph_readlane64(pe, l), gph_readlane64(pe, r), (int)((cbit >> node) & 1),
                              (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, cb);
         STAMP_END(7);
         todo &= ~bit;
@@ -844,7 +765,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
         r = __builtin_amdgcn_readlane(ri, node);
       }
       STAMP_BEGIN(7);
-      prune_node_q<gdbl *, gdbl2 *>(l, r, rdlane64(pe, l), rdlane64(pe, r), __builtin_amdgcn_readlane(coff, node),
+      prune_node_q<gdbl *, gdbl2 *>(l, r, gph_readlane64(pe, l), gph_readlane64(pe, r), __builtin_amdgcn_readlane(coff, node),
                                     __builtin_amdgcn_readlane(coff, l), __builtin_amdgcn_readlane(coff, r), P, lc, cb, prev,
                                     q0, q1, q2, q3);
       STAMP_END(7);
@@ -1056,7 +977,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
         const int node = __builtin_ctzll(rmask);
         rmask &= rmask - 1;
         const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
-        prune_node_r<DP>(node, l, r, rdlane64(pe, l), rdlane64(pe, r), 0, 0, 0, P, scr, q_leaf);
+        prune_node_r<DP>(node, l, r, gph_readlane64(pe, l), gph_readlane64(pe, r), 0, 0, 0, P, scr, q_leaf);
         todo &= ~((uint64_t)1 << node);
       }
     } else {
@@ -1064,7 +985,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
       const int node = __builtin_ctzll(pm ? pm : rmask);
       const uint64_t bit = (uint64_t)1 << node;
       const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
-      prune_node_q<DP, DP2>(l, r, rdlane64(pe, l), rdlane64(pe, r), (node - n) * P * 4, l >= n ? (l - n) * P * 4 : 0,
+      prune_node_q<DP, DP2>(l, r, gph_readlane64(pe, l), gph_readlane64(pe, r), (node - n) * P * 4, l >= n ? (l - n) * P * 4 : 0,
                             r >= n ? (r - n) * P * 4 : 0, P, lane < P ? lane : P - 1, scr, prev, q0, q1, q2, q3, q_leaf);
       todo &= ~bit;
       prev = node;
@@ -1601,32 +1522,14 @@ GPH_DEV void delta_clear(int inst)
 GPH_DEV void accept_event_chain_changes(int inst)
 {
   int i, pop, b, ue, oe, dlin = DI(inst, DI_DLIN);
-#ifdef GPH_HOSTEMU
-  for (i = 0; i < DI(inst, DI_NPOPS); i++) {
-    pop = DPOPS(inst, i);
-    setCOALS(pop, COALS(pop) + DCOAL(inst, i));
-  }
-  for (i = 0; i < DI(inst, DI_NBANDS); i++) {
-    b = DBANDS(inst, i);
-    setMIGST(b, MIGST(b) + DMIG(inst, i));
-  }
+  /* the listed populations / bands / events are distinct: one lane per list entry */
+  (void)pop; (void)b;
+  GPH_EACH1(k, DI(inst, DI_NPOPS)) { const int q = gph_lds.s_dpops[inst][k]; gph_lds.coal[q] = gph_lds.coal[q] + gph_lds.s_dcoal[inst][k]; }
+  GPH_EACH1(k, DI(inst, DI_NBANDS)) { const int q = gph_lds.s_dbands[inst][k]; gph_lds.migst[q] = gph_lds.migst[q] + gph_lds.s_dmig[inst][k]; }
   oe = DI(inst, DI_ORIG);
   i = DI(inst, DI_NEV) - 1;
   if (i >= 0 && DEV(inst, i) == oe) i--;
-  for (; i >= 0; i--) setENLIN(DEV(inst, i), ENLIN(DEV(inst, i)) + dlin);
-#else
-  /* the listed populations / bands / events are distinct: one lane per list entry */
-  (void)pop; (void)b;
-  {
-    const int lane = GPH_LANE;
-    if (lane < DI(inst, DI_NPOPS)) { const int q = gph_lds.s_dpops[inst][lane]; gph_lds.coal[q] = gph_lds.coal[q] + gph_lds.s_dcoal[inst][lane]; }
-    if (lane < DI(inst, DI_NBANDS)) { const int q = gph_lds.s_dbands[inst][lane]; gph_lds.migst[q] = gph_lds.migst[q] + gph_lds.s_dmig[inst][lane]; }
-    oe = DI(inst, DI_ORIG);
-    i = DI(inst, DI_NEV) - 1;
-    if (i >= 0 && DEV(inst, i) == oe) i--;
-    for (int k = lane; k <= i; k += GPH_NLANES) { const int q = gph_lds.s_dev[inst][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + dlin); }
-  }
-#endif
+  GPH_EACH(k, i + 1) { const int q = gph_lds.s_dev[inst][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + dlin); }
   ue = DI(inst, DI_UPD);
   if (ue >= 0) {
     setENODE(ue, ENODE(oe));
@@ -1794,16 +1697,9 @@ GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
   }
   setDI(inst, DI_NPOPS, g_lay.K);
   setDI(inst, DI_NBANDS, g_lay.B);
-#ifdef GPH_HOSTEMU
-  for (i = 0; i < g_lay.K; i++) { setDPOPS(inst, i, i); setDCOAL(inst, i, 0.0); }
-  for (i = 0; i < g_lay.B; i++) { setDBANDS(inst, i, i); setDMIG(inst, i, 0.0); }
-#else
-  {   /* one lane per population / band */
-    const int lane = GPH_LANE;
-    if (lane < g_lay.K) { gph_lds.s_dpops[inst][lane] = (int16_t)lane; gph_lds.s_dcoal[inst][lane] = 0.0; }
-    if (lane < g_lay.B) { gph_lds.s_dbands[inst][lane] = (int16_t)lane; gph_lds.s_dmig[inst][lane] = 0.0; }
-  }
-#endif
+  /* one lane per population / band */
+  GPH_EACH1(k, g_lay.K) { gph_lds.s_dpops[inst][k] = (int16_t)k; gph_lds.s_dcoal[inst][k] = 0.0; }
+  GPH_EACH1(k, g_lay.B) { gph_lds.s_dbands[inst][k] = (int16_t)k; gph_lds.s_dmig[inst][k] = 0.0; }
   mig_rate = 0.0;
   for (b = 0; b < g_lay.B; b++) {
     if (g_model.bandTgt[b] == pop && g_model.bandStart[b] < age && g_model.bandEnd[b] > age) {

@@ -99,6 +99,141 @@ __device__ inline double gph_rfl64(double x)
 // VGPR and read back (v_cndmask + v_readfirstlane + s_bitcmp)
 #define UNI(c) (__builtin_amdgcn_ballot_w64((bool)(c)) != 0)
 #endif
+// ---- the lane primitives the per-locus code is written in, ONE form for both builds (the host build has one lane)
+// GPH_EACH(k, n): items 0..n-1 dealt round-robin to the lanes, any n.  GPH_EACH1(k, n): n <= 64, item k on lane k
+// (no loop on the device).  Items must be independent: the host runs them one after the other.
+#define GPH_EACH(k, n) for (int k = GPH_LANE; k < (n); k += GPH_NLANES)
+#ifdef GPH_HOSTEMU
+#define GPH_EACH1(k, n) for (int k = 0; k < (n); k++)
+#else
+#define GPH_EACH1(k, n) if (const int k = GPH_LANE; k < (n))
+#endif
+// the value lane `i` holds of a per-lane variable (the host's single lane holds item i when it asks for it)
+#ifdef GPH_HOSTEMU
+#define GPH_LANEVAL32(v, i) (v)
+#define GPH_LANEVAL64(v, i) (v)
+#else
+__device__ inline double gph_readlane64(double v, int l)
+{
+  union { double d; int32_t i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+  return u.d;
+}
+#define GPH_LANEVAL32(v, i) __builtin_amdgcn_readlane((int)(v), (i))
+#define GPH_LANEVAL64(v, i) gph_readlane64((v), (i))
+#endif
+// a 16-byte record (GphNode, GphEv) of the LDS image with one access (ds_read_b128)
+struct gph_w4 { uint32_t x, y, z, w; };
+template <class T> GPH_DEVHOT gph_w4 gph_ld16(const T *p)   /* p points into the LDS image */
+{
+  static_assert(sizeof(T) == 16, "16-byte records only");
+  gph_w4 r;
+#ifdef GPH_HOSTEMU
+  memcpy(&r, p, 16);
+#else
+  typedef uint32_t gph_u4 __attribute__((ext_vector_type(4)));
+  const gph_u4 w = *(const GPH_LDS gph_u4 *)p;
+  r.x = w.x; r.y = w.y; r.z = w.z; r.w = w.w;
+#endif
+  return r;
+}
+// coalesced 16-byte copies between HBM and the LDS image, lanes = consecutive 16-byte words
+#define GPH_LDSP(p) ((GPH_LDS void *)(p))      /* the address of a member of the static LDS image, as an LDS pointer */
+#ifdef GPH_HOSTEMU
+GPH_DEV void gph_copy16_in(void *lds, const void *glb, int n16) { memcpy(lds, glb, (size_t)n16 << 4); }
+GPH_DEV void gph_copy16_out(void *glb, const void *lds, int n16) { memcpy(glb, lds, (size_t)n16 << 4); }
+#else
+typedef uint32_t gph_u32x4 __attribute__((ext_vector_type(4)));
+GPH_DEV void gph_copy16_in(GPH_LDS void *lds, const void *glb, int n16)
+{
+  GPH_EACH(i, n16) ((GPH_LDS gph_u32x4 *)lds)[i] = ((const gph_u32x4 *)glb)[i];
+}
+GPH_DEV void gph_copy16_out(void *glb, const GPH_LDS void *lds, int n16)
+{
+  GPH_EACH(i, n16) ((gph_u32x4 *)glb)[i] = ((const GPH_LDS gph_u32x4 *)lds)[i];
+}
+#endif
+// n16 <= 64: one word per lane, no loop
+#ifdef GPH_HOSTEMU
+GPH_DEV void gph_copy16_in1(void *lds, const void *glb, int n16) { memcpy(lds, glb, (size_t)n16 << 4); }
+#else
+GPH_DEV void gph_copy16_in1(GPH_LDS void *lds, const void *glb, int n16)
+{
+  GPH_EACH1(i, n16) ((GPH_LDS gph_u32x4 *)lds)[i] = ((const gph_u32x4 *)glb)[i];
+}
+#endif
+// two such copies with every load of the first ACH / BCH kilobytes ISSUED before the first one is waited for (a
+// copy loop -- load 1 KB, wait, write LDS, repeat -- serialises one memory round trip per kilobyte at the head of a
+// wavefront); what lies beyond BCH KB of the second block (pattern-rich loci) follows in a loop
+#ifdef GPH_HOSTEMU
+template <int ACH, int BCH> GPH_DEV void gph_copy16_in2(void *la, const void *ga, int na, void *lb, const void *gb, int nb)
+{
+  memcpy(la, ga, (size_t)na << 4);
+  memcpy(lb, gb, (size_t)nb << 4);
+}
+#else
+template <int ACH, int BCH> GPH_DEV void gph_copy16_in2(GPH_LDS void *la, const void *ga, int na, GPH_LDS void *lb, const void *gb, int nb)
+{
+  const int lane = GPH_LANE;
+  const gph_u32x4 *ps = (const gph_u32x4 *)ga, *ss = (const gph_u32x4 *)gb;
+  gph_u32x4 pr[ACH], sr[BCH];
+#pragma unroll
+  for (int k = 0; k < ACH; k++) if (lane + 64 * k < na) pr[k] = ps[lane + 64 * k];
+#pragma unroll
+  for (int k = 0; k < BCH; k++) if (lane + 64 * k < nb) sr[k] = ss[lane + 64 * k];
+  GPH_LDS gph_u32x4 *pd = (GPH_LDS gph_u32x4 *)la, *sd = (GPH_LDS gph_u32x4 *)lb;
+#pragma unroll
+  for (int k = 0; k < ACH; k++) if (lane + 64 * k < na) pd[lane + 64 * k] = pr[k];
+#pragma unroll
+  for (int k = 0; k < BCH; k++) if (lane + 64 * k < nb) sd[lane + 64 * k] = sr[k];
+  for (int i = lane + 64 * BCH; i < nb; i += GPH_NLANES) sd[i] = ss[i];
+}
+#endif
+// the wave-uniform integer scalars of a locus: lane i of ONE vector register holds scalar i (a read is a v_readlane
+// with a constant lane, a write a v_writelane); the host keeps an array
+#ifdef GPH_HOSTEMU
+template <int NN> struct GphPad {
+  int32_t v[NN] = {};
+  int get(int i) const { return v[i]; }
+  void set(int i, int x) { v[i] = x; }
+  void load(const int32_t *src, int n) { for (int k = 0; k < NN; k++) v[k] = k < n ? src[k] : 0; }
+  void store(int32_t *dst, int n) const { for (int k = 0; k < n; k++) dst[k] = v[k]; }
+};
+#define GPH_PADGET(i) (r_pad.get(i))
+#define GPH_PADSET(i, x) (r_pad.set((i), (x)))
+#else
+template <int NN> struct GphPad {
+  static_assert(NN <= 64, "one scalar per lane");
+  int32_t v = 0;
+  __device__ inline void load(const int32_t *src, int n) { const int lane = GPH_LANE; v = lane < n ? ((const GPH_LDS int32_t *)src)[lane] : 0; }
+  __device__ inline void store(int32_t *dst, int n) const { const int lane = GPH_LANE; if (lane < n) ((GPH_LDS int32_t *)dst)[lane] = v; }
+};
+#define GPH_PADGET(i) __builtin_amdgcn_readlane(r_pad.v, (i))
+#define GPH_PADSET(i, x) do { const int pv_ = RFL(x); asm("v_writelane_b32 %0, %1, %2" : "+v"(r_pad.v) : "s"(pv_), "i"(i)); } while (0)
+#endif
+// a / b given y = RN(1/b).  Device: q0 = a*y, r = fma(-q0, b, a) (exact), q = fma(r, y, q0) is the correctly rounded
+// quotient (Markstein) without the ~12-instruction divide expansion; tools/verify_fma_div*.c compare it with the
+// hardware division on 1.4e9 operands, all-ones significands of b included.  The host divides -- which also makes
+// every golden-trace test of the host build a check of that equivalence.
+GPH_DEV double gph_quot(double a, double b, double y)
+{
+#ifdef GPH_HOSTEMU
+  (void)y;
+  return a / b;
+#else
+  const double q0 = a * y;
+  return __builtin_fma(__builtin_fma(-q0, b, a), y, q0);
+#endif
+}
+// first error of a locus into the launch's error word
+#ifdef GPH_HOSTEMU
+GPH_DEV void gph_raise(int *err, int code) { if (*err == 0) *err = code; }
+#else
+GPH_DEV void gph_raise(int *err, int code) { atomicMax(err, code); }
+#endif
+
 typedef GPH_LDS double lf64;
 typedef GPH_LDS int16_t li16;
 typedef GPH_LDS int32_t li32;

@@ -77,6 +77,7 @@ timeout 900 $REF main -n 1 w2.ctl w2b.ctl > w2.stdout 2>/dev/null
 
 # x8: the engine's hard caps -- 32 leaves, 31 populations (16 current), 16 migration bands (library variant `x`)
 gen x8 8 10 300 24 8 --mig-beta 0.00000004
+timeout 900 $REF main -n 1 x8.ctl >/dev/null 2>&1     # x8.trace: the reference's own trace file at the caps
 
 # kernel-level fixtures: single calls of the reference's per-locus functions after N iterations
 for c in "m4 60" "a7 40" "g2 20"; do set -- $c; timeout 300 $REF unit $1.ctl $2 $1.unit >/dev/null 2>&1; done

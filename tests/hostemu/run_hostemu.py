@@ -16,17 +16,18 @@ HOSTEMU = os.path.join(REPO, "tests", "hostemu", "libgphocs_hostemu.so")
 def build_hostemu(sanitize=False):
     csrc = os.path.join(REPO, "g-phocs_amd", "csrc")
     srcs = [os.path.join(csrc, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp", "gph_readtrace.cpp", "gph_comm.cpp")]
-    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
-    if os.path.exists(HOSTEMU) and all(os.path.getmtime(HOSTEMU) >= os.path.getmtime(d) for d in deps):
-        return HOSTEMU
+    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.abspath(__file__)]
+    out = HOSTEMU.replace(".so", "_san.so") if sanitize else HOSTEMU
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
     # the engine's hard caps (library variant `x`): every golden fits, the image size does not matter on the host
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU", "-DGPH_CAP_LEAVES=32", "-DGPH_CAP_K=32", "-DGPH_CAP_B=16",
            "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
-           "-x", "c++"] + srcs + ["-lrt", "-o", HOSTEMU]
+           "-x", "c++"] + srcs + ["-lrt", "-o", out]
     if sanitize:
-        cmd[1:1] = ["-fsanitize=address,undefined"]
+        cmd[1:1] = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
     subprocess.run(cmd, check=True)
-    return HOSTEMU
+    return out
 
 
 def run(pack_path, iters, trace, state=None, state_iter=None, with_cond=True, lib=None):

@@ -322,7 +322,7 @@ def test_native_library_is_the_path(G):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8"])
 def test_program_trace_file(name, tmp_path):
     """G-PhoCS-hip <control-file> on the MI355X: the trace file of the real G-PhoCS binary for the same
     control + sequence files (tests/golden/*.trace), to the printed precision (%8.5f / %.6f)."""

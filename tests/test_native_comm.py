@@ -102,3 +102,24 @@ def test_sampler_over_native_shm_comm(hostemu, tmp_path, name, iters):
     golden = open(os.path.join(GOLDEN, name + ".rtrace")).read().splitlines()[:len(mine)]
     (tmp_path / "g").write_text("\n".join(golden) + "\n")
     compare_records(out + ".0", str(tmp_path / "g"))
+
+
+@pytest.mark.parametrize("name,ranks", [("m3", 1), ("a7", 2), ("v8", 1), ("x8", 1)])
+def test_engine_sources_under_asan_ubsan(hostemu, tmp_path, name, ranks):
+    """the engine sources (host build) under AddressSanitizer + UndefinedBehaviorSanitizer, whole program through the
+    launcher: no report (either aborts the run) and the reference's trace file.  The GPU pool offers no sanitizer, so
+    this is where out-of-bounds indices into the locus image, the chain state and the reduced rows would show."""
+    import run_hostemu
+    san = run_hostemu.build_hostemu(sanitize=True)
+    rt = [subprocess.run(["gcc", "-print-file-name=" + n], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(p) and os.path.exists(p) for p in rt):
+        pytest.skip("sanitizer runtimes are not installed")
+    exe = os.path.join(REPO, "g-phocs_amd", "G-PhoCS-hip")
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    env = dict(os.environ, GPHOCS_HIP_LIB=san, LD_PRELOAD=":".join(rt), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    args = [exe] + (["-g", str(ranks)] if ranks > 1 else []) + [name + ".ctl"]
+    r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    _same_trace(os.path.join(GOLDEN, name + ".trace"), os.path.join(tmp_path, name + ".trace"))
