@@ -30,9 +30,11 @@ CSRC = os.path.join(_HERE, "csrc")
 # rewrites multi-exit loops and unstructured merges with guard flags (lane masks carried through phis) and pays for
 # the extra merges with register copies in the loop bodies; leaving uniform regions as the plain scalar-branch CFG
 # they are: -5 % sweep time, -7..18 % static instructions per kernel.
+# -amdgpu-sched-strategy=max-ilp: the sweep kernel is issue-bound at a fixed occupancy (launch bounds), so the
+# scheduler has nothing to gain from trading latency hiding for registers: -0.7 %.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-result", "-pthread", "-mllvm", "-disable-machine-licm",
-               "-mllvm", "-structurizecfg-skip-uniform-regions", "-ldl", "-lrt"]
+               "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-ldl", "-lrt"]
 
 # Capacity variants of the same library (same C ABI, same sources): the static LDS image of a locus is
 # sized by compile-time capacities (csrc/gph_types.h), and a tighter image means more resident

@@ -227,9 +227,11 @@ GPH_DEV double l_rndu(GphRng &g)
 {
   uint32_t x = g.x, y = g.y, z = g.z;
   double r;
-  x = 171u * (x % 177u) - 2u * (x / 177u);
-  y = 172u * (y % 176u) - 35u * (y / 176u);
-  z = 170u * (z % 178u) - 63u * (z / 178u);
+  /* 171 * (x % 177) - 2 * (x / 177) = 171 * x - (171 * 177 + 2) * (x / 177) in arithmetic modulo 2^32 (which is what
+   * the unsigned expression is): one quotient, two products and a difference per component */
+  x = 171u * x - 30269u * (x / 177u);
+  y = 172u * y - 30307u * (y / 176u);
+  z = 170u * z - 30323u * (z / 178u);
   g.x = x;
   g.y = y;
   g.z = z;
@@ -249,6 +251,9 @@ GPH_DEV double l_rndu(GphRng &g)
     q = zd * rz; double qz = __builtin_fma(__builtin_fma(-q, mz, zd), rz, q);
     r = qx + qy + qz;
   }
+  /* r - (int)r for 0 <= r < 2^19: both the subtraction and v_fract_f64's r - floor(r) are exact, i.e. the same value
+   * (one instruction instead of convert, convert back, subtract) */
+  return __builtin_amdgcn_fract(r);
 #endif
   r = (r - (int)r);
   return r;
@@ -486,7 +491,9 @@ GPH_DEV double bperm64(int byteaddr, double v)
 }
 // sum of term[0..P-1] in lane order, P <= 64 (lanes >= P and lanes without a term hold +0.0: x + 0.0 == x bit for
 // bit, and the running sum is never -0.0): two lane reads with a constant lane + one add per pattern, no mask
-// bookkeeping, an exit test every eight patterns
+// bookkeeping, an exit test every eight patterns.  (Measured alternative: every lane fetching term[k] through the LDS
+// crossbar -- ds_bpermute with the lane in the offset field, one add per pattern, a third of the vector instructions
+// -- is 2 % SLOWER: the permutes' round trip sits on the evaluation's critical path.)
 GPH_DEVHOT double ordered_sum64(double term, int P)
 {
   double s = 0.0;
