@@ -200,7 +200,7 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate, int
 
 // ---------------------------------------------------------------- genealogy sweeps
 // UpdateGB_InternalNode per-locus body, GPhoCS.c:2299-2425
-GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune, GphRng &rng)
+template <class RNG> GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune, RNG &rng)
 {
   int pop, inode, i, son, mig, acc = 0;
   double t, tnew, lnacc, lnLd, dgen, tb0, tb1;
@@ -252,7 +252,7 @@ GPH_DEV void sweep_internal(const GphDev &D, int g, double finetune, GphRng &rng
 }
 
 // UpdateGB_MigrationNode per-locus body, GPhoCS.c:2453-2587
-GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune, GphRng &rng)
+template <class RNG> GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune, RNG &rng)
 {
   int mi, mignode, pop_s, pop_t, ev_s, ev_t, below, mig_below, mig_above, father, acc = 0, totmigs = 0;
   double t, tnew, tb0, tb1, dgen, lnacc, dLog = 0;
@@ -302,7 +302,7 @@ GPH_DEV void sweep_mignodes(const GphDev &D, int g, double finetune, GphRng &rng
 }
 
 // UpdateGB_MigSPR per-locus body, GPhoCS.c:2610-2944 (no admixture)
-GPH_DEV void sweep_spr(const GphDev &D, int g, GphRng &rng)
+template <class RNG> GPH_DEV void sweep_spr(const GphDev &D, int g, RNG &rng)
 {
   int node, res, father, father_pop_old, sibling, b, i, mig, ev, target, pop, acc = 0, fpn, fen;
   double lnLd, lnacc, t_new;
@@ -376,7 +376,7 @@ GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double f
 {
   STAMP_BEGIN(0);
   stage_in(D, g, D.pages, 1);
-  GphRng rng;
+  GphRngB rng;       /* uniforms in batches of 64: gph_locus.h */
   rng_load(rng);
   /* flag 8: synchronizeEvents of the previous iteration (patch.c:3548), deferred into this kernel */
   OUT(g, 15, (flags & 8) ? (double)synchronize_events() : 1.0);

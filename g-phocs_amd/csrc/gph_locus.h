@@ -258,8 +258,74 @@ GPH_DEV double l_rndu(GphRng &g)
   r = (r - (int)r);
   return r;
 }
+// ---- the sweep kernel's generator: the SAME stream, 64 draws at a time.  The integer recurrences stay serial (scalar
+// unit, one lane of three registers written per step); the expensive part of a draw -- three exact quotients, two sums and
+// the fractional part, 15 fp64 vector instructions that used to run for ONE useful lane -- runs once per batch with a draw in
+// every lane.  Handing a draw out is two lane reads.  The state written back to the page is the one after the last draw
+// handed out (lane pos-1 of the batch), so a kernel leaves the generator exactly where the serial code leaves it.
+#ifdef GPH_HOSTEMU
+typedef GphRng GphRngB;
+#else
+struct GphRngB {
+  uint32_t x, y, z;      // state after the last draw of the batch (uniform)
+  int pos;               // draws of the batch handed out; GPH_WAVE = none left
+  uint32_t rx, ry, rz;   // per lane: state after draw `lane` of the batch
+  double u;              // per lane: draw `lane` of the batch
+};
+GPH_DEV void rng_load(GphRngB &g)
+{
+  g.x = (uint32_t)ISC(IS_RX); g.y = (uint32_t)ISC(IS_RY); g.z = (uint32_t)ISC(IS_RZ);
+  g.pos = GPH_WAVE; g.rx = g.ry = g.rz = 0; g.u = 0.0;
+}
+GPH_DEV void rng_store(const GphRngB &g)
+{
+  uint32_t x = g.x, y = g.y, z = g.z;
+  if (g.pos < GPH_WAVE) {
+    const int l = g.pos - 1;    /* a batch is only made when a draw is wanted: pos >= 1 */
+    x = (uint32_t)__builtin_amdgcn_readlane((int)g.rx, l);
+    y = (uint32_t)__builtin_amdgcn_readlane((int)g.ry, l);
+    z = (uint32_t)__builtin_amdgcn_readlane((int)g.rz, l);
+  }
+  setISC(IS_RX, (int)x); setISC(IS_RY, (int)y); setISC(IS_RZ, (int)z);
+}
+GPH_DEV void rng_refill(GphRngB &g)
+{
+  uint32_t x = g.x, y = g.y, z = g.z;
+  int vx = 0, vy = 0, vz = 0;
+#pragma unroll 4
+  for (int k = 0; k < GPH_WAVE; k++) {
+    x = 171u * x - 30269u * (x / 177u);
+    y = 172u * y - 30307u * (y / 176u);
+    z = 170u * z - 30323u * (z / 178u);
+    /* lane select through M0: a VOP3 instruction reads one scalar register besides it (constant-bus limit) */
+    asm("s_mov_b32 m0, %6\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+        : "+v"(vx), "+v"(vy), "+v"(vz) : "s"(x), "s"(y), "s"(z), "s"(k) : "m0");
+  }
+  g.x = x; g.y = y; g.z = z;
+  g.rx = (uint32_t)vx; g.ry = (uint32_t)vy; g.rz = (uint32_t)vz;
+#if defined(__HIP_DEVICE_COMPILE__)       /* (the host pass of hipcc only parses this) */
+  {
+    const gph_cdbl *RC = GPH_RNGC;
+    const double rx = RC[0], ry = RC[1], rz = RC[2], mx = RC[3], my = RC[4], mz = RC[5];
+    double xd = (double)(uint32_t)vx, yd = (double)(uint32_t)vy, zd = (double)(uint32_t)vz, q;
+    q = xd * rx; double qx = __builtin_fma(__builtin_fma(-q, mx, xd), rx, q);
+    q = yd * ry; double qy = __builtin_fma(__builtin_fma(-q, my, yd), ry, q);
+    q = zd * rz; double qz = __builtin_fma(__builtin_fma(-q, mz, zd), rz, q);
+    g.u = __builtin_amdgcn_fract(qx + qy + qz);
+  }
+#endif
+  g.pos = 0;
+}
+GPH_DEV double l_rndu(GphRngB &g)
+{
+  if (g.pos >= GPH_WAVE) rng_refill(g);
+  const double u = gph_readlane64(g.u, g.pos);
+  g.pos++;
+  return u;
+}
+#endif
 // rndnormal, utils.c:459-472
-GPH_DEV double l_rndnormal(GphRng &g)
+template <class RNG> GPH_DEV double l_rndnormal(RNG &g)
 {
   double u, v, s;
   int guard = 0;
@@ -274,7 +340,7 @@ GPH_DEV double l_rndnormal(GphRng &g)
   return u * s;
 }
 // rnd2normal8, utils.c:482-488 (kernel constants utils.c:427-431)
-GPH_DEV double l_rnd2normal8(GphRng &g)
+template <class RNG> GPH_DEV double l_rnd2normal8(RNG &g)
 {
   const double m2s2 = 8.;
   double m2N = sqrt(m2s2 / (m2s2 + 1.));
@@ -1674,8 +1740,8 @@ GPH_DEV double rubber_band_ripple(int do_or_redo)
 // ---------------------------------------------------------------- traceLineage
 // traceLineage, patch.c:886-1331.  RECONNECT == 0: walk the existing edge above
 // `node`, removing one lineage; RECONNECT == 1: re-sample its path from the prior
-template <int RECONNECT>
-GPH_DEVHOT int trace_lineage(int node, GphRng &rng)
+template <int RECONNECT, class RNG>
+GPH_DEVHOT int trace_lineage(int node, RNG &rng)
 {
   const int inst = RECONNECT;
   node = RFL(node);
