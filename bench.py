@@ -239,6 +239,7 @@ def main():
     dist = None
     allreduce = None
     comm = None
+    comm_fallback = False
     ncoll = [0]
     force_dist = os.environ.get("GPH_BENCH_FORCE_DIST") == "1"   # exercise the collective path on one GPU
     L_total = a.loci * world if a.weak else a.loci
@@ -257,14 +258,25 @@ def main():
             if rank == 0:
                 import ctypes
                 raw = (ctypes.c_uint8 * 128)()
-                assert lib.gph_comm_unique_id(raw) == 0
-                idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
+                if lib.gph_comm_unique_id(raw) == 0:
+                    idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
             dist.broadcast(idbuf, 0)
             idbytes = bytes(idbuf.cpu().tolist())
-            comm = lib.gph_comm_create_rccl(idbytes, rank, world, local_rank)
-            assert comm, "gph_comm_create_rccl failed"
-        else:
-            # <= 512-byte payloads through torch.distributed: every rank all-gathers the (sums | mins) vector and
+            if any(idbytes):
+                comm = lib.gph_comm_create_rccl(idbytes, rank, world, local_rank)
+            # every rank must end up on the same exchange: if ANY rank could not join, all fall back to the hook
+            ok = torch.tensor([1 if comm else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm:
+                    lib.gph_comm_destroy(comm)
+                comm = None
+                comm_fallback = True
+                if rank == 0:
+                    print("bench: the engine's RCCL communicator could not be created on every rank -- "
+                          "falling back to the torch.distributed hook", file=sys.stderr)
+        if comm is None:
+            # <= 1.5-KB payloads through torch.distributed: every rank all-gathers the (sums | mins) vector and
             # reduces the `world` rows itself in rank order
             SLOTS = 192
             hbuf = torch.zeros(SLOTS, dtype=torch.float64).pin_memory()
@@ -390,7 +402,7 @@ def main():
                        "kernel_launches_per_iteration": (hs1["launches"] - hs0["launches"]) / a.steps,
                        "parallelism": f"loci sharded over {world} rank(s), one process per GPU"
                                       + (f", native RCCL all-gather of the reduced row on the engine's stream" if comm else
-                                         (", torch.distributed hook" if dist else ""))},
+                                         (", torch.distributed hook" + (" (fallback: the RCCL communicator could not be created)" if comm_fallback else "") if dist else ""))},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (fused UpdateGB_InternalNode+MigrationNode+MigSPR)",
                          "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "accounting": "ALGORITHMIC bytes per evaluation (96 R P + 20 N + 8 U + 8, SURVEY 8d) / HIP-event "
