@@ -724,6 +724,9 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
 {
   const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
   useOld = RFL(useOld);
+#ifdef GPH_EXP_WARM
+  warm = true;
+#endif
   const int P = CNT(CN_P);
   if (P == 0) return 0.0;
   const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n);
