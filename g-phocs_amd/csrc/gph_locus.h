@@ -724,9 +724,6 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
 {
   const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
   useOld = RFL(useOld);
-#ifdef GPH_EXP_WARM
-  warm = true;
-#endif
   const int P = CNT(CN_P);
   if (P == 0) return 0.0;
   const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n);
@@ -781,7 +778,9 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   /* conditionals written by an earlier evaluation of this wave must have landed before they are re-read */
   GPH_WAVE_FENCE();
   if (warm && !wide) {
-    /* a kernel that evaluates ONE proposal per locus finds the conditionals it reads (the children of recomputed
+    /* (only kernels that evaluate ONE proposal per locus ask for this; in the sweep kernel, whose conditionals are
+     * warm in L2, the same prefetch costs 4 % -- measured)
+     * a kernel that evaluates ONE proposal per locus finds the conditionals it reads (the children of recomputed
      * nodes that are not recomputed themselves) cold in HBM, one dependent miss per node of the path.  Touch
      * them all with a single load first -- 8 lanes per array, one 128-byte line each -- so the misses overlap. */
     uint64_t sm = __ballot(isnode && lane >= n && !((todo >> lane) & 1) && fal >= 0 && ((todo >> fal) & 1));
