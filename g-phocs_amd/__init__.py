@@ -65,7 +65,31 @@ def lib_path(name="m"):
 
 
 def build(verbose=False):
-    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU), every variant."""
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU), every variant.  Safe to call from
+    several processes at once (one rank per GPU all call it): an exclusive file lock serialises them, the first one
+    builds what is out of date into a temporary file and renames it, the others find everything up to date."""
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _run_to(cmd, out, verbose):
+    tmp = f"{out}.tmp.{os.getpid()}"
+    if verbose:
+        print(" ".join(cmd + ["-o", out]))
+    try:
+        subprocess.run(cmd + ["-o", tmp], check=True)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+
+
+def _build_locked(verbose):
     srcs = [os.path.join(CSRC, f) for f in LIB_SOURCES]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
         [os.path.join(REPO, "include", "gphocs_hip.h")]
@@ -73,25 +97,16 @@ def build(verbose=False):
         out = os.path.join(_HERE, fn)
         if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
             continue
-        cmd = ["hipcc"] + HIPCC_FLAGS + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}",
-                                         f"-DGPH_SWEEP_WAVES={waves}"] + srcs + ["-o", out]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+        _run_to(["hipcc"] + HIPCC_FLAGS + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}",
+                                           f"-DGPH_SWEEP_WAVES={waves}"] + srcs, out, verbose)
     # the program: same command line as the reference's G-PhoCS binary (GPhoCS.c:84-238)
     exe, main = os.path.join(_HERE, "G-PhoCS-hip"), os.path.join(CSRC, "gph_main.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(main), os.path.getmtime(deps[-1])):
-        cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(REPO, "include"), main, "-ldl", "-o", exe]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+        _run_to(["g++", "-O2", "-std=c++17", "-I", os.path.join(REPO, "include"), main, "-ldl"], exe, verbose)
     # the post-run trace summary tool (readTrace.c), host only
     exe, main = os.path.join(_HERE, "readTrace"), os.path.join(CSRC, "gph_readtrace.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(main), os.path.getmtime(deps[-1])):
-        cmd = ["g++", "-O2", "-std=c++17", "-DGPH_READTRACE_MAIN", main, "-o", exe]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+        _run_to(["g++", "-O2", "-std=c++17", "-DGPH_READTRACE_MAIN", main], exe, verbose)
     return LIB_PATH
 
 

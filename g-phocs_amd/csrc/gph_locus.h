@@ -297,7 +297,8 @@ GPH_DEV void rng_refill(GphRngB &g)
     x = 171u * x - 30269u * (x / 177u);
     y = 172u * y - 30307u * (y / 176u);
     z = 170u * z - 30323u * (z / 178u);
-    /* lane select through M0: a VOP3 instruction reads one scalar register besides it (constant-bus limit) */
+    /* lane select through M0: a VOP3 instruction reads one scalar register besides it (constant-bus limit).  Nothing
+     * else in this translation unit's code uses M0 (gfx9 DS instructions do not need it; checked in the ISA) */
     asm("s_mov_b32 m0, %6\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
         : "+v"(vx), "+v"(vy), "+v"(vz) : "s"(x), "s"(y), "s"(z), "s"(k) : "m0");
   }
