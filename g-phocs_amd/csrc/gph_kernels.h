@@ -27,9 +27,10 @@ struct GphDev {            // device pointers (passed by value to every kernel)
 
 #include "gph_locus.h"   // opens struct GphCtx; closed at the end of this file
 
-// Loci are stored sorted by their number of phased patterns and launched in buckets of
-// similar P, each bucket with an LDS allocation sized for ITS largest locus: the few
-// pattern-rich loci no longer dictate the occupancy of all the others.
+// Loci are stored sorted by decreasing number of phased patterns (the longest wavefronts start first).  ONE
+// dispatch covers every locus with at most one pattern per lane (P <= 64); the rare pattern-rich ones form a second
+// one with its own LDS allocation (per-pattern terms array, generic mapping).  More, finer P-buckets were measured
+// and dropped: every dispatch costs about one wavefront lifetime of tail.
 
 // ---------------------------------------------------------------- staging
 GPH_DEV void copy16_g2l(int lds_off, const char *src, int bytes) { gph_copy16_in(GPH_SMB + lds_off, src, bytes >> 4); }
