@@ -213,3 +213,21 @@ def test_other_configs_at_full_size(G, oracle_cli, tmp_path, idx):
     P = __import__("numpy").diff(pk.pattern_offsets)
     print(f"configs[{idx}]: {c['L']} loci x {c['n']} leaves, mean {P.mean():.1f} / max {P.max()} phased patterns, "
           f"{cnt['evals']} evaluations in 4 iterations; vs oracle worst rel diff {worst:.3e}; two ranks vs one {worst2:.3e}")
+
+
+def test_long_trajectory_keeps_the_reference_invariants(G):
+    """400 iterations of the benchmark workload (the chain well past its prior-sampled start: migration events, deeper
+    trees) with `checkAll` (patch.c:2745) every 40: every incremental statistic, log-likelihood and conditional array
+    of every locus against a from-scratch recomputation, ten times along the way; any per-locus error code (chain-walk
+    guards, event-pool exhaustion, the reflect guard) aborts an iteration with an error status.  tools/soak.py runs the
+    same for thousands of iterations."""
+    pk = _workload(G, 40)
+    s = G.Sampler(pk)
+    s.initialize()
+    for it in range(400):
+        s.iteration(it)
+    acc = s.accept_counts()
+    hs = s.host_stats()
+    s.close()
+    assert all(a > 0 for a in acc[:8]), acc
+    assert hs["resident"] and hs["syncs"] <= 400 + 64     # one per iteration, + initialisation and the checkAll passes
