@@ -1805,7 +1805,10 @@ GPH_DEVHOT int trace_lineage(int node, RNG &rng)
       bool through;
       /* ONE exit, at the bottom: the rare stops raise `status` and fall through to it.  (Measured alternatives: the
        * rare arrivals handled after the step instead of before it, or outside this loop altogether -- the second
-       * leaves a copy-free inner loop and pays for it at every exit and re-entry: +2 % sweep time.) */
+       * leaves a copy-free inner loop and pays for it at every exit and re-entry: +2 % sweep time.  Requesting the
+       * NEXT event's record while the current interval is worked on (software pipelining of the one LDS round trip
+       * per interval): +0.9 % -- the other wavefronts already cover that latency, the four extra loop-carried
+       * registers do not come free.) */
       do {
         through = false;
         if (nev >= GPH_CAP_E) { gph_fail(96); status = 3; }
