@@ -2,7 +2,11 @@
 """Benchmark of the hot path: full MCMC iterations of the per-locus likelihood engine.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+  ... bench.py --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or bare -- then this
+  process never touches a GPU: it starts the N rank processes itself (one per GPU, the engine's RCCL communicator
+  between them), waits, relays rank 0's ONE JSON line and exits non-zero if there are fewer than N devices or any
+  rank fails.  The reference's knob for the same thing is `-n threads` (GPhoCS.c:95, 116-145, MultiCoreUtils.h:8).
 
 step      = one MCMC iteration of performMCMC's proposal sequence (GPhoCS.c:1476-1821) over every
             locus: fused genealogy sweep (node ages, migration ages, SPR), theta, migration rates,
@@ -18,14 +22,16 @@ value     = locus-likelihood evaluations per second (computeLocusDataLikelihood(
             equivalents, counted by the kernels); MCMC iterations/s is reported next to it.
 roofline  = dominant kernel (fused genealogy sweep): algorithmic bytes (96*R*P + 20*N + 8*U + 8 per
             evaluation, counted per evaluation by the kernel) / HIP-event duration, vs 8 TB/s HBM.
-cpu_baseline = the oracle restatement (bit-identical to the reference on the golden vectors) timed
-            single-threaded on a bounded sample (first --cpu-loci loci, a few iterations) on this
-            box's host cores -- rank 0, N = 1 only.
+cpu_baseline = the REAL reference (oracle/_ref, OpenMP build) on the first --cpu-loci loci (default 20 000: a 0.7-GB
+            working set, beyond any L3) of the same data set, started ONCE and timed at 1 / 8 / 16 / 32 / all host
+            threads; the best is the value, with its thread count and the CPU model.  Secondary, labelled: the serial
+            build and the oracle restatement on 5 000 loci.  Rank 0, N = 1 only.
 """
 import argparse
 import json
 import multiprocessing as mp
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -121,36 +127,59 @@ def write_seq_sample(pack, nloci, path):
             f.write("\n")
 
 
-def cpu_baseline_reference(config, pack, nloci, iters):
-    """the REAL reference (oracle/_ref, compiled from its own sources in the build container) timed on a
-    bounded sample of the same workload: serial build on 1 core and its OpenMP build on all cores"""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_reference(config, pack, nloci, iters, small_loci, small_iters):
+    """the REAL reference (oracle/_ref, compiled from its own sources in the build container) timed on the host cores
+    of this box.  Primary: its OpenMP build on the first `nloci` loci of the workload (>= 20 000: the working set is
+    far beyond L3), ONE start-up, then `iters` iterations at every thread count of {1, 8, 16, 32, all cores}; the best
+    is the value.  Secondary: the serial build on `small_loci` loci (the earlier rounds' figure)."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import gen_synth
     ref = os.path.join(REPO, "oracle", "_ref", "gphocs_ref")
     ref_omp = os.path.join(REPO, "oracle", "_ref", "gphocs_ref_omp")
     if not os.path.exists(ref):
         return None
-    out = {}
+    ncores = os.cpu_count() or 1
+    out = {"unit": "evals/s", "kind": "reference", "cpu_model": cpu_model(), "host_cores": ncores}
     with tempfile.TemporaryDirectory() as td:
-        write_seq_sample(pack, nloci, os.path.join(td, "s.seq"))
-        gen_synth.write_ctl(os.path.join(td, "s.ctl"), gen_synth.CONFIGS[config], "s.seq", "s.trace", nloci, 12345,
+        if os.path.exists(ref_omp) and nloci > 0:
+            write_seq_sample(pack, nloci, os.path.join(td, "b.seq"))
+            gen_synth.write_ctl(os.path.join(td, "b.ctl"), gen_synth.CONFIGS[config], "b.seq", "b.trace", nloci, 12345,
+                                1000, 100000)
+            counts = sorted({t for t in (1, 8, 16, 32, ncores) if t <= ncores})
+            t0 = time.perf_counter()
+            r = subprocess.run([ref_omp, "timesweep", "b.ctl", str(iters), "1", ",".join(map(str, counts))], cwd=td,
+                               check=True, capture_output=True, text=True, timeout=1500)
+            rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+            by = {int(x["threads"]): x for x in rows if "threads" in x}
+            best = max(by.values(), key=lambda x: x["evals_per_s"])
+            out.update({"value": best["evals_per_s"], "cores": int(best["threads"]),
+                        "sample": f"first {nloci} loci of the workload (sequence file, {nloci * 0.035:.0f} MB of per-locus state) "
+                                  f"on the reference's OpenMP build: one start-up ({rows[0].get('startup_seconds', 0):.0f} s, untimed), "
+                                  f"then 1 warm-up + {iters} timed iterations at each of {counts} threads; best = "
+                                  f"{int(best['threads'])} threads ({best['seconds']:.1f} s); whole leg {time.perf_counter() - t0:.0f} s",
+                        "iters_per_s_at_sample": best["iters_per_s"],
+                        "by_threads": {str(t): {"value": x["evals_per_s"], "seconds": x["seconds"]} for t, x in sorted(by.items())}})
+        write_seq_sample(pack, small_loci, os.path.join(td, "s.seq"))
+        gen_synth.write_ctl(os.path.join(td, "s.ctl"), gen_synth.CONFIGS[config], "s.seq", "s.trace", small_loci, 12345,
                             1000, 100000)
-        r = json.loads(subprocess.run([ref, "time", "s.ctl", str(iters), "2"], cwd=td, check=True,
+        r = json.loads(subprocess.run([ref, "time", "s.ctl", str(small_iters), "2"], cwd=td, check=True,
                                       capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1])
-        out = {"value": r["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "reference",
-               "sample": f"first {nloci} loci of the workload written as a sequence file, {iters} iterations after "
-                         f"2 warm-up ({r['seconds']:.1f} s), serial reference build; "
-                         f"{r['iters_per_s'] * nloci:.0f} locus-iterations/s",
-               "iters_per_s_at_sample": r["iters_per_s"]}
-        if os.path.exists(ref_omp):
-            nc = min(os.cpu_count() or 1, 8)   # the reference scales ~3x on 8 threads and collapses beyond (atomics)
-            env = dict(os.environ, OMP_NUM_THREADS=str(nc))
-            try:
-                r2 = json.loads(subprocess.run([ref_omp, "time", "s.ctl", str(iters), "2"], cwd=td, check=True, env=env,
-                                               capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1])
-                out["openmp_8_threads"] = {"value": r2["evals_per_s"], "cores": nc, "seconds": r2["seconds"]}
-            except Exception as ex:  # pragma: no cover
-                out["openmp_8_threads"] = {"error": str(ex)}
+        small = {"value": r["evals_per_s"], "cores": 1, "kind": "reference",
+                 "sample": f"SECONDARY (not like for like: {small_loci * 0.035:.0f}-MB working set): first {small_loci} loci, "
+                           f"{small_iters} iterations after 2 warm-up ({r['seconds']:.1f} s), serial reference build"}
+        if "value" not in out:
+            out.update({"value": small["value"], "cores": 1, "sample": small["sample"]})
+        out["serial_small_sample"] = small
     return out
 
 
@@ -203,6 +232,71 @@ def build_shard(G, config, L_total, begin, end, mut_scale, seed0, cache_dir):
     return pk
 
 
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`bench.py --gpus N` with no launcher around it: this process starts the N ranks (one process per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment -- what torch.distributed.run would set), waits for them and
+    relays rank 0's JSON line.  It never initialises a GPU itself (counting devices does not)."""
+    n = a.gpus
+    if not a.host_emulation:
+        import torch
+        nd = torch.cuda.device_count()
+        if nd < n:
+            print(f"bench: --gpus {n} but this node shows {nd} HIP device(s)", file=sys.stderr)
+            return 2
+    import gphocs_amd as G
+    G.build()                                   # once, before the ranks race for the build lock
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    deadline = time.time() + a.launch_timeout
+    bad = None
+    while bad is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc is not None and rc != 0:
+                bad = (r, rc)
+        if time.time() > deadline:
+            bad = (-1, "timeout")
+        time.sleep(0.05)
+    if bad is None:
+        for r, p in enumerate(procs):
+            if p.returncode != 0:
+                bad = (r, p.returncode)
+    if bad is not None:
+        # a rank that failed leaves the others waiting in the next exchange: stop exactly the processes started here
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print(f"bench: rank {bad[0]} failed ({bad[1]}); the job was stopped", file=sys.stderr)
+        return 1
+    out = procs[0].stdout.read()
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if not lines:
+        print("bench: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    line = json.loads(lines[-1])
+    if line.get("n_gpus") != n:
+        print(f"bench: rank 0 reports n_gpus = {line.get('n_gpus')}, expected {n}", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,13 +310,23 @@ def main():
     ap.add_argument("--preroll", type=int, default=200, help="untimed iterations before the warm-up (SURVEY 8d: measure "
                     "after 200 iterations from the prior-sampled start)")
     ap.add_argument("--samples-per-log", type=int, default=0, help="checkAll period (0 = the pack's: 100)")
-    ap.add_argument("--cpu-loci", type=int, default=5000)
-    ap.add_argument("--cpu-iters", type=int, default=16)
+    ap.add_argument("--cpu-loci", type=int, default=20000, help="loci of the CPU baseline's data set (the first ones of the workload)")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-small-loci", type=int, default=5000, help="the secondary, cache-friendlier CPU sample")
+    ap.add_argument("--cpu-small-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lib", default=None, help="alternative build of the library (A/B measurements)")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "hook"], help="cross-rank exchange: native RCCL all-gather on "
-                    "the engine's stream (default) or the torch.distributed hook (a host round trip per reduction)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "hook", "shm"], help="cross-rank exchange: native RCCL all-gather on "
+                    "the engine's stream (default), the torch.distributed hook (a host round trip per reduction), or the "
+                    "host shared-memory exchange (ranks that share a device)")
+    ap.add_argument("--host-emulation", action="store_true", help="TESTS ONLY: the host build of the engine sources "
+                    "(tests/hostemu), gloo, shared-memory exchange -- exercises this script's N-rank path without a GPU; "
+                    "the line is not a measurement")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0)
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
 
     # stdout carries exactly ONE line (the JSON): anything native libraries print there (RCCL's version banner,
     # the HIP runtime) is sent to stderr instead; the saved descriptor is used for the result line only
@@ -232,10 +336,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        print(f"bench: --gpus {a.gpus} but WORLD_SIZE = {world}: the launcher's world size is what runs", file=sys.stderr)
     import torch
     import gphocs_amd as G
-    G.build()
-    torch.cuda.set_device(local_rank)
+    emu = a.host_emulation
+    if emu:
+        sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
+        import run_hostemu
+        a.lib = run_hostemu.build_hostemu()
+        if a.comm == "rccl":
+            a.comm = "shm"
+    else:
+        G.build()
+        torch.cuda.set_device(local_rank)
+    dev_sync = (lambda: None) if emu else torch.cuda.synchronize
     dist = None
     allreduce = None
     comm = None
@@ -244,14 +359,23 @@ def main():
     force_dist = os.environ.get("GPH_BENCH_FORCE_DIST") == "1"   # exercise the collective path on one GPU
     L_total = a.loci * world if a.weak else a.loci
     begin, end = (rank * a.loci, (rank + 1) * a.loci) if a.weak else shard_of(L_total, rank, world)
+    if end <= begin:
+        print(f"bench: rank {rank} of {world} gets no loci out of {L_total}", file=sys.stderr)
+        sys.exit(2)
     pack = build_shard(G, a.config, L_total, begin, end, a.mut_scale, 20261002 + a.config, os.path.join(REPO, "bench_cache"))
     if a.samples_per_log > 0:
         pack.samplesPerLog = a.samples_per_log
     lib = G.load_library(a.lib) if a.lib else G.load_library(dims=(pack.n, pack.K, pack.B))
     if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm (bench bookkeeping only)
-        dev = torch.device("cuda", local_rank)
+        # bench bookkeeping only (barrier, max-over-ranks time, the 128-byte RCCL id); nccl == RCCL on ROCm
+        dist.init_process_group("gloo" if emu else "nccl", rank=rank, world_size=world)
+        dev = torch.device("cpu") if emu else torch.device("cuda", local_rank)
+        if a.comm == "shm":
+            comm = lib.gph_comm_create_shm(f"/gphocs-bench-{os.environ.get('MASTER_PORT', '0')}".encode(), rank, world)
+            if not comm:
+                print("bench: the shared-memory communicator could not be created", file=sys.stderr)
+                sys.exit(2)
         if a.comm == "rccl":
             # the engine's own communicator: rank 0 makes the id, torch.distributed carries the 128 bytes
             idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
@@ -279,10 +403,12 @@ def main():
             # <= 1.5-KB payloads through torch.distributed: every rank all-gathers the (sums | mins) vector and
             # reduces the `world` rows itself in rank order
             SLOTS = 192
-            hbuf = torch.zeros(SLOTS, dtype=torch.float64).pin_memory()
+            hbuf = torch.zeros(SLOTS, dtype=torch.float64)
+            hout = torch.zeros(world * SLOTS, dtype=torch.float64)
+            if not emu:
+                hbuf, hout = hbuf.pin_memory(), hout.pin_memory()
             dbuf = torch.zeros(SLOTS, dtype=torch.float64, device=dev)
             dout = torch.zeros(world * SLOTS, dtype=torch.float64, device=dev)
-            hout = torch.zeros(world * SLOTS, dtype=torch.float64).pin_memory()
 
             def allreduce(sums, mins):
                 ns, nm = sums.size, mins.size
@@ -293,7 +419,8 @@ def main():
                 dbuf.copy_(hbuf, non_blocking=True)
                 dist.all_gather_into_tensor(dout, dbuf)
                 hout.copy_(dout, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
+                if not emu:
+                    torch.cuda.current_stream().synchronize()
                 rows = hout.numpy().reshape(world, SLOTS)
                 if ns:
                     acc = rows[0, :ns].copy()
@@ -328,22 +455,24 @@ def main():
         s.class_stats(k, reset=True)
     s.set_timing(1)
     hs0 = s.host_stats()
+    acc0 = s.accept_counts()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     t0 = time.perf_counter()
     for it in range(it0, it0 + a.steps):
         s.iteration(it)
-    torch.cuda.synchronize()
+    dev_sync()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     hs1 = s.host_stats()
+    acc1 = s.accept_counts()
     cnt = s.counters()            # summed over all ranks by the engine (the counters ride in the reduced rows)
     sweep = s.class_stats(0)
     evals, tmax = float(cnt["evals"]), dt
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if emu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
     # amortised cost of checkAll (patch.c:2745, every iterations-per-log = 100 iterations): one untimed-region call
@@ -366,20 +495,39 @@ def main():
         # load-once / store-once bound of a sweep: 2 * (32 N P + 32 E + 20 N) bytes per locus
         N_, E_ = 2 * pack.n - 1, 2 * pack.n + 40 + 3 * pack.B + pack.K + 10
         per_sweep_bytes = float(np.sum(2.0 * (32.0 * N_ * P + 32.0 * E_ + 20.0 * N_)))
-        # HBM traffic of the dominant kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
-        # WRITE_SIZE, per launch) of an EARLIER run of this command, committed under profiles/ -- not measured here
-        traffic, traffic_src = None, None
+        # HBM traffic and instruction counts of the dominant kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x2
+        # gfx950 correction + WRITE_SIZE, per launch; SQ_INSTS_* per wavefront) of an EARLIER run of this command,
+        # committed under profiles/ -- not measured here.  They are the measurement of ONE build: used only when the
+        # file's build id is the loaded library's and the shard has the file's size.
+        build_id = lib.gph_build_id().decode()
+        traffic, traffic_src, issue = None, None, None
         tf = os.path.join(REPO, "profiles", "traffic_k_sweep.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                if tj.get("loci") == L_local:
+                if tj.get("loci") == L_local and tj.get("build_id") == build_id:
                     traffic = tj["hbm_bytes_per_launch"]
                     traffic_src = "profiles/traffic_k_sweep.json (%s)" % tj.get("build", "committed rocprofv3 --pmc passes, not this run")
+                    if tj.get("valu_per_wave") and sweep_ms > 0:
+                        # issue roofline: a CU issues at most one VALU and one SALU wave-instruction per cycle (4 SIMDs x
+                        # 16 lanes: a wave64 instruction holds its SIMD for 4 cycles); cycles a CU has per locus at the
+                        # nominal 2.4 GHz (the clock under load is lower: the fractions are lower bounds)
+                        cyc = sweep_ms * 1e-3 * 2.4e9 / (L_local / 256.0)
+                        issue = {"valu_per_wave": tj["valu_per_wave"], "salu_per_wave": tj["salu_per_wave"],
+                                 "lds_per_wave": tj.get("lds_per_wave"), "clock_ghz_assumed": 2.4,
+                                 "cycles_per_locus_per_cu": cyc, "valu_issue_frac": tj["valu_per_wave"] / cyc,
+                                 "salu_issue_frac": tj["salu_per_wave"] / cyc,
+                                 "floor_ms": max(tj["valu_per_wave"], tj["salu_per_wave"]) * (L_local / 256.0) / 2.4e9 * 1e3,
+                                 "source": traffic_src}
+                elif tj.get("loci") == L_local:
+                    traffic_src = (f"none: profiles/traffic_k_sweep.json was measured with build {tj.get('build_id')}, "
+                                   f"the loaded library is {build_id}")
             except Exception:
                 pass
         nsync = (hs1["syncs"] - hs0["syncs"]) / a.steps
         ncol = (hs1["collectives"] - hs0["collectives"]) / a.steps if comm else ncoll[0] / max(a.preroll + a.warmup + a.steps, 1)
+        comm_kind = lib.gph_comm_kind(comm).decode() if comm else ("torch.distributed hook" if dist else "none")
+        comm_world = int(lib.gph_comm_world(comm)) if comm else (world if dist else 1)
         line = {
             "metric": "locus-likelihood evals/sec (+ MCMC iters/sec), 100k loci, 1/2/4/8 MI355X",
             "value": evals / tmax, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -394,26 +542,31 @@ def main():
                        "bands": int(pack.B),
                        "mean_phased_patterns": float(P.mean()), "max_phased_patterns": int(P.max()),
                        "data_diversity": f"mutation scale {a.mut_scale} x the prior mean theta (tunes P to ~18 phased patterns per 1-kb locus)",
+                       "evals_timed": evals,
                        "evals_per_locus_iter": evals / (L_total * a.steps),
                        "recomputed_nodes_per_eval": cnt["eval_nodes"] / max(cnt["evals"], 1),
                        "algorithmic_bytes_per_eval": cnt["eval_bytes"] / max(cnt["evals"], 1),
+                       "accept_counts_timed": [int(y - x) for x, y in zip(acc0, acc1)],
                        "preroll_iterations": a.preroll,
                        "checkall_period": int(pack.samplesPerLog), "checkall_in_timed_window": in_window,
                        "checkall_ms": check_ms,
                        "checkall_amortised_ms_per_iteration": (check_ms / int(pack.samplesPerLog)) if check_ms else None,
                        "host_syncs_per_iteration": nsync,
                        "collectives_per_iteration": ncol if (dist is not None) else 0,
+                       "communicator": comm_kind, "communicator_world": comm_world,
                        "decisions": "device-resident (k_global)" if hs1["resident"] else "host",
                        "kernel_launches_per_iteration": (hs1["launches"] - hs0["launches"]) / a.steps,
+                       "library_build_id": build_id,
                        "parallelism": f"loci sharded over {world} rank(s), one process per GPU"
-                                      + (f", native RCCL all-gather of the reduced row on the engine's stream" if comm else
+                                      + (f", native {comm_kind} exchange of the reduced row" + (" on the engine's stream" if hs1["resident"] else "") if comm else
                                          (", torch.distributed hook" + (" (fallback: the RCCL communicator could not be created)" if comm_fallback else "") if dist else ""))},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (fused UpdateGB_InternalNode+MigrationNode+MigSPR)",
                          "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "accounting": "ALGORITHMIC bytes per evaluation (96 R P + 20 N + 8 U + 8, SURVEY 8d) / HIP-event "
                                        "kernel time; mostly L2 / Infinity-Cache hits, see hbm_counter_frac for DRAM",
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "hbm_counter_frac": (traffic / (sweep_ms * 1e-3) / 8e12) if traffic else None,
+                         "hbm_counter_frac": (traffic / (sweep_ms * 1e-3) / 8e12) if traffic and sweep_ms > 0 else None,
+                         "issue": issue,
                          "per_sweep": {"bytes": per_sweep_bytes, "bound_ms_at_peak": per_sweep_bytes / 8e12 * 1e3,
                                        "frac": per_sweep_bytes / 8e12 * 1e3 / sweep_ms if sweep_ms > 0 else None,
                                        "accounting": "load-once/store-once: 2 (32 N P + 32 E + 20 N) bytes per locus per sweep"},
@@ -423,17 +576,18 @@ def main():
             "kernels": kern,
             "hbm_resident_bytes": s.hbm_bytes(),
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if emu:
+            line["data"] = "synthetic; HOST EMULATION of the engine sources (tests only): not a measurement"
+        if world == 1 and not a.no_cpu_baseline and not emu:
             try:
-                cb = cpu_baseline_reference(a.config, pack, min(a.cpu_loci, L_total), a.cpu_iters)
-                port = cpu_baseline(G, pack, min(a.cpu_loci, L_total), a.cpu_iters)
+                cb = cpu_baseline_reference(a.config, pack, min(a.cpu_loci, L_total), a.cpu_iters,
+                                            min(a.cpu_small_loci, L_total), a.cpu_small_iters)
+                port = cpu_baseline(G, pack, min(a.cpu_small_loci, L_total), a.cpu_small_iters)
                 if cb is None:
                     cb = port
                     cb["note"] = "oracle/_ref (the real reference binary) is absent on this box: the restatement was timed"
                 else:
-                    cb["port_single_thread"] = {"value": port["value"], "kind": "port"}
-                cb["sample_caveat"] = (f"timed on {min(a.cpu_loci, L_total)} loci (working set ~"
-                                       f"{min(a.cpu_loci, L_total) * 0.035:.0f} MB) against {L_total} on the GPU: not like for like")
+                    cb["port_single_thread_small_sample"] = {"value": port["value"], "kind": "port"}
                 line["cpu_baseline"] = cb
             except Exception as ex:  # pragma: no cover
                 line["cpu_baseline"] = {"error": str(ex)}

@@ -32,9 +32,20 @@ CSRC = os.path.join(_HERE, "csrc")
 # they are: -5 % sweep time, -7..18 % static instructions per kernel.
 # -amdgpu-sched-strategy=max-ilp: the sweep kernel is issue-bound at a fixed occupancy (launch bounds), so the
 # scheduler has nothing to gain from trading latency hiding for registers: -0.7 %.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wno-unused-result", "-pthread", "-mllvm", "-disable-machine-licm",
-               "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-ldl", "-lrt"]
+HIPCC_BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+              "-Wno-unused-result", "-pthread"]
+HIPCC_TUNING = ["-mllvm", "-disable-machine-licm", "-mllvm", "-structurizecfg-skip-uniform-regions",
+                "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+HIPCC_FLAGS = HIPCC_BASE + HIPCC_TUNING
+HIPCC_LIBS = ["-ldl", "-lrt"]        # after the sources: an --as-needed linker drops libraries named before their users
+# The tuning switches above are backend options of THIS compiler (uniformity analysis decides what
+# -structurizecfg-skip-uniform-regions leaves alone; the batched generator's inline asm relies on nothing else in
+# the translation unit using M0): the version they were validated with is recorded, build() warns when hipcc
+# differs, and a control build WITHOUT them (`libgphocs_hip_plain.so`) runs the golden parity tests next to the
+# tuned one (tests/test_gpu_parity.py::test_plain_build_parity), so a compiler change that breaks an assumption
+# shows as a difference between the two.
+HIPCC_VALIDATED = "roc-7.2.0 26014"
+PLAIN_LIB = "libgphocs_hip_plain.so"    # capacities of variant `m`, no -mllvm switches
 
 # Capacity variants of the same library (same C ABI, same sources): the static LDS image of a locus is
 # sized by compile-time capacities (csrc/gph_types.h), and a tighter image means more resident
@@ -89,16 +100,44 @@ def _run_to(cmd, out, verbose):
             os.unlink(tmp)
 
 
+def hipcc_version():
+    try:
+        out = subprocess.run(["hipcc", "--version"], capture_output=True, text=True, timeout=60).stdout
+    except Exception:  # pragma: no cover
+        return ""
+    for ln in out.splitlines():
+        if "clang version" in ln:
+            return ln.strip()
+    return out.strip().splitlines()[0] if out.strip() else ""
+
+
 def _build_locked(verbose):
+    ver = hipcc_version()
+    if HIPCC_VALIDATED not in ver:
+        print(f"gphocs_amd.build: hipcc is '{ver}', the backend switches {HIPCC_TUNING[1::2]} were validated with "
+              f"'{HIPCC_VALIDATED}': run the -m gpu parity suite (it compares the tuned build with the plain one)")
     srcs = [os.path.join(CSRC, f) for f in LIB_SOURCES]
+    import hashlib
+    def build_id(flags):
+        h = hashlib.sha256()
+        for f in sorted(os.listdir(CSRC)):
+            h.update(f.encode() + b"\0" + open(os.path.join(CSRC, f), "rb").read())
+        h.update(" ".join(flags).encode() + ver.encode())
+        return h.hexdigest()[:12]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
         [os.path.join(REPO, "include", "gphocs_hip.h")]
     for name, (cl, ck, cb, waves, fn) in VARIANTS.items():
         out = os.path.join(_HERE, fn)
         if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
             continue
-        _run_to(["hipcc"] + HIPCC_FLAGS + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}",
-                                           f"-DGPH_SWEEP_WAVES={waves}"] + srcs, out, verbose)
+        fl = HIPCC_FLAGS + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"]
+        _run_to(["hipcc"] + fl + [f'-DGPH_BUILD_ID="{name}-{build_id(fl)}"'] + srcs + HIPCC_LIBS, out, verbose)
+    # control build without the backend switches (parity tests only)
+    out = os.path.join(_HERE, PLAIN_LIB)
+    if not (os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)):
+        cl, ck, cb, waves, _ = VARIANTS["m"]
+        fl = HIPCC_BASE + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"]
+        _run_to(["hipcc"] + fl + [f'-DGPH_BUILD_ID="plain-{build_id(fl)}"'] + srcs + HIPCC_LIBS, out, verbose)
     # the program: same command line as the reference's G-PhoCS binary (GPhoCS.c:84-238)
     exe, main = os.path.join(_HERE, "G-PhoCS-hip"), os.path.join(CSRC, "gph_main.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(main), os.path.getmtime(deps[-1])):
@@ -178,7 +217,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_comm_unique_id", "gph_comm_create_rccl", "gph_comm_create_shm", "gph_comm_attach_shm", "gph_comm_shm_bytes",
     "gph_comm_destroy", "gph_comm_world", "gph_comm_rank", "gph_comm_on_stream", "gph_comm_kind",
     "gph_comm_allgather_stream", "gph_comm_allreduce_host", "gph_run_control_file_comm", "gph_device_count",
-    "gph_engine_unit",
+    "gph_engine_unit", "gph_build_id", "gph_comm_local_group", "gph_comm_create_local",
 ]
 
 
@@ -259,6 +298,13 @@ def _load_library(path):
     lib.gph_engine_set_timing.argtypes = [C.c_void_p, C.c_uint32]
     lib.gph_engine_unit.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]
     lib.gph_run_control_file_comm.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.gph_build_id.restype = C.c_char_p
+    lib.gph_comm_local_group.argtypes = [C.c_int32, C.c_int32]
+    lib.gph_comm_local_group.restype = C.c_void_p
+    lib.gph_comm_create_local.argtypes = [C.c_void_p, C.c_int32]
+    lib.gph_comm_create_local.restype = C.c_void_p
+    lib.gph_comm_world.argtypes = [C.c_void_p]
+    lib.gph_comm_rank.argtypes = [C.c_void_p]
     return lib
 
 

@@ -2,6 +2,8 @@
 #include "gph_comm.h"
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,13 +25,19 @@ struct ShmSeg {                       // one cache line per rank's arrival count
   std::atomic<uint32_t> magic;
   std::atomic<uint32_t> failed;
   char pad0[56];
+  // named segments only: rank r writes its pid into hello[r], the LIVE rank 0 of this run answers with the same value
+  // in ack[r].  A leftover segment of a crashed run (same name, right size, right magic) has nobody to answer: the
+  // rank unmaps it and opens the name again until it finds the segment rank 0 has just made.
+  std::atomic<uint32_t> hello[64], ack[64];
   struct alignas(64) Slot { std::atomic<uint64_t> seq; char pad[56]; } slot[64];
   double data[2][64][GPH_COMM_MAXN];
 };
 
+struct gph_comm_group;
 struct gph_comm {
-  int kind = 0;                       // 1 RCCL, 2 shm
+  int kind = 0;                       // 1 RCCL, 2 shm, 3 local (thread ranks of one process on one device)
   int rank = 0, world = 1;
+  gph_comm_group *group = nullptr;
   // shm
   ShmSeg *seg = nullptr;
   bool owns_mapping = false;
@@ -54,12 +62,17 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
+Rccl *rccl_load();
 Rccl *rccl()
 {
+  static std::once_flag once;
+  static Rccl *R = nullptr;
+  std::call_once(once, [] { R = rccl_load(); });
+  return R;
+}
+Rccl *rccl_load()
+{
   static Rccl R;
-  static bool tried = false;
-  if (tried) return R.h ? &R : nullptr;
-  tried = true;
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char *n : names) if ((R.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   /* a copy this process already holds */
   if (!R.h) for (const char *n : names) if ((R.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
@@ -151,37 +164,126 @@ gph_comm *gph_comm_attach_shm(void *mapping, int32_t rank, int32_t world)
 gph_comm *gph_comm_create_shm(const char *name, int32_t rank, int32_t world)
 {
   if (!name || world < 1 || world > 64 || rank < 0 || rank >= world) return nullptr;
-  int fd = -1;
   const auto t0 = std::chrono::steady_clock::now();
+  auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  const double limit = 120.0;
   if (rank == 0) {
+    /* a fresh, zero-filled segment under the name (a leftover of a crashed run is unlinked first) */
     shm_unlink(name);
-    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd >= 0 && ftruncate(fd, (off_t)sizeof(ShmSeg)) != 0) { close(fd); fd = -1; }
-  } else {
-    for (;;) {   /* until rank 0 has made it */
-      fd = shm_open(name, O_RDWR, 0600);
-      struct stat st;
-      if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(ShmSeg)) break;
-      if (fd >= 0) { close(fd); fd = -1; }
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) break;
-      usleep(1000);
+    if (fd < 0) { fprintf(stderr, "gphocs_hip: cannot create the shared-memory segment %s\n", name); return nullptr; }
+    void *m = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { shm_unlink(name); return nullptr; }
+    gph_comm *c = gph_comm_attach_shm(m, rank, world);
+    if (!c) { munmap(m, sizeof(ShmSeg)); shm_unlink(name); return nullptr; }
+    c->owns_mapping = true;
+    c->shm_name = name;
+    c->seg->magic.store(0x47504843u, std::memory_order_release);
+    /* answer every rank's hello: only a rank that sits on THIS segment gets an answer */
+    for (int seen = 1; seen < world;) {
+      seen = 1;
+      for (int r = 1; r < world; r++) {
+        const uint32_t h = c->seg->hello[r].load(std::memory_order_acquire);
+        if (h) { c->seg->ack[r].store(h, std::memory_order_release); seen++; }
+      }
+      if (seen < world) {
+        if (elapsed() > limit) { fprintf(stderr, "gphocs_hip: rank 0 waited %.0f s for the other ranks at %s\n", limit, name); gph_comm_destroy(c); return nullptr; }
+        usleep(200);
+      }
     }
+    return c;
   }
-  if (fd < 0) { fprintf(stderr, "gphocs_hip: cannot open the shared-memory segment %s\n", name); return nullptr; }
-  void *m = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (m == MAP_FAILED) return nullptr;
-  gph_comm *c = gph_comm_attach_shm(m, rank, world);
-  if (!c) { munmap(m, sizeof(ShmSeg)); return nullptr; }
-  c->owns_mapping = true;
-  c->shm_name = name;
-  if (rank == 0) c->seg->magic.store(0x47504843u, std::memory_order_release);
-  else {
-    while (c->seg->magic.load(std::memory_order_acquire) != 0x47504843u) {
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) { gph_comm_destroy(c); return nullptr; }
+  const uint32_t me = (uint32_t)getpid() | 0x80000000u;   /* never 0 */
+  while (elapsed() <= limit) {
+    int fd = shm_open(name, O_RDWR, 0600);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(ShmSeg)) { if (fd >= 0) close(fd); usleep(1000); continue; }
+    void *m = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return nullptr;
+    ShmSeg *seg = (ShmSeg *)m;
+    /* wait (briefly) for the live rank 0 of this run to answer; silence = a leftover segment: open the name again */
+    bool ok = false;
+    const auto t1 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() < 0.25) {
+      if (seg->magic.load(std::memory_order_acquire) == 0x47504843u) {
+        seg->hello[rank].store(me, std::memory_order_release);
+        if (seg->ack[rank].load(std::memory_order_acquire) == me) { ok = true; break; }
+      }
       usleep(200);
     }
+    if (!ok) { munmap(m, sizeof(ShmSeg)); continue; }
+    gph_comm *c = gph_comm_attach_shm(m, rank, world);
+    if (!c) { munmap(m, sizeof(ShmSeg)); return nullptr; }
+    c->owns_mapping = true;
+    c->shm_name = name;
+    return c;
   }
+  fprintf(stderr, "gphocs_hip: rank %d found no live shared-memory segment %s within %.0f s\n", rank, name, limit);
+  return nullptr;
+}
+
+// ---------------------------------------------------------------- thread ranks on one device
+// One group per job: a generation barrier for the host threads, per rank two HIP events and the address of the row it
+// contributes.  An all-gather = every rank records `ready` behind its reduction kernel, the threads meet, every rank
+// queues (wait for ready[r], copy rank r's row) for every r on ITS stream and records `done`, the threads meet again
+// and every stream waits for every `done` (nobody overwrites its row while another rank still reads it).  No host
+// synchronisation with the device: the stream semantics are the ones of the RCCL all-gather.
+struct gph_comm_group {
+  int world = 1, device = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0, refs = 0;
+  uint64_t gen = 0;
+  bool failed = false;
+  const double *src[64] = {nullptr};
+  double hbuf[64][GPH_COMM_MAXN];
+#ifndef GPH_HOSTEMU
+  hipEvent_t ready[64], done[64];
+#endif
+};
+static int group_barrier(gph_comm_group *g)
+{
+  std::unique_lock<std::mutex> lk(g->m);
+  if (g->failed) return 1;
+  const uint64_t my = g->gen;
+  if (++g->arrived == g->world) { g->arrived = 0; g->gen++; g->cv.notify_all(); return 0; }
+  if (!g->cv.wait_for(lk, std::chrono::seconds(300), [&] { return g->gen != my || g->failed; })) {
+    fprintf(stderr, "gphocs_hip: a thread rank waited 300 s for the others\n");
+    g->failed = true;
+    g->cv.notify_all();
+  }
+  return g->failed ? 1 : 0;
+}
+
+gph_comm_group *gph_comm_local_group(int32_t world, int32_t device)
+{
+#ifdef GPH_HOSTEMU
+  (void)world; (void)device;
+  return nullptr;
+#else
+  if (world < 1 || world > 64 || hipSetDevice(device) != hipSuccess) return nullptr;
+  gph_comm_group *g = new gph_comm_group();
+  g->world = world; g->device = device;
+  for (int r = 0; r < world; r++)
+    if (hipEventCreateWithFlags(&g->ready[r], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming) != hipSuccess) { delete g; return nullptr; }
+  return g;
+#endif
+}
+
+gph_comm *gph_comm_create_local(gph_comm_group *g, int32_t rank)
+{
+  if (!g || rank < 0 || rank >= g->world) return nullptr;
+  gph_comm *c = new gph_comm();
+  c->kind = 3; c->rank = rank; c->world = g->world; c->group = g;
+#ifndef GPH_HOSTEMU
+  c->device = g->device;
+#endif
+  std::lock_guard<std::mutex> lk(g->m);
+  g->refs++;
   return c;
 }
 
@@ -202,13 +304,25 @@ void gph_comm_destroy(gph_comm *c)
     munmap(c->seg, sizeof(ShmSeg));
     if (c->rank == 0 && !c->shm_name.empty()) shm_unlink(c->shm_name.c_str());
   }
+  if (c->kind == 3 && c->group) {
+    gph_comm_group *g = c->group;
+    bool last;
+    { std::lock_guard<std::mutex> lk(g->m); last = --g->refs == 0; if (!last) { g->failed = true; g->cv.notify_all(); } }   /* a rank that leaves early releases the others */
+    if (last) {
+#ifndef GPH_HOSTEMU
+      (void)hipSetDevice(g->device);
+      for (int r = 0; r < g->world; r++) { (void)hipEventDestroy(g->ready[r]); (void)hipEventDestroy(g->done[r]); }
+#endif
+      delete g;
+    }
+  }
   delete c;
 }
 
 int gph_comm_world(const gph_comm *c) { return c ? c->world : 1; }
 int gph_comm_rank(const gph_comm *c) { return c ? c->rank : 0; }
-int gph_comm_on_stream(const gph_comm *c) { return c && c->kind == 1; }
-const char *gph_comm_kind(const gph_comm *c) { return !c ? "none" : c->kind == 1 ? "rccl" : "shm"; }
+int gph_comm_on_stream(const gph_comm *c) { return c && (c->kind == 1 || c->kind == 3); }
+const char *gph_comm_kind(const gph_comm *c) { return !c ? "none" : c->kind == 1 ? "rccl" : c->kind == 2 ? "shm" : "local"; }
 
 int gph_comm_allgather_stream(gph_comm *c, const double *d_in, double *d_out, int32_t count, void *stream)
 {
@@ -216,6 +330,24 @@ int gph_comm_allgather_stream(gph_comm *c, const double *d_in, double *d_out, in
   (void)c; (void)d_in; (void)d_out; (void)count; (void)stream;
   return 1;
 #else
+  if (c && c->kind == 3) {
+    gph_comm_group *g = c->group;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = sizeof(double) * (size_t)count;
+    g->src[c->rank] = d_in;
+    if (hipEventRecord(g->ready[c->rank], st) != hipSuccess) return 1;
+    if (group_barrier(g)) return 1;
+    for (int r = 0; r < c->world; r++) {
+      if (r != c->rank && hipStreamWaitEvent(st, g->ready[r], 0) != hipSuccess) return 1;
+      if (d_out + (size_t)r * count != g->src[r] &&
+          hipMemcpyAsync(d_out + (size_t)r * count, g->src[r], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+    }
+    if (hipEventRecord(g->done[c->rank], st) != hipSuccess) return 1;
+    if (group_barrier(g)) return 1;
+    for (int r = 0; r < c->world; r++)
+      if (r != c->rank && hipStreamWaitEvent(st, g->done[r], 0) != hipSuccess) return 1;
+    return 0;
+  }
   if (!c || c->kind != 1) return 1;
   Rccl *R = rccl();
   ncclResult_t rc = R->AllGather(d_in, d_out, (size_t)count, ncclDouble, c->nccl, (hipStream_t)stream);
@@ -264,6 +396,25 @@ int gph_comm_allreduce_host(gph_comm *c, double *sums, int32_t nsum, double *min
       mins[i] = a;
     }
     return 0;
+  }
+  if (c->kind == 3) {
+    /* host path of the thread ranks (the stepwise entry points): a buffer per rank in the group, two meetings */
+    gph_comm_group *g = c->group;
+    double *mine = g->hbuf[c->rank];
+    if (nsum) memcpy(mine, sums, sizeof(double) * nsum);
+    if (nmin) memcpy(mine + nsum, mins, sizeof(double) * nmin);
+    if (group_barrier(g)) return 1;
+    for (int i = 0; i < nsum; i++) {
+      double a = g->hbuf[0][i];
+      for (int r = 1; r < c->world; r++) a += g->hbuf[r][i];
+      sums[i] = a;
+    }
+    for (int i = 0; i < nmin; i++) {
+      double a = g->hbuf[0][nsum + i];
+      for (int r = 1; r < c->world; r++) { const double v = g->hbuf[r][nsum + i]; a = v < a ? v : a; }
+      mins[i] = a;
+    }
+    return group_barrier(g);
   }
 #ifndef GPH_HOSTEMU
   if (c->kind == 1) {

@@ -258,9 +258,13 @@ __global__ void __launch_bounds__(GPH_RED_THREADS) k_reduce_stage(GphKargs KA, G
   __syncthreads();
   /* ONE release per block (thread 0, after the block barrier: cumulative over the block's stores) -- an agent-scope
    * fence writes the L2 back, and 2048 wavefronts doing it cost more than the reduction itself */
-  if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(ticket, 1u) == gridDim.x - 1; if (s_last) __threadfence(); }
+  if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(ticket, 1u) == gridDim.x - 1; }
   __syncthreads();
   if (!s_last) return;
+  /* every wavefront of the last block acquires for itself before it reads the other blocks' partials (they were
+   * written through other XCDs' L2s): one agent-scope fence per wavefront of ONE block -- the memory model asks for
+   * it, the cache-wide invalidate of thread 0's fence only happened to cover the other waves */
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (nc0 > 0) reduce_final_body(nc0, part, red, sh.f);
   if (nc1 > 0) reduce_final_body(nc1, part + 3 * GPH_RED_BLOCKS * GPH_RED_COLS, red + GPH_RED_STRIDE, sh.f);
   if (threadIdx.x == 0) { red[3 * GPH_RED_COLS] = (double)*D.err; *ticket = 0; }
@@ -728,8 +732,12 @@ static int finish_sync(gph_engine *e)
   return check_error(e);
 }
 
-// run a deferred synchronizeEvents pass now (anything but the next genealogy sweep is about to touch the pages)
-static int flush_sync(gph_engine *e)
+static int run_stage_now(gph_engine *e, int stage, int arg);
+// run a deferred synchronizeEvents pass now (anything but the next genealogy sweep is about to touch the pages).
+// now = the caller is a stepwise entry point that goes on to edit the host mirror of the chain state and push it: the
+// stage that checks the pass (Fatal Error 0075/0076, the class-8 counters) must then have run -- on the host, result
+// checked -- before that, or the push would overwrite what a queued device-side stage wrote
+static int flush_sync(gph_engine *e, bool now)
 {
   if (!e->sync_pending) return 0;
   e->sync_pending = false;
@@ -737,6 +745,7 @@ static int flush_sync(gph_engine *e)
   LAUNCH(e, 8, k_sync, 0);
   int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
   if (rc) return rc;
+  if (now) return run_stage_now(e, GS_REFRESH_DONE, 0);
   return run_stage(e, GS_REFRESH_DONE, 0, e->G_h->iteration);
 }
 
@@ -1081,7 +1090,7 @@ int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result
   if (!e || !e->initialized || !a || !out) return GPH_ESTATE;
   if (a->num_aff > 2 * GPH_MAXB) return GPH_EARG;
   SETDEV(e);
-  { int rcs = flush_sync(e); if (rcs) return rcs; }
+  { int rcs = flush_sync(e, true); if (rcs) return rcs; }
   GphTauArgs &A = e->G_h->tau;
   memset(&A, 0, sizeof A);
   A.ap = a->ap; A.son0 = a->son0; A.son1 = a->son1; A.isRoot = a->isRoot; A.num_aff = a->num_aff; A.mode = a->mode;
@@ -1136,7 +1145,7 @@ int gph_engine_mixing_evaluate(gph_engine *e, double c, double *dataDelta)
 {
   if (!e || !e->initialized || !dataDelta) return GPH_ESTATE;
   SETDEV(e);
-  { int rcs = flush_sync(e); if (rcs) return rcs; }
+  { int rcs = flush_sync(e, true); if (rcs) return rcs; }
   e->G_h->mix_c = c;
   int rc = push_G(e);
   if (rc) return rc;
@@ -1228,7 +1237,7 @@ int gph_engine_synchronize(gph_engine *e, int32_t refresh, double *oldGen, doubl
     if (newGen) *newGen = 0.0;
     return 0;
   }
-  { int rcs = flush_sync(e); if (rcs) return rcs; }
+  { int rcs = flush_sync(e, true); if (rcs) return rcs; }
   PUSH_IF_DIRTY(e);
   LAUNCH(e, 8, k_sync, (int)refresh);
   int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
@@ -1246,7 +1255,7 @@ int gph_engine_check_all(gph_engine *e, int32_t *ok, double *sumData, double *su
 {
   if (!e || !e->initialized) return GPH_ESTATE;
   SETDEV(e);
-  { int rcs = flush_sync(e); if (rcs) return rcs; }
+  { int rcs = flush_sync(e, true); if (rcs) return rcs; }
   PUSH_IF_DIRTY(e);
   LAUNCH(e, 4, k_check, 0);
   int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
@@ -1348,6 +1357,11 @@ int gph_debug_math(const double *x, const double *y, int32_t n, double *out, int
 #endif
 }
 
+#ifndef GPH_BUILD_ID
+#define GPH_BUILD_ID "unidentified"
+#endif
+const char *gph_build_id(void) { return GPH_BUILD_ID; }
+
 int gph_engine_hbm_bytes(gph_engine *e, double *bytes)
 {
   if (!e || !bytes) return GPH_EARG;
@@ -1408,7 +1422,7 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     fprintf(stderr, "gphocs_hip: UpdateLocusRate over a shard of the loci needs the all-reduce hook (gph_engine_set_allreduce)\n");
     return GPH_EARG;
   }
-  { int rcs = flush_sync(e); if (rcs) return rcs; }
+  { int rcs = flush_sync(e, true); if (rcs) return rcs; }
   PUSH_IF_DIRTY(e);
   const GphLayout &y = e->lay;
   const int n = e->cfg.n, N = 2 * n - 1;
@@ -1630,7 +1644,7 @@ int gph_engine_iteration_(gph_engine *e, int32_t iteration, const double *lr_alp
   }
   if ((iteration + 1) % Gh.samplesPerLog == 0) {
     // checkAll, patch.c:2745-2884: consistency checks + accumulator resynchronisation
-    if ((rc = flush_sync(e))) return rc;
+    if ((rc = flush_sync(e, false))) return rc;
     LAUNCH(e, 4, k_check, 0);
     if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
     if ((rc = reduce_stats(e))) return rc;
@@ -1648,7 +1662,7 @@ int gph_engine_unit(gph_engine *e, int32_t op, int32_t arg, double *out, int32_t
 {
   if (!e || !e->initialized || !out || op < 0 || op > 2 || stride < 3 * (e->cfg.n - 1) || stride < 4) return GPH_EARG;
   SETDEV(e);
-  { int rcs = flush_sync(e); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
+  { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
   if (op == 2) {
     if (arg < e->cfg.Kc || arg >= e->cfg.K) return GPH_EARG;
     GphGlobal &G = *e->G_h;
@@ -1694,7 +1708,7 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
 {
   if (!e || !e->initialized || !path) return GPH_ESTATE;
   SETDEV(e);
-  { int rcs = flush_sync(e); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
+  { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
   const GphLayout &y = e->lay;
   std::vector<char> pages(e->pages_bytes), cond(withCond ? e->cond_bytes : 0);
   int rc = d2h(e, pages.data(), e->dev.pages, e->pages_bytes);

@@ -15,7 +15,9 @@
 #include <libgen.h>
 #include <signal.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
+#include <cerrno>
 #include <unistd.h>
 #include <atomic>
 #include <climits>
@@ -65,6 +67,15 @@ static void *load_engine(const std::string &dir, const char *ctl, const char *ct
   return h;
 }
 
+// the launcher's children, for the signal handler: a launcher that is told to stop takes its ranks with it
+static pid_t g_kids[64];
+static volatile sig_atomic_t g_nkids = 0;
+static void forward_signal(int sig)
+{
+  for (int r = 0; r < g_nkids; r++) if (g_kids[r] > 0) kill(g_kids[r], sig);
+  _exit(128 + sig);
+}
+
 static int usage(const char *a0)
 {
   fprintf(stderr, "usage: %s [-v] [-d device] [-g gpus] <control-file> [secondary-control-file]\n", a0);
@@ -103,6 +114,8 @@ int main(int argc, char **argv)
     pid_t p = fork();
     if (p < 0) { perror("fork"); for (int q = 0; q < r; q++) kill(kids[q], SIGTERM); return 2; }
     if (p == 0) {
+      prctl(PR_SET_PDEATHSIG, SIGTERM);          /* the launcher died (killed -9, say): do not linger in an exchange */
+      if (getppid() == 1) _exit(2);
       void *h = load_engine(dir, ctl, ctl2);
       Mailbox *mb = (Mailbox *)shared;
       // how many devices are there?  Child 0 asks (the first GPU call of this process tree) and tells the others
@@ -138,12 +151,21 @@ int main(int argc, char **argv)
       _exit(rc ? 1 : 0);
     }
     kids[r] = p;
+    g_kids[r] = p;
+    g_nkids = r + 1;
   }
+  signal(SIGTERM, forward_signal);
+  signal(SIGINT, forward_signal);
   // a rank that fails takes the job down: the others would wait for it in the next exchange
   int status = 0, left = gpus, bad = 0;
   while (left > 0) {
     pid_t p = wait(&status);
-    if (p < 0) break;
+    if (p < 0) {
+      if (errno == EINTR) continue;
+      perror("G-PhoCS-hip: wait");             /* no children left to wait for although some are unaccounted: a failure */
+      for (int r = 0; r < gpus; r++) kill(kids[r], SIGTERM);
+      return 2;
+    }
     left--;
     const bool failed = !WIFEXITED(status) || WEXITSTATUS(status) != 0;
     if (failed && !bad) {

@@ -92,7 +92,13 @@ static int run_control_file(const char *ctl, const char *ctl2, int32_t device, i
   }
   // loci shard in contiguous blocks of ceil(L / world) (OpenMP static scheduling of the reference, MultiCoreUtils.h:8)
   const int64_t per = (L + world - 1) / world, lb = std::min<int64_t>(rank * per, L), le = std::min<int64_t>((rank + 1) * per, L);
-  if (le <= lb) return fail(GPH_EARG, "more ranks than loci");
+  if ((int64_t)(world - 1) * per >= L) {
+    /* the same test on every rank: the whole job stops here, nobody is left waiting in an exchange */
+    if (lead) fprintf(stderr, "gphocs_hip: %d ranks over %lld loci in blocks of %lld leave the last rank(s) without loci -- use at most %lld ranks\n",
+                      world, (long long)L, (long long)per, (long long)((L + per - 1) / per));
+    return fail(GPH_EARG, "sharding the loci over the ranks");
+  }
+  (void)le;
   cfg.L_total = L;
   cfg.locus_begin = lb;
   cfg.device = device;

@@ -74,6 +74,9 @@ typedef int (*gph_allreduce_fn)(void *user, double *sums, int32_t nsum, double *
  *   RCCL: ncclAllGather of the reduced row over xGMI, queued on the engine's stream -- no host synchronisation;
  *         librccl is dlopen()ed on first use.  RCCL refuses two ranks on one GPU.
  *   shm:  host shared-memory exchange for ranks that share a GPU (tests on a 1-GPU box).
+ *   local: the ranks are THREADS of one process that share a device (tests on a 1-GPU box): the all-gather runs on
+ *         the engines' streams (HIP events order the device-to-device copies), so the device-resident world > 1
+ *         path -- reduction, gather, rank-order combine in k_global -- runs exactly as it does under RCCL.
  * rank 0 makes the id and hands it to the other ranks by any means (pipe, file, torch.distributed). */
 typedef struct gph_comm gph_comm;
 #define GPH_COMM_ID_BYTES 128
@@ -82,6 +85,11 @@ int gph_comm_unique_id(void *id128);
 gph_comm *gph_comm_create_rccl(const void *id128, int32_t rank, int32_t world, int32_t device);
 gph_comm *gph_comm_create_shm(const char *name, int32_t rank, int32_t world);   /* name "/unique-per-run", same on every rank */
 gph_comm *gph_comm_attach_shm(void *zeroed_shared_mapping, int32_t rank, int32_t world);
+/* thread ranks of one process on one device: one group per job, one communicator per rank (thread); the group is
+ * released with its last communicator */
+typedef struct gph_comm_group gph_comm_group;
+gph_comm_group *gph_comm_local_group(int32_t world, int32_t device);
+gph_comm *gph_comm_create_local(gph_comm_group *group, int32_t rank);
 size_t gph_comm_shm_bytes(int32_t world);
 void gph_comm_destroy(gph_comm *c);
 int gph_comm_world(const gph_comm *c);
@@ -193,6 +201,9 @@ int64_t gph_engine_num_loci(gph_engine *e);
 /* parity probe: out[5n] = exp(x), log(x), sqrt(|x|), x/y, floor(x) evaluated on the device */
 int gph_debug_math(const double *x, const double *y, int32_t n, double *out5n, int32_t device);
 int gph_engine_hbm_bytes(gph_engine *e, double *bytes);
+/* identity of this build of the library: hash of its sources and compiler flags (measurement files under profiles/
+ * carry it, and bench.py drops a committed counter measurement that was taken with another build) */
+const char *gph_build_id(void);
 
 /* ------------------------------------------------------------------------------------
  * host MCMC driver: the iteration body of performMCMC (GPhoCS.c:1476-1821) above the

@@ -19,6 +19,10 @@
  *   run   <ctl> <iters> <out.trace> [statefile] [state_iter]
  *                                    replay iterations, one record per proposal
  *   time  <ctl> <iters>              timed iterations (cpu_baseline)
+ *   timesweep <ctl> <iters> <warm> <t1,t2,...>
+ *                                    ONE start-up, then `iters` timed iterations per OpenMP thread count of the
+ *                                    list (omp_set_num_threads, as GPhoCS.c:145 does for `-n`): the cpu_baseline
+ *                                    at the benchmark's own data-set size without paying the start-up per count
  *   rng   <seed> <count>             RNG golden stream
  *   reflect                          reflect() golden table
  *   main  <args...>                  the reference's own main()
@@ -452,6 +456,46 @@ static int cmd_time(int argc, char **argv)
   return 0;
 }
 
+/* cpu_baseline at full size: start up once, time every thread count of the list on the running chain */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static int cmd_timesweep(int argc, char **argv)
+{
+  char *ctl = argv[2], *list = argc > 5 ? argv[5] : (char *)"1", *tok;
+  int iters = atoi(argv[3]), warm = atoi(argv[4]);
+  int it = 0, k, *acceptCountArray;
+  long evalsPerLocusIter;
+  double t0, t1, ts = now_s();
+  startup(ctl);
+  acceptCountArray = (int *)calloc(dataSetup.popTree->numPops, sizeof(int));
+  initializeMCMC();
+  printf("{\"startup_seconds\": %.3f, \"loci\": %d}\n", now_s() - ts, dataSetup.numLoci);
+  fflush(stdout);
+  evalsPerLocusIter = (dataSetup.numSamples - 1) + (2 * dataSetup.numSamples - 2) +
+                      (dataSetup.popTree->numPops - dataSetup.popTree->numCurPops) +
+                      (mcmcSetup.doMixing ? 1 : 0);
+  for (tok = strtok(list, ","); tok; tok = strtok(NULL, ",")) {
+    int threads = atoi(tok);
+    if (threads < 1) continue;
+#ifdef _OPENMP
+    omp_set_num_threads(threads);
+#else
+    threads = 1;
+#endif
+    for (k = 0; k < warm; k++, it++) one_iteration(NULL, it, acceptCountArray, 0);
+    t0 = now_s();
+    for (k = 0; k < iters; k++, it++) one_iteration(NULL, it, acceptCountArray, 0);
+    t1 = now_s();
+    printf("{\"threads\": %d, \"loci\": %d, \"iters\": %d, \"seconds\": %.6f, \"iters_per_s\": %.6f, "
+           "\"evals_per_s\": %.3f, \"nominal_evals_per_locus_iter\": %ld}\n",
+           threads, dataSetup.numLoci, iters, t1 - t0, iters / (t1 - t0),
+           (double)evalsPerLocusIter * dataSetup.numLoci * iters / (t1 - t0), evalsPerLocusIter);
+    fflush(stdout);
+  }
+  return 0;
+}
+
 /* ingest: wall time of the reference's own start-up path (readControlFile + readSeqFile +
  * processAlignments, GPhoCS.c:150-205): the CPU baseline of the sequence front end */
 static int cmd_ingest(char *ctl)
@@ -509,6 +553,7 @@ int main(int argc, char **argv)
   if (!strcmp(argv[1], "run") && argc >= 5) return cmd_run(argc, argv);
   if (!strcmp(argv[1], "unit") && argc >= 5) return cmd_unit(argc, argv);
   if (!strcmp(argv[1], "time") && argc >= 4) return cmd_time(argc, argv);
+  if (!strcmp(argv[1], "timesweep") && argc >= 5) return cmd_timesweep(argc, argv);
   if (!strcmp(argv[1], "ingest") && argc >= 3) return cmd_ingest(argv[2]);
   if (!strcmp(argv[1], "rng") && argc >= 4) return cmd_rng(argc, argv);
   if (!strcmp(argv[1], "reflect")) return cmd_reflect();

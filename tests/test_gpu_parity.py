@@ -373,3 +373,146 @@ def test_program_through_rccl_launcher(tmp_path, name):
             continue
         wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
         assert len(wf) == len(gf) and all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
+
+
+# ---------------------------------------------------------------- world > 1 on the device-resident path
+def _thread_ranks(G, pack_path, iters, world, tmp_path):
+    """`world` ranks as THREADS of this process on the one GPU, each with its engine over its block of loci and a
+    gph_comm_create_local() communicator: the all-gather of the reduced rows runs on the engines' streams (HIP events
+    order the copies), so flush_pending's multi-rank branch -- k_reduce_stage without the fused stage, the gather into
+    `world` rows, k_global combining them in rank order -- runs exactly as it does under RCCL over xGMI"""
+    import threading
+    pk = G.Pack.load(pack_path)
+    lib = G.load_library(dims=(pk.n, pk.K, pk.B))
+    group = lib.gph_comm_local_group(world, 0)
+    assert group
+    comms = [lib.gph_comm_create_local(group, r) for r in range(world)]
+    assert all(comms) and lib.gph_comm_kind(comms[0]) == b"local" and lib.gph_comm_on_stream(comms[0]) == 1
+    out, errs, stats = [str(tmp_path / f"rec.{r}") for r in range(world)], [], [None] * world
+
+    def work(r):
+        try:
+            s = G.Sampler(pk, lib=lib, rank=r, world=world, comm=comms[r])
+            s.set_record_file(out[r])
+            s.initialize()
+            for it in range(iters):
+                s.iteration(it)
+            s.dump_state(out[r] + ".state", True)
+            s.set_record_file(None)
+            stats[r] = s.host_stats()
+            s.close()
+        except Exception as ex:  # a failed rank must not leave the others waiting: destroying its communicator releases them
+            errs.append((r, ex))
+            lib.gph_comm_destroy(comms[r])
+            comms[r] = None
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    for c in comms:
+        if c:
+            lib.gph_comm_destroy(c)
+    assert not errs, errs
+    return out, stats
+
+
+@pytest.mark.parametrize("name,world", [("m3", 2), ("a7", 2), ("m4", 3), ("a6", 2)])
+def test_thread_ranks_run_the_resident_multi_rank_path(G, tmp_path, name, world):
+    """world > 1 with the decisions on the device, on a one-GPU box: every rank writes the single-rank golden's records
+    (rubber-band conflicts with the min-reduced first conflicting locus, sample-age moves, checkAll included), the
+    shards' final states concatenate to the golden state, one host synchronisation per iteration"""
+    iters = CASES[name]
+    out, stats = _thread_ranks(G, os.path.join(GOLDEN, name + ".gpk"), iters, world, tmp_path)
+    for r in range(1, world):
+        assert open(out[0]).read() == open(out[r]).read()
+    compare_records(out[0], os.path.join(GOLDEN, name + ".rtrace"))
+    for hs in stats:
+        assert hs["resident"] and hs["collectives"] >= 4 * iters and hs["syncs"] <= iters + 8, hs
+    # per-locus state: the ranks' dumps, in rank order, are the golden's LOCUS blocks
+    def blocks(path):
+        txt = open(path).read()
+        return txt[txt.index("LOCUS "):txt.rindex("ENDSTATE")]
+    joined = tmp_path / "joined.state"
+    gold = open(os.path.join(GOLDEN, name + ".state")).read()
+    joined.write_text(gold[:gold.index("LOCUS ")] + "".join(blocks(o + ".state") for o in out) + "ENDSTATE\n")
+    compare_states(str(joined), os.path.join(GOLDEN, name + ".state"), skip_global=True)
+
+
+def _ndev():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("name", ["m3", "a7", "v8"])
+def test_launcher_two_real_rccl_ranks(tmp_path, name):
+    """`G-PhoCS-hip -g 2` with one GPU per rank: ncclCommInitRank with world 2, the stream-queued all-gather over
+    xGMI between k_reduce_stage and k_global -- the real binary's trace file.  Needs a box with >= 2 GPUs."""
+    if _ndev() < 2:
+        pytest.skip("one GPU on this box: RCCL wants one GPU per rank (the thread-rank test covers the same engine path)")
+    import shutil
+    exe = os.path.join(REPO, "g-phocs_amd", "G-PhoCS-hip")
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    r = subprocess.run([exe, "-g", "2", "-v", name + ".ctl"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "shared-memory exchange" not in r.stdout
+    want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
+    got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
+    assert want[0] == got[0] and len(want) == len(got)
+    for w, g in zip(want[1:], got[1:]):
+        if w == g:
+            continue
+        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
+        assert len(wf) == len(gf) and all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
+
+
+def test_bench_two_real_rccl_ranks():
+    """`python bench.py --gpus 2` (no launcher around it) on a box with >= 2 GPUs: two ranks, RCCL communicator of
+    world 2 as RCCL reports it, device-resident decisions, the counters of the one-rank run"""
+    if _ndev() < 2:
+        pytest.skip("one GPU on this box")
+    import json
+    args = ["--loci", "4000", "--preroll", "4", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    lines = []
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n)] + args, capture_output=True,
+                           text=True, timeout=1800, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert len(r.stdout.strip().splitlines()) == 1
+        lines.append(json.loads(r.stdout))
+    one, two = lines
+    c = two["config"]
+    assert two["n_gpus"] == 2 and c["loci_this_rank"] == 2000 and c["communicator"] == "rccl" and c["communicator_world"] == 2
+    assert c["decisions"].startswith("device-resident") and c["host_syncs_per_iteration"] <= 1.01
+    assert c["evals_timed"] == one["config"]["evals_timed"]
+    assert c["accept_counts_timed"] == one["config"]["accept_counts_timed"]
+
+
+@pytest.mark.parametrize("name", ["m3", "a7", "g2", "v8"])
+def test_plain_build_parity(G, tmp_path, name):
+    """the control build WITHOUT the backend switches the hot path is tuned with (-disable-machine-licm,
+    -structurizecfg-skip-uniform-regions, max-ilp scheduling): same goldens, and byte-identical records to the tuned
+    build -- a compiler whose uniformity analysis or M0 usage breaks an assumption of the tuned build shows here"""
+    plain = os.path.join(REPO, "g-phocs_amd", G.PLAIN_LIB)
+    assert os.path.exists(plain)
+    lib = G.load_library(plain)
+    assert lib.gph_build_id().decode().startswith("plain-")
+    pk = G.Pack.load(os.path.join(GOLDEN, name + ".gpk"))
+    recs = []
+    for tag, l in (("plain", lib), ("tuned", G.load_library(dims=(pk.n, pk.K, pk.B)))):
+        s = G.Sampler(pk, lib=l)
+        p = str(tmp_path / f"{tag}.rec")
+        s.set_record_file(p)
+        s.initialize()
+        for it in range(CASES[name]):
+            s.iteration(it)
+        s.dump_state(p + ".state", True)
+        s.set_record_file(None)
+        s.close()
+        recs.append(p)
+    compare_records(recs[0], os.path.join(GOLDEN, name + ".rtrace"))
+    compare_states(recs[0] + ".state", os.path.join(GOLDEN, name + ".state"))
+    assert open(recs[0]).read() == open(recs[1]).read()
+    assert open(recs[0] + ".state").read() == open(recs[1] + ".state").read()
