@@ -305,6 +305,9 @@ def _load_library(path):
     lib.gph_comm_create_local.restype = C.c_void_p
     lib.gph_comm_world.argtypes = [C.c_void_p]
     lib.gph_comm_rank.argtypes = [C.c_void_p]
+    lib.gph_comm_on_stream.argtypes = [C.c_void_p]
+    lib.gph_comm_attach_shm.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.gph_comm_attach_shm.restype = C.c_void_p
     return lib
 
 

@@ -374,10 +374,8 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   y.o_coal = OFS(coal); y.o_migst = OFS(migst); y.o_rb_age = OFS(rb_age); y.o_fscal = OFS(fscal);
   y.o_iscal = OFS(iscal);
   y.o_nev = OFS(nev);
-  y.o_changed = OFS(changed); y.o_changedc = OFS(changedc);
   y.o_first = OFS(first);
   y.o_mig_i = OFS(mig_i); y.o_living = OFS(living); y.o_ncoal = OFS(ncoal); y.o_nmig = OFS(nmig); y.o_rb_i = OFS(rb_i);
-  y.o_condbit = OFS(condbit); y.o_dirty = OFS(dirty);
   y.page_bytes = align_up(OFS(s_dcoal), 16);
 #undef OFS
   // dynamic LDS: the locus' sequence block (same bytes as its HBM block, laid out by its own P: GPH_Q_* in
@@ -1729,7 +1727,7 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
     const GphNode *nd = (const GphNode *)(pg + y.o_nd);
     const int16_t *ne = (const int16_t *)(pg + y.o_nev);
     const int16_t *first = (const int16_t *)(pg + y.o_first);
-    const uint8_t *cbit = (const uint8_t *)(pg + y.o_condbit);
+    const uint64_t cbits = (uint64_t)(uint32_t)is[IS_CBIT0] | ((uint64_t)(uint32_t)is[IS_CBIT1] << 32);
     const GphEv *evr = (const GphEv *)(pg + y.o_ev);
     fprintf(f, "LOCUS %lld root %d dataLnL %a genLnL %a rng %u %u %u\n", (long long)(go + e->cfg.locus_begin), is[IS_ROOT],
             fs[FS_DATALNL], fs[FS_GENLNL], (unsigned)is[IS_RX], (unsigned)is[IS_RY], (unsigned)is[IS_RZ]);
@@ -1761,7 +1759,7 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
       int P = e->h_P[g];
       const char *cb = cond.data() + e->h_cond_off[g];
       for (int i = y.n; i < y.N; i++) {
-        const double *c = (const double *)(cb + ((size_t)(cbit[i] * (y.n - 1) + (i - y.n)) * P) * 32);
+        const double *c = (const double *)(cb + ((size_t)((int)((cbits >> i) & 1) * (y.n - 1) + (i - y.n)) * P) * 32);
         fprintf(f, "K %d", i);
         for (int k = 0; k < 4 * P; k++) fprintf(f, " %a", c[k]);
         fprintf(f, "\n");

@@ -27,6 +27,15 @@ template <bool GPH_GM> struct GphCtxT {
   }
 #endif
   GphPad<IS_COUNT + CN_COUNT + SI_COUNT> r_pad;     /* GPH_PADGET / GPH_PADSET, gph_rt.h */
+  // node sets of the saved version (LocusDataLikelihood.c:75-104: recalcConditionals[], changedNodeIds[] /
+  // changedCondIds[]) and the double buffer's current halves, bit = genealogy node: wave-uniform 64-bit scalars for
+  // as long as a kernel works on the locus, held in lane pairs of the scalar pad (page words IS_DIRTY / IS_CBIT /
+  // IS_SAVED): a read is two lane reads, no LDS round trip.  Marking a node, resetSaved and the conditional half of
+  // revertToSaved are a few scalar instructions; the reference's two id lists are not kept at all (a list is only
+  // ever walked to visit the members of the set).
+#define m_dirty_get() pad64(IS_DIRTY0)
+#define m_cbit_get() pad64(IS_CBIT0)
+#define m_saved_get() pad64(IS_SAVED0)
 
 // ---------------------------------------------------------------- accessors
 #define AGE(i) (gph_lds.nd[i].age)
@@ -58,8 +67,6 @@ template <bool GPH_GM> struct GphCtxT {
 #define SVF(i) RFL((int)gph_lds.sv[i].father)
 #define SVL(i) RFL((int)gph_lds.sv[i].left)
 #define SVR(i) RFL((int)gph_lds.sv[i].right)
-#define CHG(i) gi16(&GphLds::changed, (i))
-#define CHGC(i) gi16(&GphLds::changedc, (i))
 #define ENEXT(e) RFL((int)gph_lds.ev[e].next)
 #define setENEXT(e, v) (gph_lds.ev[e].next = (int16_t)(v))
 #define EPREV(e) RFL((int)gph_lds.ev[e].prev)
@@ -84,10 +91,7 @@ template <bool GPH_GM> struct GphCtxT {
 #define setRBI(k, i, v) si16(&GphLds::rb_i, (k) * GPH_CAP_RB + (i), (v))
 #define ISC(k) GPH_PADGET(k)
 #define setISC(k, v) GPH_PADSET((k), (v))
-#define CBIT(i) gu8(&GphLds::condbit, (i))
-#define setCBIT(i, v) su8(&GphLds::condbit, (i), (v))
-#define DIRTY(i) gu8(&GphLds::dirty, (i))
-#define setDIRTY(i, v) su8(&GphLds::dirty, (i), (v))
+#define CBIT(i) ((int)((m_cbit_get() >> (i)) & 1))
 // scratch
 #define DEV(inst, i) RFL((int)gph_lds.s_dev[inst][i])
 #define setDEV(inst, i, v) (gph_lds.s_dev[inst][i] = (uint8_t)(v))
@@ -208,6 +212,8 @@ GPH_DEV void gph_fail(int code) { if (CNT(CN_ERROR) == 0) setCNT(CN_ERROR, code)
 GPH_DEV int gph_failed() { return CNT(CN_ERROR) != 0; }
 GPH_DEV int gph_errcode() { return CNT(CN_ERROR); }
 
+#define pad64(k) ((uint64_t)(uint32_t)ISC(k) | ((uint64_t)(uint32_t)ISC((k) + 1) << 32))
+#define setpad64(k, v) do { const uint64_t pv64_ = (v); setISC((k), (int)(uint32_t)pv64_); setISC((k) + 1, (int)(uint32_t)(pv64_ >> 32)); } while (0)
 GPH_DEV void load_scalars() { r_pad.load(gph_lds.iscal, IS_COUNT); }
 GPH_DEV void flush_scalars() { r_pad.store(gph_lds.iscal, IS_COUNT); }
 
@@ -376,26 +382,21 @@ GPH_DEV double l_reflect(double x, double a, double b)
 }
 
 // ---------------------------------------------------------------- data likelihood
-// copyNodeConditionals, LocusDataLikelihood.c:1889-1906
+// copyNodeConditionals, LocusDataLikelihood.c:1889-1906: a node not yet marked in this proposal switches to the other
+// half of its double buffer
 GPH_DEV int lik_mark_cond(int node)
 {
-  int k;
-  if (CNT(CN_P) <= 0 || DIRTY(node)) return 1;
-  k = ISC(IS_NCHANGEDC);
-  si16(&GphLds::changedc, k, node);
-  setISC(IS_NCHANGEDC, k + 1);
-  setDIRTY(node, 1);
-  setCBIT(node, CBIT(node) ^ 1);
+  const uint64_t bit = (uint64_t)1 << node, d = m_dirty_get();
+  if (CNT(CN_P) <= 0 || (d & bit)) return 1;
+  setpad64(IS_DIRTY0, d | bit);
+  setpad64(IS_CBIT0, m_cbit_get() ^ bit);
   return 0;
 }
 // copyNodeToSaved, LocusDataLikelihood.c:1864-1876
 GPH_DEV void lik_save_node(int node, int recalc)
 {
-  int k;
   if (recalc) lik_mark_cond(node);
-  k = ISC(IS_NCHANGED);
-  si16(&GphLds::changed, k, node);
-  setISC(IS_NCHANGED, k + 1);
+  setpad64(IS_SAVED0, m_saved_get() | ((uint64_t)1 << node));
   gph_lds.sv[node] = gph_lds.nd[node];   /* one 16-byte record: age, father, left, right */
 }
 // adjustGenNodeAge, LocusDataLikelihood.c:875-882
@@ -407,50 +408,32 @@ GPH_DEV void lik_adjust_age(int node, double age)
 // resetSaved, LocusDataLikelihood.c:852-864
 GPH_DEV void lik_reset_saved()
 {
-  int i;
-  setISC(IS_COPYALL, 0);
-  setISC(IS_NCHANGED, 0);
-  setISC(IS_NCHANGEDC, 0);
+  setISC(IS_SAVED0, 0); setISC(IS_SAVED1, 0);
+  setISC(IS_DIRTY0, 0); setISC(IS_DIRTY1, 0);
   setISC(IS_SV_ROOT, -1);
   setFS(FS_SV_DATALNL, FS(FS_DATALNL));
-  (void)i;
-  GPH_EACH1(k, g_lay.N) gph_lds.dirty[k] = 0;   /* one lane per node */
 }
-// revertToSaved, LocusDataLikelihood.c:768-841 (value semantics: a node's saved
-// record and its previous conditional array are restored)
+// revertToSaved, LocusDataLikelihood.c:768-841 (value semantics: a node's saved record and its previous conditional
+// array are restored).  Every saved node on its own lane: one 16-byte copy each, all at once (the reference walks
+// changedNodeIds[]; the copyAll case of mixing is the same thing with every node in the set).  Every node whose
+// conditionals were recomputed goes back to the other half of its double buffer.
 GPH_DEV void lik_revert()
 {
-  int i, node, nc, ncc;
   setFS(FS_DATALNL, FS(FS_SV_DATALNL));
   if (ISC(IS_SV_ROOT) >= 0) { setISC(IS_ROOT, ISC(IS_SV_ROOT)); setISC(IS_SV_ROOT, -1); }
-  if (ISC(IS_COPYALL)) {
-    for (node = 0; node < g_lay.N; node++) {
-      setAGE(node, SVAGE(node));
-      setFATH(node, SVF(node));
-      setLEFT(node, SVL(node));
-      setRGHT(node, SVR(node));
-      if (DIRTY(node)) setCBIT(node, CBIT(node) ^ 1);
+  const uint64_t sv_ = m_saved_get();
+  if (sv_ != 0) {
+    GPH_EACH1(k, g_lay.N) {
+      if ((sv_ >> k) & 1) {
+        GphNode r = gph_lds.sv[k];
+        r.npop = gph_lds.nd[k].npop;     /* nodePops is not part of the saved version */
+        gph_lds.nd[k] = r;
+      }
     }
-    lik_reset_saved();
-    return;
   }
-  nc = ISC(IS_NCHANGED);
-  ncc = ISC(IS_NCHANGEDC);
-  if (nc == 0 && ncc == 0) return;
-  for (i = 0; i < nc; i++) {
-    node = CHG(i);
-    setAGE(node, SVAGE(node));
-    setFATH(node, SVF(node));
-    setLEFT(node, SVL(node));
-    setRGHT(node, SVR(node));
-    if (DIRTY(node)) { setCBIT(node, CBIT(node) ^ 1); setDIRTY(node, 0); }
-  }
-  for (i = 0; i < ncc; i++) {
-    node = CHGC(i);
-    if (DIRTY(node)) { setCBIT(node, CBIT(node) ^ 1); setDIRTY(node, 0); }
-  }
-  setISC(IS_NCHANGED, 0);
-  setISC(IS_NCHANGEDC, 0);
+  setpad64(IS_CBIT0, m_cbit_get() ^ m_dirty_get());
+  setISC(IS_DIRTY0, 0); setISC(IS_DIRTY1, 0);
+  setISC(IS_SAVED0, 0); setISC(IS_SAVED1, 0);
 }
 
 // computeEdgeConditionalJC, LocusDataLikelihood.c:1831-1848
@@ -735,11 +718,10 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   if (isnode) me = gph_lds.nd[lane];    /* the lane's node record: one 16-byte read */
   const int le = me.left, ri = me.right;
   const double ag = me.age;
-  uint64_t dirty = __ballot(isnode && gph_lds.dirty[lane] != 0);
-  uint64_t cbit = __ballot(isnode && gph_lds.condbit[lane] != 0);
+  uint64_t dirty = m_dirty_get(), cbit = m_cbit_get();
   const uint64_t internal = (((uint64_t)1 << N) - 1) & ~(((uint64_t)1 << n) - 1);
-  uint64_t newly = 0, need, todo;
-  if (!useOld) { newly = internal & ~dirty; dirty |= internal; cbit ^= newly; }
+  uint64_t need, todo;
+  if (!useOld) { cbit ^= internal & ~dirty; dirty |= internal; }
   setFS(FS_SV_DATALNL, FS(FS_DATALNL));
   if (!useOld) {
     need = internal;
@@ -772,7 +754,9 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   const int lc = lane < P ? lane : P - 1;
   /* copyNodeConditionals (LocusDataLikelihood.c:1889) of every node that is going to be recomputed, all at once:
    * a node not yet dirty in this proposal switches to its other array */
-  if (useOld) { const uint64_t flip = todo & ~dirty; dirty |= flip; cbit ^= flip; newly |= flip; }
+  if (useOld) { const uint64_t flip = todo & ~dirty; dirty |= flip; cbit ^= flip; }
+  setpad64(IS_DIRTY0, dirty);
+  setpad64(IS_CBIT0, cbit);
   /* offset (in doubles) of the lane's node's current array */
   const int coff = (((int)((cbit >> lane) & 1)) * (n - 1) + (lane - n)) * P * 4;
   const int fal = me.father;
@@ -851,18 +835,6 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   }
   if (failed) { gph_fail(100); return FS(FS_DATALNL); }
   setCNT(CN_NODES, CNT(CN_NODES) + nord);
-  STAMPB_BEGIN(3);
-  /* write the dirty / current-buffer sets back, append the newly marked nodes to the list */
-  if (isnode) {
-    gph_lds.dirty[lane] = (uint8_t)((dirty >> lane) & 1);
-    gph_lds.condbit[lane] = (uint8_t)((cbit >> lane) & 1);
-    if ((newly >> lane) & 1) {
-      int pos = ISC(IS_NCHANGEDC) + __builtin_popcountll(newly & (((uint64_t)1 << lane) - 1));
-      gph_lds.changedc[pos] = (int16_t)lane;
-    }
-  }
-  setISC(IS_NCHANGEDC, ISC(IS_NCHANGEDC) + __builtin_popcountll(newly));
-  STAMPB_END(3);
   STAMPB_BEGIN(4);
   /* root reduction, LocusDataLikelihood.c:466-479: per unphased pattern
    * log(sum over phases and bases / (4*phases)) * count, summed in pattern order */
@@ -931,7 +903,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   const int n = g_lay.n, N = g_lay.N;
   (void)warm;
   useOld = RFL(useOld);
-  int P = CNT(CN_P), i, node, k, sp, nord, ncc, U;
+  int P = CNT(CN_P), i, node, k, sp, nord, U;
   uint64_t need = 0;
   double lnl;
   if (P == 0) return 0.0;
@@ -942,9 +914,9 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   if (!useOld) {
     for (node = n; node < N; node++) need |= (uint64_t)1 << node;
   } else {
-    ncc = ISC(IS_NCHANGEDC);
-    for (i = 0; i < ncc; i++) {
-      node = CHGC(i);
+    for (i = 0; i < N; i++) {
+      if (!((m_dirty_get() >> i) & 1)) continue;
+      node = i;
       int guard = 0;
       while (node >= 0 && !((need >> node) & 1)) {
         need |= (uint64_t)1 << node;
@@ -1173,7 +1145,6 @@ GPH_DEV double lik_scale_ages(double factor)
 {
   int node;
   double old = FS(FS_DATALNL);
-  setISC(IS_COPYALL, 1);
   for (node = 0; node < g_lay.N; node++) lik_adjust_age(node, factor * AGE(node));
   lik_compute(1);
   return FS(FS_DATALNL) - old;

@@ -10,7 +10,7 @@
 //            read it.  Loci the serial reference would never have touched after
 //            a migration conflict keep their main page.
 //   cond   : per locus [2][n-1][P][4] fp64 conditional likelihoods of the internal
-//            nodes (double buffer, the page's condbit[node] selects the current
+//            nodes (double buffer, bit `node` of the page's IS_CBIT set selects the current
 //            half) -- leaves are not stored as doubles: a leaf is a base code.
 //   seq    : per locus leaf codes u8[P][n], phases u16[P], counts i32[P] (read-only).
 //
@@ -28,7 +28,7 @@
 #define GPH_OLDAGE 999.0   // patch.h:21
 #define GPH_WAVE 64
 #define FS_COUNT_ 5
-#define IS_COUNT_ 12
+#define IS_COUNT_ 16
 
 enum { GPH_COAL = 0, GPH_IN_MIG, GPH_OUT_MIG, GPH_MIG_BAND_START, GPH_MIG_BAND_END,
        GPH_SAMPLES_START, GPH_END_CHAIN, GPH_DUMMY };
@@ -62,13 +62,10 @@ struct GphLayout {
   int32_t o_mig_age, o_coal, o_migst, o_rb_age, o_fscal;
   // i16
   int32_t o_nev;
-  int32_t o_changed, o_changedc;
   int32_t o_first;
   int32_t o_mig_i, o_living, o_ncoal, o_nmig, o_rb_i;
   // i32
   int32_t o_iscal;
-  // u8
-  int32_t o_condbit, o_dirty;
   int32_t page_bytes;      // multiple of 16: the page part of GphLds
   int32_t Pmax;            // max phased patterns of any locus on this device
   int32_t lds_bytes;       // largest dynamic-LDS allocation of a launch (sequence block [+ terms])
@@ -112,7 +109,11 @@ enum { CN_EVALS = 0, CN_NODES, CN_ERROR, CN_P, CN_NOTENOUGH, CN_COUNT };
 // f64 scalars in the page (index into o_fscal)
 enum { FS_DATALNL = 0, FS_SV_DATALNL, FS_GENLNL, FS_GENDELTA, FS_MUTRATE, FS_COUNT };
 // i32 scalars in the page (index into o_iscal)
-enum { IS_ROOT = 0, IS_SV_ROOT, IS_COPYALL, IS_NCHANGED, IS_NCHANGEDC, IS_FREE, IS_NUM_MIGS,
+// IS_DIRTY / IS_CBIT / IS_SAVED: three 64-bit node sets (bit = genealogy node), two words each -- the nodes whose
+// conditionals were recomputed by the pending proposal (savedVersion.recalcConditionals, LocusDataLikelihood.c:75-104),
+// the half of the double buffer that holds each node's CURRENT conditionals, and the nodes whose record was saved
+// (savedVersion.changedNodeIds).  While a kernel works on the locus they are three scalar registers (GphCtx).
+enum { IS_ROOT = 0, IS_SV_ROOT, IS_DIRTY0, IS_DIRTY1, IS_CBIT0, IS_CBIT1, IS_SAVED0, IS_SAVED1, IS_FREE, IS_NUM_MIGS,
        IS_RB_NUM, IS_CONFLICT_LOG, IS_RX, IS_RY, IS_RZ, IS_COUNT };
 // i16 fields per migration node (o_mig_i + 6*mig)
 enum { MG_BRANCH = 0, MG_BAND, MG_SPOP, MG_TPOP, MG_SEV, MG_TEV, MG_COUNT };
@@ -169,10 +170,8 @@ struct alignas(16) GphLds {
   double coal[GPH_CAP_K], migst[GPH_CAP_B], rb_age[GPH_CAP_RB], fscal[FS_COUNT_];
   int32_t iscal[IS_COUNT_];
   int16_t nev[GPH_CAP_N];
-  int16_t changed[2 * GPH_CAP_N], changedc[2 * GPH_CAP_N];
   int16_t first[GPH_CAP_K];
   int16_t mig_i[GPH_MAX_MIGS * 6], living[GPH_MAX_MIGS], ncoal[GPH_CAP_K], nmig[GPH_CAP_B], rb_i[3 * GPH_CAP_RB];
-  uint8_t condbit[GPH_CAP_N], dirty[GPH_CAP_N];
   // ---- LDS-only scratch: pending-proposal storage of GENETREE_STATS_DELTA x2 (patch.h:60-72),
   // MIG_SPR_STATS (patch.h:97-105), genetree_stats_check (patch.h:109), pruning work lists
   double s_dcoal[2][GPH_CAP_K], s_dmig[2][GPH_CAP_B], s_sprf[GPH_MAX_MIGS + 2];

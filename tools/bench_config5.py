@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[4] at its stated size: 200 000 loci x 1 kb, 10 diploid samples (20 leaves), 7-population tree,
-4 migration bands, one fixed ancient sample (library variant `l`).  python tools/bench_config5.py [lib.so] [loci]"""
+4 migration bands, one fixed ancient sample (library variant `l`).  python tools/bench_config5.py [lib.so] [loci] [preroll]
+Same protocol as bench.py: an untimed pre-roll (default 200 iterations) before 5 warm-up and 10 timed iterations."""
 import json, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -10,15 +11,16 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
 pack = bench.build_workload(G, 5, L, 6.5, 20261007, os.path.join(REPO, "bench_cache"))
 lib = G.load_library(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "-" else G.load_library(dims=(pack.n, pack.K, pack.B))
 s = G.Sampler(pack, lib=lib)
+PRE = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 s.initialize()
-for it in range(5):
+for it in range(PRE + 5):
     s.iteration(it)
 s.counters(reset=True)
 for k in range(16):
     s.class_stats(k, reset=True)
 t0 = time.perf_counter()
 N = 10
-for it in range(5, 5 + N):
+for it in range(PRE + 5, PRE + 5 + N):
     s.iteration(it)
 dt = time.perf_counter() - t0
 c = s.counters()
@@ -29,5 +31,6 @@ print(json.dumps({"workload": f"BASELINE configs[4]: {L} loci, 20 leaves, 13 pop
                   "evals_per_s": c["evals"] / dt, "iters_per_s": N / dt, "ms_per_iteration": dt / N * 1e3,
                   "sweep_ms": sw["ms"] / sw["launches"], "sweep_algorithmic_bytes": sw["bytes"] / sw["launches"],
                   "sweep_roofline_frac": sw["bytes"] / sw["launches"] / (sw["ms"] / sw["launches"] * 1e-3) / 8e12,
-                  "tau_eval_ms": te["ms"] / max(te["launches"], 1), "hbm_resident_bytes": s.hbm_bytes()}))
+                  "tau_eval_ms": te["ms"] / max(te["launches"], 1), "hbm_resident_bytes": s.hbm_bytes(),
+                  "preroll_iterations": PRE, "library_build_id": lib.gph_build_id().decode()}))
 s.close()

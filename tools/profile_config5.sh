@@ -4,6 +4,8 @@
 #   bash tools/profile_config5.sh  ->  gpurun_out/config5_*.{json,csv}
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; export TMPDIR=/tmp
+# every pass is ONE run into an EMPTY directory (the r02 summary merged two runs)
+rm -rf $OUT/config5_kstats $OUT/config5_pmc
 python3 tools/bench_config5.py > $OUT/config5_bench.json 2> $OUT/config5_bench.err
 echo "bench rc=$?"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/config5_kstats -o k --output-format csv -- python3 $ROOT/tools/bench_config5.py > $OUT/config5_kstats.log 2>&1)

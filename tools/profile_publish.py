@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Copy the outputs of tools/profile_round.sh <tag> from gpurun_out/ into profiles/ (the committed evidence):
 bench line (with the measured HBM traffic filled in), kernel stats, counter summary, traffic_k_sweep.json.
-   python3 tools/profile_publish.py <tag> [round-prefix, default r02]"""
+   python3 tools/profile_publish.py <tag> [round-prefix, default r03]
+traffic_k_sweep.json carries the build id of the library the counters were taken with (bench line: library_build_id);
+bench.py uses the file only for that build."""
 import json
 import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 d = json.load(open(f"gpurun_out/pmc_{tag}.json"))
 k = [x for x in d if "k_sweep" in x][0]
 s = d[k]
@@ -18,15 +20,19 @@ n = s["SQ_WAVES"]["sum"]
 print("k_sweep dispatches", nd, "fetch GB %.2f write GB %.2f" % (fetch / 1e9, write / 1e9))
 for c in sorted(s):
     print("%-22s per wave %12.1f" % (c, s[c]["sum"] / n))
+b = json.load(open(f"gpurun_out/bench_{tag}.json"))
+build_id = b["config"].get("library_build_id")
 json.dump({"kernel": "k_sweep", "loci": 100000, "hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch,
-           "write_bytes": write, "build": f"{rnd} {tag}, library variant s",
+           "write_bytes": write, "build": f"{rnd} {tag}, library variant s", "build_id": build_id,
+           "valu_per_wave": s["SQ_INSTS_VALU"]["sum"] / n, "salu_per_wave": s["SQ_INSTS_SALU"]["sum"] / n,
+           "lds_per_wave": s["SQ_INSTS_LDS"]["sum"] / n, "smem_per_wave": s["SQ_INSTS_SMEM"]["sum"] / n,
+           "wave_cycles_per_wave": s["SQ_WAVE_CYCLES"]["sum"] / n,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_collect.sh): "
                      "FETCH_SIZE(KB)*1024*2 (gfx950 correction) + WRITE_SIZE(KB)*1024 per k_sweep dispatch (one "
                      f"dispatch per sweep), averaged over the {nd} dispatches of a 200-iteration pre-roll + 4 iterations"},
           open("profiles/traffic_k_sweep.json", "w"), indent=1)
 shutil.copy(f"gpurun_out/pmc_{tag}.json", f"profiles/{rnd}_pmc_{tag}.json")
 shutil.copy(f"gpurun_out/kstats_{tag}/k_kernel_stats.csv", f"profiles/{rnd}_bench_kernel_stats_{tag}.csv")
-b = json.load(open(f"gpurun_out/bench_{tag}.json"))
 b["roofline"]["traffic"] = fetch + write
 b["roofline"]["traffic_source"] = f"profiles/traffic_k_sweep.json ({rnd} {tag}: rocprofv3 --pmc passes of the same command on the same box)"
 b["roofline"]["hbm_counter_frac"] = (fetch + write) / (b["roofline"]["avg_launch_ms"] * 1e-3) / 8e12
