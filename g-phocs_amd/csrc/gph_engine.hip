@@ -45,9 +45,9 @@ GphGlobal *gph_G_emu = nullptr;
 // device-resident chain state KA.G (everything launched after a decision the host has not seen yet)
 GPH_KERNEL(k_init, GphKargs KA, GphDev D, int j0, uint32_t seedz, const double *mutRate, int preDraws) { GphCtxG lx; lx.kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0, preDraws); }
 GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphKargs KA, GphDev D, int j0, int flags, double ftCoal, double ftMig) { GphCtx lx; lx.kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
-GPH_KERNEL(k_tau_eval, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_tau_eval(D, j0 + GPH_BLK, GPH_G->tau); }
+GPH_KERNEL(k_tau_eval, GphKargs KA, GphDev D, int j0, int fuse) { GphCtxG lx; lx.kb_tau_eval(D, j0 + GPH_BLK, GPH_G->tau, fuse); }
 GPH_KERNEL(k_tau_finish, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_tau_finish(D, j0 + GPH_BLK); }
-GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_mix_eval(D, j0 + GPH_BLK, GPH_G->mix_c); }
+GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, int fuse) { GphCtxG lx; lx.kb_mix_eval(D, j0 + GPH_BLK, GPH_G->mix_c, fuse); }
 GPH_KERNEL(k_mix_finish, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_mix_finish(D, j0 + GPH_BLK); }
 GPH_KERNEL(k_sync, GphKargs KA, GphDev D, int j0, int refresh) { GphCtxG lx; lx.kb_sync(D, j0 + GPH_BLK, refresh); }
 GPH_KERNEL(k_check, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_check(D, j0 + GPH_BLK); }
@@ -1101,7 +1101,7 @@ int gph_engine_tau_evaluate(gph_engine *e, const gph_tau_args *a, gph_tau_result
   }
   int rc = push_G(e);
   if (rc) return rc;
-  LAUNCH(e, 1, k_tau_eval, 0);
+  LAUNCH(e, 1, k_tau_eval, 0);     /* stepwise: the finish of the previous proposal was a call of its own */
   if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
   if ((rc = run_stage_now(e, GS_COUNT_ONLY, 1))) return rc;
   // first conflicting locus in serial (input) order: loci after it were never touched by
@@ -1121,6 +1121,7 @@ int gph_engine_tau_commit(gph_engine *e)
   SETDEV(e);
   e->G_h->tau_flag = 1;
   e->G_h->tau_limit = (long long)1 << 62;
+  gg_fill_fin(*e->G_h, 1, e->G_h->tau_limit);
   int rc = push_G(e);
   if (rc) return rc;
   LAUNCH(e, 5, k_tau_finish, 0);
@@ -1133,6 +1134,7 @@ int gph_engine_tau_revert(gph_engine *e, int64_t first_conflict)
   SETDEV(e);
   e->G_h->tau_flag = 0;
   e->G_h->tau_limit = first_conflict >= 0 ? (long long)first_conflict : (long long)1 << 62;
+  gg_fill_fin(*e->G_h, 0, e->G_h->tau_limit);
   int rc = push_G(e);
   if (rc) return rc;
   LAUNCH(e, 5, k_tau_finish, 0);
@@ -1605,32 +1607,43 @@ int gph_engine_iteration_(gph_engine *e, int32_t iteration, const double *lr_alp
    * per-locus touch-ups of the accepted theta / migration-rate proposals */
   if (Kc < K && (rc = run_stage(e, GS_TAU_PROPOSE, Kc, iteration))) return rc;
   if ((rc = apply_list(e))) return rc;
+  /* the commit / revert of a decided proposal rides at the head of the NEXT evaluate kernel (the next population's,
+   * or mixing's): the decision stage froze what it needs in the chain state (GphTauFin), and the stage that proposes
+   * the next move goes out in the same launch as the decision.  fin = a finish is owed; GPH_NO_FUSE=1 (tests) runs
+   * every finish as a kernel of its own, as the stepwise entry points do */
+  const bool no_fuse = getenv("GPH_NO_FUSE") && atoi(getenv("GPH_NO_FUSE")) != 0;
+  int fin = 0;
+  auto finish_now = [&]() -> int { if (fin) { fin = 0; LAUNCH(e, 5, k_tau_finish, 0); } return 0; };
   for (int ap = Kc; ap < K; ++ap) {
     if (ap > Kc && (rc = run_stage(e, GS_TAU_PROPOSE, ap, iteration))) return rc;
-    LAUNCH(e, 1, k_tau_eval, 0);
+    if (no_fuse && (rc = finish_now())) return rc;
+    { const int fuse = fin; fin = 0; LAUNCH(e, 1, k_tau_eval, fuse); }
     if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
     if ((rc = run_stage(e, GS_TAU_DECIDE, ap, iteration))) return rc;
-    LAUNCH(e, 5, k_tau_finish, 0);
+    fin = 1;
   }
   if ((rc = run_stage(e, GS_TAU_END, 0, iteration))) return rc;
   for (int pop = 0; pop < Kc; ++pop) {
     if (!Gh.updateSampleAge[pop]) continue;
     if ((rc = run_stage(e, GS_SAGE_PROPOSE, pop, iteration))) return rc;
-    LAUNCH(e, 1, k_tau_eval, 0);
+    if (no_fuse && (rc = finish_now())) return rc;
+    { const int fuse = fin; fin = 0; LAUNCH(e, 1, k_tau_eval, fuse); }
     if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
     if ((rc = run_stage(e, GS_SAGE_DECIDE, pop, iteration))) return rc;
-    LAUNCH(e, 5, k_tau_finish, 0);
+    fin = 1;
   }
   if ((rc = run_stage(e, GS_SAGE_END, 0, iteration))) return rc;
   if (Gh.doMixing) {
     if ((rc = run_stage(e, GS_MIX_PROPOSE, 0, iteration))) return rc;
     if (Gh.ftMixing > 0.0) {
-      LAUNCH(e, 2, k_mix_eval, 0);
+      if (no_fuse && (rc = finish_now())) return rc;
+      { const int fuse = fin; fin = 0; LAUNCH(e, 2, k_mix_eval, fuse); }
       if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
       if ((rc = run_stage(e, GS_MIX_DECIDE, 0, iteration))) return rc;
       LAUNCH(e, 7, k_mix_finish, 0);
     }
   }
+  if ((rc = finish_now())) return rc;    /* no evaluate kernel followed the last decision */
   if (iteration == Gh.startMig) {
     // sampleMigRates, then the genLogLikelihood refresh of every locus (GPhoCS.c:1738-1757) inside synchronizeEvents' pass
     if ((rc = run_stage(e, GS_STARTMIG, 0, iteration))) return rc;

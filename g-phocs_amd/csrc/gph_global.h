@@ -412,6 +412,20 @@ GPH_HD void gg_sage_propose(GphGlobal &G, int pop)
   G.pend_taufactor0 = taufactor[0]; G.pend_taufactor1 = taufactor[1];
 }
 
+// freeze what the finish of the decided proposal needs (gph_types.h: GphTauFin)
+GPH_HD void gg_fill_fin(GphGlobal &G, int flag, long long limit)
+{
+  const GphTauArgs &A = G.tau;
+  const GphModel &M = G.model;
+  GphTauFin &F = G.fin;
+  F.ap = A.ap; F.son0 = A.son0; F.son1 = A.son1; F.isRoot = A.isRoot; F.mode = A.mode; F.flag = flag; F.limit = limit;
+  F.tauold = A.tauold; F.taunew = A.taunew; F.taub0 = A.taub0; F.taub1 = A.taub1;
+  F.taufactor0 = A.taufactor0; F.taufactor1 = A.taufactor1;
+  F.age_ap = M.popAge[A.ap];
+  F.age_s0 = A.son0 >= 0 ? M.popAge[A.son0] : 0.0;
+  F.age_s1 = A.son1 >= 0 ? M.popAge[A.son1] : 0.0;
+}
+
 // the decision of UpdateTau (GPhoCS.c:3835-3858, 3946, 3960) / UpdateSampleAge (:4447-4470) from the reduced
 // vector of the evaluate kernel: section 0 sums 0 ntj0, 1 ntj1, 3 genDelta, 4 dataDelta, min 14 first conflicting
 // locus (1e300 = none).  kind 1 = tau, 2 = sample age
@@ -439,6 +453,7 @@ GPH_HD void gg_tau_decide(GphGlobal &G, const GphRed &R, int kind)
     G.tau_limit = mig_conflict ? (long long)fc : (long long)1 << 62;
     G.pend_kind = 0;
   }
+  gg_fill_fin(G, G.tau_flag, G.tau_limit);
 }
 // end of UpdateTau / UpdateSampleAge: the record lines of performMCMC's caller (one per population, then the
 // conflict count) and the accept totals (GPhoCS.c:1621-1650)

@@ -400,13 +400,13 @@ GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double f
 // loop 1 body of UpdateTau, GPhoCS.c:3491-3833.  Reads the main page, writes the
 // evaluated state to the SHADOW page (see gph_types.h); new conditionals go to the
 // non-current halves.  out: 0 ntj0, 1 ntj1, 2 conflict, 3 genDelta, 4 dataDelta
-GPH_DEV void kb_tau_eval(const GphDev &D, int g, gph_ctau &A)
+GPH_DEV void kb_tau_eval(const GphDev &D, int g, gph_ctau &A, int fuse)
 {
   const int ap = A.ap, s0 = A.son0, s1 = A.son1;
   double age_mt, new_age = 0.0, dGen = 0, dData = 0, gd;
   int srcP, tgtP, fatherNode, inode, inORout = -1, ev = -1, n1_0 = 0, n1_1 = 0, i, mig, mig1, band, pop;
   int conflict = 0, k;
-  stage_in(D, g, D.pages, 1);
+  stage_in_after_finish(D, g, fuse);
   setISC(IS_CONFLICT_LOG, 1);
   setISC(IS_RB_NUM, 0);
   for (i = 0; i < ISC(IS_NUM_MIGS); i++) {
@@ -517,13 +517,13 @@ GPH_DEV void kb_tau_eval(const GphDev &D, int g, gph_ctau &A)
     if (!gph_failed()) {
       gd = rubber_band_ripple(1);
       if (A.mode) {
-        gd += rubber_band(ap, A.taub1, A.tauold, A.taufactor1, 0, &n1_1);
-        gd += rubber_band(ap, A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
+        gd += rubber_band(ap, g_model.popAge[ap], A.taub1, A.tauold, A.taufactor1, 0, &n1_1);
+        gd += rubber_band(ap, g_model.popAge[ap], A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
       } else {
-        if (A.isRoot) gd += rubber_band(ap, A.taub0, A.tauold, A.taufactor1, 0, &n1_1);
-        else gd += rubber_band(ap, A.taub1, A.tauold, A.taufactor1, 0, &n1_1);
-        gd += rubber_band(s0, A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
-        gd += rubber_band(s1, A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
+        if (A.isRoot) gd += rubber_band(ap, g_model.popAge[ap], A.taub0, A.tauold, A.taufactor1, 0, &n1_1);
+        else gd += rubber_band(ap, g_model.popAge[ap], A.taub1, A.tauold, A.taufactor1, 0, &n1_1);
+        gd += rubber_band(s0, g_model.popAge[s0], A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
+        gd += rubber_band(s1, g_model.popAge[s1], A.taub0, A.tauold, A.taufactor0, 0, &n1_0);
       }
       setFS(FS_GENDELTA, gd);
       dGen += gd;
@@ -543,21 +543,21 @@ GPH_DEV void kb_tau_eval(const GphDev &D, int g, gph_ctau &A)
   stage_out(D, g, D.shadow, 2);
 }
 
-// loop 2 body (commit), GPhoCS.c:3885-3936 (+ adjustRootEvents patch.c:1808 for the root)
-GPH_DEV void kb_tau_commit(const GphDev &D, int g, gph_ctau &A)
+// loop 2 body (commit), GPhoCS.c:3885-3936 (+ adjustRootEvents patch.c:1808 for the root), on the evaluated state in
+// the LDS image; F = the decided proposal as gg_tau_decide froze it
+GPH_DEV void tau_commit_body(gph_cfin &F)
 {
   int dummy = 0, i, mig, nw, ev;
   double age;
-  stage_in(D, g, D.shadow, 0);
   setFS(FS_GENLNL, FS(FS_GENLNL) + FS(FS_GENDELTA));
-  if (A.mode) {   /* UpdateSampleAge commit, GPhoCS.c:4500-4509 */
-    rubber_band(A.ap, A.taub1, A.tauold, A.taufactor1, 1, &dummy);
-    rubber_band(A.ap, A.taub0, A.tauold, A.taufactor0, 1, &dummy);
+  if (F.mode) {   /* UpdateSampleAge commit, GPhoCS.c:4500-4509 */
+    rubber_band(F.ap, F.age_ap, F.taub1, F.tauold, F.taufactor1, 1, &dummy);
+    rubber_band(F.ap, F.age_ap, F.taub0, F.tauold, F.taufactor0, 1, &dummy);
   } else {
-    if (A.isRoot) rubber_band(A.ap, A.taub0, A.tauold, A.taufactor1, 1, &dummy);
-    else rubber_band(A.ap, A.taub1, A.tauold, A.taufactor1, 1, &dummy);
-    rubber_band(A.son0, A.taub0, A.tauold, A.taufactor0, 1, &dummy);
-    rubber_band(A.son1, A.taub0, A.tauold, A.taufactor0, 1, &dummy);
+    if (F.isRoot) rubber_band(F.ap, F.age_ap, F.taub0, F.tauold, F.taufactor1, 1, &dummy);
+    else rubber_band(F.ap, F.age_ap, F.taub1, F.tauold, F.taufactor1, 1, &dummy);
+    rubber_band(F.son0, F.age_s0, F.taub0, F.tauold, F.taufactor0, 1, &dummy);
+    rubber_band(F.son1, F.age_s1, F.taub0, F.tauold, F.taufactor0, 1, &dummy);
   }
   lik_reset_saved();
   for (i = 0; i < ISC(IS_RB_NUM); i++) {
@@ -572,44 +572,69 @@ GPH_DEV void kb_tau_commit(const GphDev &D, int g, gph_ctau &A)
     remove_event(RBI(0, i));
   }
   setISC(IS_RB_NUM, 0);
-  if (A.isRoot) {
+  if (F.isRoot) {
     int guard = 0;
     ev = FIRSTEV(g_lay.rootPop);
-    age = A.taunew;
+    age = F.taunew;
     while (ENEXT(ev) >= 0) { age += EVT(ev); ev = ENEXT(ev); if (++guard > g_lay.E) { gph_fail(97); break; } }
     setEVT(ev, GPH_OLDAGE - age);
+  }
+}
+// loops 3/4 (reject), GPhoCS.c:3965-3989: only loci whose ripple moved events differ from their main page; everything
+// else is bit-identical already (and loci past the first conflicting one were never touched by the serial reference)
+GPH_DEV bool tau_revert_needed(const GphDev &D, int g, gph_cfin &F)
+{
+  if (D.orig[g] + D.locus_begin >= F.limit) return false;
+  const int32_t *is = (const int32_t *)(D.shadow + (size_t)g * g_lay.page_bytes + g_lay.o_iscal);
+  return RFL(is[IS_RB_NUM]) != 0;
+}
+
+// the finish of the decided proposal as a kernel of its own (the stepwise entry points; the iteration's last one when
+// no evaluate kernel follows): commit or revert by the flag the decision stage froze (gph_global.h: gg_tau_decide)
+GPH_DEV void kb_tau_finish(const GphDev &D, int g)
+{
+  gph_cfin &F = GPH_G->fin;
+  if (RFL(F.flag)) {
+    stage_in(D, g, D.shadow, 0);
+    tau_commit_body(F);
+  } else {
+    if (!tau_revert_needed(D, g, F)) return;
+    stage_in(D, g, D.shadow, 0);
+    lik_revert();
+    rubber_band_ripple(0);
   }
   out_common(D, g);
   stage_out(D, g, D.pages, 0);
 }
 
-// loops 3/4 body (reject), GPhoCS.c:3965-3989: only loci whose ripple moved events
-// differ from their main page; everything else is bit-identical already
-GPH_DEV void kb_tau_revert(const GphDev &D, int g, long long limit)
+// stage-in for a kernel that runs right behind a decision: with fuse != 0 the finish of the decided proposal is done
+// first, in place -- accepted: the evaluated state comes from the shadow page, is committed in LDS and written to the
+// main page (one page read less than finish kernel + stage-in, and one launch less); rejected: only loci whose ripple
+// moved events take that route.  Either way the LDS image is the locus's current state when this returns.
+GPH_DEV void stage_in_after_finish(const GphDev &D, int g, int fuse)
 {
-  if (D.orig[g] + D.locus_begin >= limit) return;   /* loci the serial reference never touched */
-  const int32_t *is = (const int32_t *)(D.shadow + (size_t)g * g_lay.page_bytes + g_lay.o_iscal);
-  if (is[IS_RB_NUM] == 0) return;
-  stage_in(D, g, D.shadow, 0);
-  lik_revert();
-  rubber_band_ripple(0);
-  out_common(D, g);
-  stage_out(D, g, D.pages, 0);
-}
-
-// commit or revert, by the flag the decision stage left in the chain state (gph_global.h: gg_tau_decide)
-GPH_DEV void kb_tau_finish(const GphDev &D, int g)
-{
-  if (RFL(GPH_G->tau_flag)) kb_tau_commit(D, g, GPH_G->tau);
-  else kb_tau_revert(D, g, GPH_G->tau_limit);
+  if (!fuse) { stage_in(D, g, D.pages, 1); return; }
+  gph_cfin &F = GPH_G->fin;
+  if (RFL(F.flag)) {
+    stage_in(D, g, D.shadow, 1);
+    tau_commit_body(F);
+    stage_out(D, g, D.pages, 0);
+  } else if (tau_revert_needed(D, g, F)) {
+    stage_in(D, g, D.shadow, 1);
+    lik_revert();
+    rubber_band_ripple(0);
+    stage_out(D, g, D.pages, 0);
+  } else {
+    stage_in(D, g, D.pages, 1);
+  }
 }
 
 // ---------------------------------------------------------------- mixing
 // evaluate loop of mixing(), GPhoCS.c:4790-4801.  out: 0 dataDelta
-GPH_DEV void kb_mix_eval(const GphDev &D, int g, double c)
+GPH_DEV void kb_mix_eval(const GphDev &D, int g, double c, int fuse)
 {
   double d;
-  stage_in(D, g, D.pages, 1);
+  stage_in_after_finish(D, g, fuse);
   d = lik_scale_ages(c);
   OUT(g, 0, d);
   out_common(D, g);
@@ -1149,10 +1174,10 @@ GPH_DEV void kb_unit(const GphDev &D, int g, int op, double *out, int stride)
     gph_ctau &A = GPH_G->tau;
     int n0 = 0, n1 = 0;
     double d, lik = 0.0;
-    if (A.isRoot) d = rubber_band(A.ap, A.taub0, A.tauold, A.taufactor1, 0, &n1);
-    else d = rubber_band(A.ap, A.taub1, A.tauold, A.taufactor1, 0, &n1);
-    d += rubber_band(A.son0, A.taub0, A.tauold, A.taufactor0, 0, &n0);
-    d += rubber_band(A.son1, A.taub0, A.tauold, A.taufactor0, 0, &n0);
+    if (A.isRoot) d = rubber_band(A.ap, g_model.popAge[A.ap], A.taub0, A.tauold, A.taufactor1, 0, &n1);
+    else d = rubber_band(A.ap, g_model.popAge[A.ap], A.taub1, A.tauold, A.taufactor1, 0, &n1);
+    d += rubber_band(A.son0, g_model.popAge[A.son0], A.taub0, A.tauold, A.taufactor0, 0, &n0);
+    d += rubber_band(A.son1, g_model.popAge[A.son1], A.taub0, A.tauold, A.taufactor0, 0, &n0);
     if (n0 + n1) { lik = -FS(FS_DATALNL); lik += lik_compute(1); }
     lik_revert();
     if (GPH_LANE == 0) { uo[0] = d; uo[1] = n0; uo[2] = n1; uo[3] = lik; }

@@ -1599,8 +1599,10 @@ GPH_DEV void reject_event_chain_changes(int inst)
 }
 
 // ---------------------------------------------------------------- rubber band
-// rubberBand, patch.c:596-801
-GPH_DEVHOT double rubber_band(int pop, double static_point, double moving_point, double factor, int post,
+// rubberBand, patch.c:596-801.  age0 = the age the population's chain starts at (comb->age of the reference): the
+// model's popAge[pop] when the proposal is evaluated; the commit passes the age the evaluation saw (GphTauFin), because
+// it may run after the model has moved on
+GPH_DEVHOT double rubber_band(int pop, double age0, double static_point, double moving_point, double factor, int post,
                              int *out_num_events)
 {
   int i, ev, b, node_id, num_lins, count_events = 0, flag, ty;
@@ -1612,7 +1614,7 @@ GPH_DEVHOT double rubber_band(int pop, double static_point, double moving_point,
   double end_time = gmax2(static_point, moving_point);
   if (pop == g_lay.rootPop) { start_time = moving_point; end_time = GPH_OLDAGE; }
   ev = FIRSTEV(pop);
-  age = g_model.popAge[pop];
+  age = age0;
   flag = (age >= start_time);
   int guard = 0;
   while (UNI(age < end_time)) {

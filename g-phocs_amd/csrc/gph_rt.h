@@ -36,6 +36,7 @@ extern GphModel g_model;
 extern GphGlobal *gph_G_emu;
 typedef const GphGlobal gph_cglobal;
 typedef const GphTauArgs gph_ctau;
+typedef const GphTauFin gph_cfin;
 #define GPH_G ((gph_cglobal *)gph_G_emu)
 #else
 #include <hip/hip_runtime.h>
@@ -65,6 +66,7 @@ typedef __attribute__((address_space(4))) const GphKargs gph_ckargs;
 typedef __attribute__((address_space(4))) const GphModel gph_cmodel;
 typedef __attribute__((address_space(4))) const GphGlobal gph_cglobal;
 typedef __attribute__((address_space(4))) const GphTauArgs gph_ctau;
+typedef __attribute__((address_space(4))) const GphTauFin gph_cfin;
 // the model tables: GphCtxT<false> (the genealogy sweep) reads the copy in the kernel-argument segment, GphCtxT<true>
 // (every kernel that runs after a decision the host has not seen) the chain state in HBM, through the pointer in the
 // kernel-argument segment and the constant address space -- scalar loads either way

@@ -200,6 +200,17 @@ struct GphTauArgs {
   double new_band_ages[GPH_MAXB * 2];
 };
 
+// what the finish (commit / revert) of a decided UpdateTau / UpdateSampleAge proposal needs, frozen by the decision stage
+// (gg_tau_decide): the finish normally rides at the HEAD of the next evaluate kernel (kb_tau_eval of the next
+// population, kb_mix_eval), i.e. after the stage that proposes the next move has already applied the accepted age and
+// the next proposal's band times to the model -- so it reads the proposal and the chain start ages it walks from HERE
+struct GphTauFin {
+  int32_t ap, son0, son1, isRoot, mode, flag;   // flag 1 = accepted: commit, 0 = revert
+  long long limit;                              // first conflicting locus (global index) or 1 << 62
+  double tauold, taunew, taub0, taub1, taufactor0, taufactor1;
+  double age_ap, age_s0, age_s1;                // popAge of the three populations as the evaluate kernel saw them
+};
+
 // ---------------------------------------------------------------------------------------
 // Chain state above the loci: what the reference keeps in process-wide globals on its main thread
 // (dataState GPhoCS.h:35-50, mcmcSetup finetunes MCMCcontrol.h:80-99, the population tree's parameters and
@@ -257,4 +268,5 @@ struct alignas(16) GphGlobal {
   // record lines of the running iteration (printed by the host after its synchronisation)
   int32_t nrec, shownValid;
   GphRec rec[GPH_REC_MAX];
+  GphTauFin fin;                     // the decided proposal whose commit / revert has not run yet
 };

@@ -516,3 +516,19 @@ def test_plain_build_parity(G, tmp_path, name):
     compare_states(recs[0] + ".state", os.path.join(GOLDEN, name + ".state"))
     assert open(recs[0]).read() == open(recs[1]).read()
     assert open(recs[0] + ".state").read() == open(recs[1] + ".state").read()
+
+
+@pytest.mark.parametrize("name", ["m3", "a7", "a6", "m4"])
+def test_fused_finish_equals_separate_finish_kernels(G, tmp_path, name):
+    """the commit / revert of a decided UpdateTau / UpdateSampleAge proposal at the head of the next evaluate kernel
+    (default) against every finish as a kernel of its own (GPH_NO_FUSE=1): byte-identical records and final state --
+    rubber-band conflicts (m3), sample-age moves in both directions (a6 / a7) -- and fewer launches"""
+    iters = CASES[name]
+    pack = os.path.join(GOLDEN, name + ".gpk")
+    a, b = str(tmp_path / "fused.rec"), str(tmp_path / "sep.rec")
+    hs_a = _records(G, pack, iters, a)
+    hs_b = _records(G, pack, iters, b, env={"GPH_NO_FUSE": "1"})
+    assert open(a).read() == open(b).read()
+    assert open(a + ".state").read() == open(b + ".state").read()
+    compare_records(a, os.path.join(GOLDEN, name + ".rtrace"))
+    assert hs_a["launches"] < hs_b["launches"], (hs_a, hs_b)
