@@ -218,6 +218,9 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_comm_destroy", "gph_comm_world", "gph_comm_rank", "gph_comm_on_stream", "gph_comm_kind",
     "gph_comm_allgather_stream", "gph_comm_allreduce_host", "gph_run_control_file_comm", "gph_device_count",
     "gph_engine_unit", "gph_build_id", "gph_comm_local_group", "gph_comm_create_local",
+    "gph_mcmc_get_chain", "gph_mcmc_set_chain", "gph_mcmc_update_gb", "gph_mcmc_update_locus_rate", "gph_mcmc_update_theta",
+    "gph_mcmc_update_mig_rates", "gph_mcmc_update_tau", "gph_mcmc_update_sample_age", "gph_mcmc_mixing",
+    "gph_mcmc_synchronize_events", "gph_mcmc_check_all", "gph_mcmc_initialize_genealogies",
 ]
 
 

@@ -340,6 +340,7 @@ struct gph_engine {
   bool loaded = false, seeded = false, model_set = false, initialized = false;
   GphKargs ka;                 // first argument of every kernel: model, layout, math constants, table addresses
   bool sync_pending = false;   // synchronizeEvents of the finished iteration rides at the head of the next sweep kernel
+  bool fin_owed = false;       // the commit / revert of the last decided tau / sample-age proposal has not run yet
   gph_counters counters = {0, 0, 0.0, 0};
   double last_ms[16] = {0};
   // per kernel class: launches, summed HIP-event ms; evaluations / bytes / nodes live in the chain state
@@ -1565,6 +1566,111 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
   return 0;
 }
 
+// The parts of an iteration, one per function performMCMC calls (GPhoCS.c:1495-1821).  gph_engine_iteration_ queues them
+// all and synchronises once; gph_engine_part_ runs ONE and returns with its result on the host (the reference's own
+// performMCMC driving the engine through the functions of GPhoCS.h:84-100: oracle/integration_binding.c).
+// e->fin_owed: the commit / revert of the last decided UpdateTau / UpdateSampleAge proposal has not run yet -- it rides
+// at the head of the next evaluate kernel (the next population's, or mixing's): the decision stage froze what it needs
+// in the chain state (GphTauFin), and the stage that proposes the next move goes out in the same launch as the decision.
+// GPH_NO_FUSE=1 (tests) runs every finish as a kernel of its own, as the stepwise entry points do.
+static int finish_owed(gph_engine *e)
+{
+  if (e->fin_owed) { e->fin_owed = false; LAUNCH(e, 5, k_tau_finish, 0); }
+  return 0;
+}
+static int part_sweep(gph_engine *e, int32_t iteration, double ftCoal, double ftMig)
+{
+  int rc;
+  // the three genealogy proposals run fused in one launch (GPhoCS.c:1495-1538); the deferred synchronizeEvents of the
+  // previous iteration rides at its head
+  const int with_sync = e->sync_pending ? 8 : 0;
+  e->sync_pending = false;
+  LAUNCH(e, 0, k_sweep, 7 | with_sync, ftCoal, ftMig);
+  if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+  if ((rc = reduce_stats(e))) return rc;
+  return run_stage(e, GS_SWEEP_DONE, with_sync, iteration);
+}
+static int part_lrate(gph_engine *e, int32_t iteration, const double *lr_alpha_finetune, int64_t *lr_accepted, double *lr_rateVar)
+{
+  // UpdateLocusRate, GPhoCS.c:1554-1563, 4598-4680 (host-driven: resident() is false with variable rates)
+  int rc;
+  GphGlobal &Gh = *e->G_h;
+  gph_locus_rate_result R;
+  R.accepted = 0; R.dataLogLikelihood = Gh.dataLogLikelihood; R.logLikelihood = Gh.logLikelihood; R.rateVar = *lr_rateVar;
+  if ((rc = gph_engine_locus_rate_update(e, lr_alpha_finetune[1], lr_alpha_finetune[0], &R))) return rc;
+  Gh.dataLogLikelihood = R.dataLogLikelihood; Gh.logLikelihood = R.logLikelihood; *lr_rateVar = R.rateVar;
+  *lr_accepted += R.accepted;
+  gg_rec(Gh, REC_LRATE, 0, (long long)R.accepted);
+  if ((rc = push_G(e))) return rc;
+  if ((rc = reduce_stats(e))) return rc;
+  return run_stage(e, GS_TOTALS, 0, iteration);
+}
+static int part_tau(gph_engine *e, int32_t iteration, bool first_proposed)
+{
+  int rc;
+  const GphGlobal &Gh = *e->G_h;
+  const int K = Gh.K, Kc = Gh.Kc;
+  const bool no_fuse = getenv("GPH_NO_FUSE") && atoi(getenv("GPH_NO_FUSE")) != 0;
+  for (int ap = Kc; ap < K; ++ap) {
+    if ((ap > Kc || !first_proposed) && (rc = run_stage(e, GS_TAU_PROPOSE, ap, iteration))) return rc;
+    if (no_fuse && (rc = finish_owed(e))) return rc;
+    { const int fuse = e->fin_owed; e->fin_owed = false; LAUNCH(e, 1, k_tau_eval, fuse); }
+    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+    if ((rc = run_stage(e, GS_TAU_DECIDE, ap, iteration))) return rc;
+    e->fin_owed = true;
+  }
+  return run_stage(e, GS_TAU_END, 0, iteration);
+}
+static int part_sage(gph_engine *e, int32_t iteration)
+{
+  int rc;
+  const GphGlobal &Gh = *e->G_h;
+  const bool no_fuse = getenv("GPH_NO_FUSE") && atoi(getenv("GPH_NO_FUSE")) != 0;
+  for (int pop = 0; pop < Gh.Kc; ++pop) {
+    if (!Gh.updateSampleAge[pop]) continue;
+    if ((rc = run_stage(e, GS_SAGE_PROPOSE, pop, iteration))) return rc;
+    if (no_fuse && (rc = finish_owed(e))) return rc;
+    { const int fuse = e->fin_owed; e->fin_owed = false; LAUNCH(e, 1, k_tau_eval, fuse); }
+    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+    if ((rc = run_stage(e, GS_SAGE_DECIDE, pop, iteration))) return rc;
+    e->fin_owed = true;
+  }
+  return run_stage(e, GS_SAGE_END, 0, iteration);
+}
+static int part_mix(gph_engine *e, int32_t iteration)
+{
+  int rc;
+  const GphGlobal &Gh = *e->G_h;
+  const bool no_fuse = getenv("GPH_NO_FUSE") && atoi(getenv("GPH_NO_FUSE")) != 0;
+  if ((rc = run_stage(e, GS_MIX_PROPOSE, 0, iteration))) return rc;
+  if (Gh.ftMixing > 0.0) {
+    if (no_fuse && (rc = finish_owed(e))) return rc;
+    { const int fuse = e->fin_owed; e->fin_owed = false; LAUNCH(e, 2, k_mix_eval, fuse); }
+    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+    if ((rc = run_stage(e, GS_MIX_DECIDE, 0, iteration))) return rc;
+    LAUNCH(e, 7, k_mix_finish, 0);
+  }
+  return 0;
+}
+// the genLogLikelihood refresh of every locus after sampleMigRates (GPhoCS.c:1749-1757), inside synchronizeEvents' pass
+static int part_refresh(gph_engine *e, int32_t iteration)
+{
+  int rc;
+  LAUNCH(e, 8, k_sync, 1);
+  if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+  return run_stage(e, GS_REFRESH_DONE, 1, iteration);
+}
+// checkAll, patch.c:2745-2884: consistency checks + accumulator resynchronisation
+static int part_check(gph_engine *e, int32_t iteration)
+{
+  int rc;
+  if ((rc = flush_sync(e, false))) return rc;
+  LAUNCH(e, 4, k_check, 0);
+  if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
+  if ((rc = reduce_stats(e))) return rc;
+  return run_stage(e, GS_CHECK_DONE, 0, iteration);
+}
+
 // ---------------------------------------------------------------- one MCMC iteration, device-resident
 // The iteration body of performMCMC (GPhoCS.c:1476-1821) as ONE stream of launches: every per-locus loop is a kernel
 // over the loci, every `omp atomic` accumulation a fixed-shape reduction (+ one RCCL all-gather of the reduced row over
@@ -1580,87 +1686,58 @@ int gph_engine_iteration_(gph_engine *e, int32_t iteration, const double *lr_alp
   SETDEV(e);
   int rc;
   GphGlobal &Gh = *e->G_h;    /* settings only: the running state is on the device until finish_sync */
-  const int K = Gh.K, Kc = Gh.Kc;
   PUSH_IF_DIRTY(e);
-  // the three genealogy proposals run fused in one launch (GPhoCS.c:1495-1538); the deferred synchronizeEvents of the
-  // previous iteration rides at its head
-  const int with_sync = e->sync_pending ? 8 : 0;
-  e->sync_pending = false;
-  LAUNCH(e, 0, k_sweep, 7 | with_sync, Gh.ftCoalTime, Gh.ftMigTime);
-  if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
-  if ((rc = reduce_stats(e))) return rc;
-  if ((rc = run_stage(e, GS_SWEEP_DONE, with_sync, iteration))) return rc;
-  if (lr_alpha_finetune) {
-    // UpdateLocusRate, GPhoCS.c:1554-1563, 4598-4680 (host-driven: resident() is false with variable rates)
-    gph_locus_rate_result R;
-    R.accepted = 0; R.dataLogLikelihood = Gh.dataLogLikelihood; R.logLikelihood = Gh.logLikelihood; R.rateVar = *lr_rateVar;
-    if ((rc = gph_engine_locus_rate_update(e, lr_alpha_finetune[1], lr_alpha_finetune[0], &R))) return rc;
-    Gh.dataLogLikelihood = R.dataLogLikelihood; Gh.logLikelihood = R.logLikelihood; *lr_rateVar = R.rateVar;
-    *lr_accepted += R.accepted;
-    gg_rec(Gh, REC_LRATE, 0, (long long)R.accepted);
-    if ((rc = push_G(e))) return rc;
-    if ((rc = reduce_stats(e))) return rc;
-    if ((rc = run_stage(e, GS_TOTALS, 0, iteration))) return rc;
-  }
+  if ((rc = part_sweep(e, iteration, Gh.ftCoalTime, Gh.ftMigTime))) return rc;
+  if (lr_alpha_finetune && (rc = part_lrate(e, iteration, lr_alpha_finetune, lr_accepted, lr_rateVar))) return rc;
   if ((rc = run_stage(e, GS_THETA, 0, iteration))) return rc;
   /* the first tau proposal touches no locus: its stage rides in the launch of the stages before it, ahead of the
    * per-locus touch-ups of the accepted theta / migration-rate proposals */
-  if (Kc < K && (rc = run_stage(e, GS_TAU_PROPOSE, Kc, iteration))) return rc;
+  if (Gh.Kc < Gh.K && (rc = run_stage(e, GS_TAU_PROPOSE, Gh.Kc, iteration))) return rc;
   if ((rc = apply_list(e))) return rc;
-  /* the commit / revert of a decided proposal rides at the head of the NEXT evaluate kernel (the next population's,
-   * or mixing's): the decision stage froze what it needs in the chain state (GphTauFin), and the stage that proposes
-   * the next move goes out in the same launch as the decision.  fin = a finish is owed; GPH_NO_FUSE=1 (tests) runs
-   * every finish as a kernel of its own, as the stepwise entry points do */
-  const bool no_fuse = getenv("GPH_NO_FUSE") && atoi(getenv("GPH_NO_FUSE")) != 0;
-  int fin = 0;
-  auto finish_now = [&]() -> int { if (fin) { fin = 0; LAUNCH(e, 5, k_tau_finish, 0); } return 0; };
-  for (int ap = Kc; ap < K; ++ap) {
-    if (ap > Kc && (rc = run_stage(e, GS_TAU_PROPOSE, ap, iteration))) return rc;
-    if (no_fuse && (rc = finish_now())) return rc;
-    { const int fuse = fin; fin = 0; LAUNCH(e, 1, k_tau_eval, fuse); }
-    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
-    if ((rc = run_stage(e, GS_TAU_DECIDE, ap, iteration))) return rc;
-    fin = 1;
-  }
-  if ((rc = run_stage(e, GS_TAU_END, 0, iteration))) return rc;
-  for (int pop = 0; pop < Kc; ++pop) {
-    if (!Gh.updateSampleAge[pop]) continue;
-    if ((rc = run_stage(e, GS_SAGE_PROPOSE, pop, iteration))) return rc;
-    if (no_fuse && (rc = finish_now())) return rc;
-    { const int fuse = fin; fin = 0; LAUNCH(e, 1, k_tau_eval, fuse); }
-    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
-    if ((rc = run_stage(e, GS_SAGE_DECIDE, pop, iteration))) return rc;
-    fin = 1;
-  }
-  if ((rc = run_stage(e, GS_SAGE_END, 0, iteration))) return rc;
-  if (Gh.doMixing) {
-    if ((rc = run_stage(e, GS_MIX_PROPOSE, 0, iteration))) return rc;
-    if (Gh.ftMixing > 0.0) {
-      if (no_fuse && (rc = finish_now())) return rc;
-      { const int fuse = fin; fin = 0; LAUNCH(e, 2, k_mix_eval, fuse); }
-      if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
-      if ((rc = run_stage(e, GS_MIX_DECIDE, 0, iteration))) return rc;
-      LAUNCH(e, 7, k_mix_finish, 0);
-    }
-  }
-  if ((rc = finish_now())) return rc;    /* no evaluate kernel followed the last decision */
+  if ((rc = part_tau(e, iteration, true))) return rc;
+  if ((rc = part_sage(e, iteration))) return rc;
+  if (Gh.doMixing && (rc = part_mix(e, iteration))) return rc;
+  if ((rc = finish_owed(e))) return rc;    /* no evaluate kernel followed the last decision */
   if (iteration == Gh.startMig) {
     // sampleMigRates, then the genLogLikelihood refresh of every locus (GPhoCS.c:1738-1757) inside synchronizeEvents' pass
     if ((rc = run_stage(e, GS_STARTMIG, 0, iteration))) return rc;
-    LAUNCH(e, 8, k_sync, 1);
-    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
-    if ((rc = run_stage(e, GS_REFRESH_DONE, 1, iteration))) return rc;
+    if ((rc = part_refresh(e, iteration))) return rc;
   } else {
     e->sync_pending = true;   /* synchronizeEvents (GPhoCS.c:1705-1714): at the head of the next sweep kernel */
   }
-  if ((iteration + 1) % Gh.samplesPerLog == 0) {
-    // checkAll, patch.c:2745-2884: consistency checks + accumulator resynchronisation
-    if ((rc = flush_sync(e, false))) return rc;
-    LAUNCH(e, 4, k_check, 0);
-    if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
-    if ((rc = reduce_stats(e))) return rc;
-    if ((rc = run_stage(e, GS_CHECK_DONE, 0, iteration))) return rc;
+  if ((iteration + 1) % Gh.samplesPerLog == 0 && (rc = part_check(e, iteration))) return rc;
+  return finish_sync(e);
+}
+
+// ONE part of an iteration, its result on the host when this returns: what a caller that keeps the reference's own
+// performMCMC runs behind each of the functions of GPhoCS.h:84-100 (gph_mcmc_update_* below; the caller has set the
+// step size(s) of the part in the chain state and, for GPH_PART_REFRESH, the freshly sampled migration rates)
+int gph_engine_part_(gph_engine *e, int32_t part, int32_t iteration, const double *lr_alpha_finetune, int64_t *lr_accepted, double *lr_rateVar)
+{
+  if (!e || !e->initialized) return GPH_ESTATE;
+  SETDEV(e);
+  int rc = 0;
+  GphGlobal &Gh = *e->G_h;
+  PUSH_IF_DIRTY(e);
+  if (part == GPH_PART_LRATE || part == GPH_PART_TAU || part == GPH_PART_SAGE || part == GPH_PART_MIX) {
+    int rcs = flush_sync(e, true);    /* a deferred synchronizeEvents pass must not be overtaken by a kernel that edits the pages */
+    if (rcs) return rcs;
   }
+  switch (part) {
+  case GPH_PART_SWEEP: rc = part_sweep(e, iteration, Gh.ftCoalTime, Gh.ftMigTime); break;
+  case GPH_PART_LRATE: rc = lr_alpha_finetune ? part_lrate(e, iteration, lr_alpha_finetune, lr_accepted, lr_rateVar) : GPH_EARG; break;
+  case GPH_PART_THETA: rc = run_stage(e, GS_THETA_ONLY, 0, iteration); if (!rc) rc = apply_list(e); break;
+  case GPH_PART_MIGR: rc = run_stage(e, GS_MIGR_ONLY, 0, iteration); if (!rc) rc = apply_list(e); break;
+  case GPH_PART_TAU: rc = part_tau(e, iteration, false); break;
+  case GPH_PART_SAGE: rc = part_sage(e, iteration); break;
+  case GPH_PART_MIX: rc = part_mix(e, iteration); break;
+  case GPH_PART_SYNC: e->sync_pending = true; break;
+  case GPH_PART_REFRESH: e->sync_pending = false; rc = part_refresh(e, iteration); break;
+  case GPH_PART_CHECK: Gh.nrec = 0; e->G_dirty = true; PUSH_IF_DIRTY(e); rc = part_check(e, iteration); break;
+  default: return GPH_EARG;
+  }
+  if (rc) return rc;
+  if ((rc = finish_owed(e))) return rc;
   return finish_sync(e);
 }
 

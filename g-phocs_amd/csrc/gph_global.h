@@ -234,11 +234,10 @@ GPH_HD void gg_sweep_done(GphGlobal &G, const GphRed &R, int with_sync)
 // UpdateTheta, GPhoCS.c:3037-3107 and UpdateMigRates, :3115-3213 (the latter only once iteration > start-mig,
 // :1596): decisions from the statistics totals; the per-locus genLogLikelihood touch-ups (:3084-3093, :3192-3200)
 // are queued in G.apply and applied to every locus in this order by k_apply_list
-GPH_HD void gg_theta_and_mig_rates(GphGlobal &G)
+GPH_HD void gg_update_theta(GphGlobal &G)
 {
   GphModel &M = G.model;
   int accepted = 0;
-  G.napply = 0;
   if (G.ftTheta > 0.0) {
     for (int pop = 0; pop < G.K; pop++) {
       double thetaold = M.theta[pop];
@@ -259,30 +258,38 @@ GPH_HD void gg_theta_and_mig_rates(GphGlobal &G)
   }
   G.acc[3] += accepted;
   gg_rec(G, REC_THETA, 0, accepted);
-  if (G.iteration > G.startMig) {
-    accepted = 0;
-    if (G.ftMigRate > 0.0) {
-      for (int b = 0; b < G.B; b++) {
-        double old_rate = M.migRate[b];
-        double lnc = G.ftMigRate * gg_rnd2normal8(G);
-        double c = gph_exp(lnc);
-        double new_rate = old_rate * c;
-        if (new_rate < 0.00001) continue;
-        double lnacc = lnc + lnc * (G.mrAlpha[b] - 1) - (new_rate - old_rate) * G.mrBeta[b];
-        double dLL = (lnc * G.tot_nmig[b] - (new_rate - old_rate) * G.tot_mig[b]);
-        lnacc += dLL;
-        if (lnacc >= 0 || gg_rndu(G) < gph_exp(lnacc)) {
-          accepted++;
-          GphApply &a = G.apply[G.napply++];
-          a.kind = 1; a.idx = b; a.lnc = lnc; a.diff = (new_rate - old_rate);
-          gg_set_mig(G, b, new_rate);
-          G.logLikelihood += dLL / G.Ltot;
-        }
+}
+GPH_HD void gg_update_mig_rates(GphGlobal &G)
+{
+  GphModel &M = G.model;
+  int accepted = 0;
+  if (G.ftMigRate > 0.0) {
+    for (int b = 0; b < G.B; b++) {
+      double old_rate = M.migRate[b];
+      double lnc = G.ftMigRate * gg_rnd2normal8(G);
+      double c = gph_exp(lnc);
+      double new_rate = old_rate * c;
+      if (new_rate < 0.00001) continue;
+      double lnacc = lnc + lnc * (G.mrAlpha[b] - 1) - (new_rate - old_rate) * G.mrBeta[b];
+      double dLL = (lnc * G.tot_nmig[b] - (new_rate - old_rate) * G.tot_mig[b]);
+      lnacc += dLL;
+      if (lnacc >= 0 || gg_rndu(G) < gph_exp(lnacc)) {
+        accepted++;
+        GphApply &a = G.apply[G.napply++];
+        a.kind = 1; a.idx = b; a.lnc = lnc; a.diff = (new_rate - old_rate);
+        gg_set_mig(G, b, new_rate);
+        G.logLikelihood += dLL / G.Ltot;
       }
     }
-    G.acc[4] += accepted;
-    gg_rec(G, REC_MIGR, 0, accepted);
   }
+  G.acc[4] += accepted;
+  gg_rec(G, REC_MIGR, 0, accepted);
+}
+GPH_HD void gg_theta_and_mig_rates(GphGlobal &G)
+{
+  G.napply = 0;
+  gg_update_theta(G);
+  if (G.iteration > G.startMig) gg_update_mig_rates(G);
 }
 
 // the model change of an accepted UpdateTau / UpdateSampleAge proposal: upstream assigns it after its commit loop
@@ -594,6 +601,8 @@ GPH_HD void gg_stage(GphGlobal &G, const GphRed &R, int stage, int arg)
     gg_rec(G, REC_CHECK, 0, 1);
     break;
   case GS_COUNT_ONLY: gg_count(G, R, arg); break;
+  case GS_THETA_ONLY: G.napply = 0; gg_update_theta(G); break;
+  case GS_MIGR_ONLY: G.napply = 0; gg_update_mig_rates(G); break;
   default: break;
   }
 }

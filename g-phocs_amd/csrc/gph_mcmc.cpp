@@ -21,6 +21,7 @@
 extern "C" GphGlobal *gph_engine_global_(gph_engine *e);             /* mutable: marks the mirror for upload */
 extern "C" const GphGlobal *gph_engine_global_ro_(gph_engine *e);
 extern "C" int gph_engine_iteration_(gph_engine *e, int32_t iteration, const double *lr_alpha_finetune, int64_t *lr_accepted, double *lr_rateVar);
+extern "C" int gph_engine_part_(gph_engine *e, int32_t part, int32_t iteration, const double *lr_alpha_finetune, int64_t *lr_accepted, double *lr_rateVar);
 
 struct gph_mcmc {
   gph_engine *e;
@@ -183,6 +184,146 @@ int gph_mcmc_iteration(gph_mcmc *m, int32_t iteration)
     fflush(m->rec);
   }
   return 0;
+}
+
+// ---------------------------------------------------------------- the reference's functions, one call each
+// (include/gphocs_hip.h: the boundary at the granularity performMCMC calls them, GPhoCS.h:84-100)
+int gph_mcmc_get_chain(gph_mcmc *m, gph_chain_state *o)
+{
+  if (!m || !o) return GPH_EARG;
+  const GphGlobal &G = GG(m);
+  memset(o, 0, sizeof *o);
+  for (int p = 0; p < m->K; p++) {
+    o->theta[p] = G.model.theta[p]; o->popAge[p] = G.model.popAge[p]; o->sampleAge[p] = G.model.sampleAge[p];
+    o->coal_stats[p] = G.tot_coal[p]; o->num_coals[p] = G.tot_ncoal[p];
+  }
+  for (int b = 0; b < m->B; b++) {
+    o->migRate[b] = G.model.migRate[b]; o->bandStart[b] = G.model.bandStart[b]; o->bandEnd[b] = G.model.bandEnd[b];
+    o->mig_stats[b] = G.tot_mig[b]; o->num_migs[b] = G.tot_nmig[b];
+  }
+  o->rng[0] = G.gx; o->rng[1] = G.gy; o->rng[2] = G.gz;
+  o->logLikelihood = G.logLikelihood; o->dataLogLikelihood = G.dataLogLikelihood; o->rateVar = m->rateVar;
+  o->rubberband_mig_conflicts = G.rubberband_conflicts;
+  return 0;
+}
+int gph_mcmc_set_chain(gph_mcmc *m, const gph_chain_state *in)
+{
+  if (!m || !in) return GPH_EARG;
+  GphGlobal &G = *gph_engine_global_(m->e);
+  for (int p = 0; p < m->K; p++) {
+    if (G.model.theta[p] != in->theta[p]) gg_set_theta(G, p, in->theta[p]);
+    G.model.popAge[p] = in->popAge[p]; G.model.sampleAge[p] = in->sampleAge[p];
+    G.tot_coal[p] = in->coal_stats[p]; G.tot_ncoal[p] = in->num_coals[p];
+  }
+  for (int b = 0; b < m->B; b++) {
+    if (G.model.migRate[b] != in->migRate[b]) gg_set_mig(G, b, in->migRate[b]);
+    G.model.bandStart[b] = in->bandStart[b]; G.model.bandEnd[b] = in->bandEnd[b];
+    G.tot_mig[b] = in->mig_stats[b]; G.tot_nmig[b] = in->num_migs[b];
+  }
+  G.gx = in->rng[0]; G.gy = in->rng[1]; G.gz = in->rng[2];
+  G.logLikelihood = in->logLikelihood; G.dataLogLikelihood = in->dataLogLikelihood; m->rateVar = in->rateVar;
+  G.rubberband_conflicts = in->rubberband_mig_conflicts;
+  return 0;
+}
+static int run_part(gph_mcmc *m, int part, int32_t iteration)
+{
+  const double lr[2] = {m->varRatesAlpha, m->ftLocusRate};
+  gph_engine_global_(m->e)->nrec = 0;
+  int rc = gph_engine_part_(m->e, part, iteration, m->mutRateMode == 1 ? lr : nullptr, &m->accLocusRate, &m->rateVar);
+  if (!rc) print_records(m, iteration);
+  return rc;
+}
+int gph_mcmc_initialize_genealogies(gph_mcmc *m)
+{
+  if (!m) return GPH_EARG;
+  int rc;
+  const GphGlobal &G = GG(m);
+  if ((rc = gph_engine_set_model(m->e, G.model.theta, G.model.popAge, G.model.sampleAge, G.model.migRate, G.model.bandStart, G.model.bandEnd))) return rc;
+  if ((rc = gph_engine_seed(m->e, (uint32_t)m->seed))) return rc;
+  if ((rc = gph_engine_init_genealogies(m->e, nullptr, nullptr))) return rc;
+  print_records(m, -1);
+  return 0;
+}
+int gph_mcmc_update_gb(gph_mcmc *m, int32_t iteration, double ftCoalTime, double ftMigTime, int64_t accepted[3], int64_t *total_mig_nodes)
+{
+  if (!m || !accepted) return GPH_EARG;
+  GphGlobal &G = *gph_engine_global_(m->e);
+  G.ftCoalTime = ftCoalTime; G.ftMigTime = ftMigTime;
+  const int64_t a0 = G.acc[0], a1 = G.acc[1], a2 = G.acc[2], a7 = G.acc[7];
+  int rc = run_part(m, GPH_PART_SWEEP, iteration);
+  if (rc) return rc;
+  const GphGlobal &H = GG(m);
+  accepted[0] = H.acc[0] - a0; accepted[1] = H.acc[1] - a1; accepted[2] = H.acc[2] - a2;
+  if (total_mig_nodes) *total_mig_nodes = H.acc[7] - a7;
+  return 0;
+}
+int gph_mcmc_update_locus_rate(gph_mcmc *m, int32_t iteration, double finetune, int64_t *accepted)
+{
+  if (!m || !accepted) return GPH_EARG;
+  *accepted = 0;
+  if (m->mutRateMode != 1) return 0;
+  m->ftLocusRate = finetune;
+  const int64_t a = m->accLocusRate;
+  int rc = run_part(m, GPH_PART_LRATE, iteration);
+  if (!rc) *accepted = m->accLocusRate - a;
+  return rc;
+}
+static int one_count(gph_mcmc *m, int part, int slot, int32_t iteration, int64_t *accepted)
+{
+  const int64_t a = GG(m).acc[slot];
+  int rc = run_part(m, part, iteration);
+  if (!rc) *accepted = GG(m).acc[slot] - a;
+  return rc;
+}
+int gph_mcmc_update_theta(gph_mcmc *m, int32_t iteration, double finetune, int64_t *accepted)
+{
+  if (!m || !accepted) return GPH_EARG;
+  gph_engine_global_(m->e)->ftTheta = finetune;
+  return one_count(m, GPH_PART_THETA, 3, iteration, accepted);
+}
+int gph_mcmc_update_mig_rates(gph_mcmc *m, int32_t iteration, double finetune, int64_t *accepted)
+{
+  if (!m || !accepted) return GPH_EARG;
+  gph_engine_global_(m->e)->ftMigRate = finetune;
+  return one_count(m, GPH_PART_MIGR, 4, iteration, accepted);
+}
+int gph_mcmc_update_tau(gph_mcmc *m, int32_t iteration, const double *finetunes, int32_t *accepted)
+{
+  if (!m || !finetunes || !accepted) return GPH_EARG;
+  GphGlobal &G = *gph_engine_global_(m->e);
+  for (int p = m->Kc; p < m->K; p++) G.ftTaus[p] = finetunes[p];
+  int rc = run_part(m, GPH_PART_TAU, iteration);
+  if (rc) return rc;
+  for (int p = m->Kc; p < m->K; p++) accepted[p] = GG(m).accArr[p];   /* upstream zeroes and fills the ancestral entries only (GPhoCS.c:3255) */
+  return 0;
+}
+int gph_mcmc_update_sample_age(gph_mcmc *m, int32_t iteration, const double *finetunes, int32_t *accepted)
+{
+  if (!m || !finetunes || !accepted) return GPH_EARG;
+  GphGlobal &G = *gph_engine_global_(m->e);
+  for (int p = 0; p < m->Kc; p++) G.ftTaus[p] = finetunes[p];
+  int rc = run_part(m, GPH_PART_SAGE, iteration);
+  if (rc) return rc;
+  for (int p = 0; p < m->Kc; p++) accepted[p] = GG(m).accArr[p];      /* the current populations' entries (GPhoCS.c:4027) */
+  return 0;
+}
+int gph_mcmc_mixing(gph_mcmc *m, int32_t iteration, double finetune, int64_t *accepted)
+{
+  if (!m || !accepted) return GPH_EARG;
+  gph_engine_global_(m->e)->ftMixing = finetune;
+  return one_count(m, GPH_PART_MIX, 6, iteration, accepted);
+}
+int gph_mcmc_synchronize_events(gph_mcmc *m, int32_t iteration, int32_t refresh)
+{
+  if (!m) return GPH_EARG;
+  return run_part(m, refresh ? GPH_PART_REFRESH : GPH_PART_SYNC, iteration);
+}
+int gph_mcmc_check_all(gph_mcmc *m, int32_t iteration, int32_t *ok)
+{
+  if (!m) return GPH_EARG;
+  int rc = run_part(m, GPH_PART_CHECK, iteration);
+  if (ok) *ok = rc == 0;
+  return rc;
 }
 
 int gph_mcmc_get_state(gph_mcmc *m, double *logL, double *dataLogL, double *theta, double *popAge, double *migRate)

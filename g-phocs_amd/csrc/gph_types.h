@@ -229,7 +229,11 @@ struct GphTauFin {
 // stages of an iteration that run above the loci (gph_global.h: gg_stage)
 enum { GS_INIT_DONE = 0, GS_SWEEP_DONE, GS_TOTALS, GS_THETA, GS_TAU_PROPOSE, GS_TAU_DECIDE, GS_TAU_END, GS_SAGE_PROPOSE,
        GS_SAGE_DECIDE, GS_SAGE_END, GS_MIX_PROPOSE, GS_MIX_DECIDE, GS_STARTMIG, GS_REFRESH_DONE, GS_CHECK_DONE,
-       GS_COUNT_ONLY };
+       GS_COUNT_ONLY,
+       GS_THETA_ONLY, GS_MIGR_ONLY };   /* UpdateTheta / UpdateMigRates as calls of their own (gph_mcmc_update_theta / _mig_rates) */
+// the parts of an iteration, one per function performMCMC calls (GPhoCS.h:84-100; gph_engine_part_)
+enum { GPH_PART_SWEEP = 0, GPH_PART_LRATE, GPH_PART_THETA, GPH_PART_MIGR, GPH_PART_TAU, GPH_PART_SAGE, GPH_PART_MIX,
+       GPH_PART_SYNC, GPH_PART_REFRESH, GPH_PART_CHECK };
 #define GPH_REC_MAX (16 + 3 * GPH_MAXK)
 struct GphRec { int32_t code, idx; int64_t acc; double dataLnL, logL; };
 enum { REC_INIT = 0, REC_INT, REC_MIGN, REC_SPR, REC_LRATE, REC_THETA, REC_MIGR, REC_TAU, REC_CONFLICTS, REC_SAGE,

@@ -290,6 +290,51 @@ int gph_run_control_file(const char *ctl_path, const char *secondary_ctl_path_or
  * reduced vectors through `allreduce` (see gph_engine_set_allreduce); rank 0 writes the trace file */
 int gph_run_control_file_ranked(const char *ctl_path, const char *secondary_ctl_path_or_null, int32_t device,
                                 int32_t verbose, int32_t rank, int32_t world, gph_allreduce_fn allreduce, void *user);
+/* ------------------------------------------------------------------------------------
+ * The reference's proposal functions, ONE CALL EACH -- the drop-in boundary at the granularity performMCMC calls them
+ * (upstream src/GPhoCS.h:84-100): a host program that keeps the reference's own performMCMC (trace writer, finetune
+ * search, log lines) replaces the BODIES of those functions by these calls and mirrors the handful of process-wide
+ * globals the reference keeps on its main thread through gph_chain_state.  oracle/integration_binding.c is that
+ * replacement written out, linked with the reference's own objects and run (tests/test_boundary_run.py).
+ *   reference function                                  call
+ *   UpdateGB_InternalNode + _MigrationNode + _MigSPR    gph_mcmc_update_gb        (GPhoCS.c:2287, 2439, 2598; one fused launch)
+ *   UpdateLocusRate        GPhoCS.c:4598                gph_mcmc_update_locus_rate
+ *   UpdateTheta            GPhoCS.c:3037                gph_mcmc_update_theta
+ *   UpdateMigRates         GPhoCS.c:3115                gph_mcmc_update_mig_rates
+ *   UpdateTau              GPhoCS.c:3224                gph_mcmc_update_tau        (accepted[ancestral pop], as upstream)
+ *   UpdateSampleAge        GPhoCS.c:4006                gph_mcmc_update_sample_age (accepted[current pop])
+ *   mixing                 GPhoCS.c:4688                gph_mcmc_mixing
+ *   synchronizeEvents loop GPhoCS.c:1705-1714           gph_mcmc_synchronize_events(refresh = 0)
+ *   sampleMigRates' genLogLikelihood loop :1749-1757    gph_mcmc_synchronize_events(refresh = 1), after set_chain
+ *   checkAll               patch.c:2745                 gph_mcmc_check_all
+ * Conventions as upstream: a step size <= 0 makes the call return 0 accepted without drawing anything; errors are a
+ * non-zero status (upstream prints "Fatal Error NNNN" and exits). */
+#define GPH_ABI_MAXK 40     /* 2 * NSPECIES - 1 = 39 populations upstream (patch.h:19) */
+#define GPH_ABI_MAXB 100    /* MAX_MIG_BANDS (patch.h:17) */
+typedef struct {
+  double theta[GPH_ABI_MAXK], popAge[GPH_ABI_MAXK], sampleAge[GPH_ABI_MAXK];   /* Population.{theta,age,sampleAge}, PopulationTree.h:60-101 */
+  double migRate[GPH_ABI_MAXB], bandStart[GPH_ABI_MAXB], bandEnd[GPH_ABI_MAXB]; /* MigrationBand.{migRate,startTime,endTime} */
+  uint32_t rng[3];                                       /* the general slot of RndCtx (utils.h:34): rndu_x, rndu_y, rndu_z */
+  double logLikelihood, dataLogLikelihood, rateVar;      /* dataState, GPhoCS.h:35-50 */
+  double coal_stats[GPH_ABI_MAXK], num_coals[GPH_ABI_MAXK], mig_stats[GPH_ABI_MAXB], num_migs[GPH_ABI_MAXB];   /* genetree_stats_total, patch.h:121 */
+  int64_t rubberband_mig_conflicts;                      /* misc_stats, patch.h */
+} gph_chain_state;
+int gph_mcmc_get_chain(gph_mcmc *m, gph_chain_state *out);
+int gph_mcmc_set_chain(gph_mcmc *m, const gph_chain_state *in);
+int gph_mcmc_update_gb(gph_mcmc *m, int32_t iteration, double ftCoalTime, double ftMigTime, int64_t accepted[3], int64_t *total_mig_nodes);
+int gph_mcmc_update_locus_rate(gph_mcmc *m, int32_t iteration, double finetune, int64_t *accepted);
+int gph_mcmc_update_theta(gph_mcmc *m, int32_t iteration, double finetune, int64_t *accepted);
+int gph_mcmc_update_mig_rates(gph_mcmc *m, int32_t iteration, double finetune, int64_t *accepted);
+int gph_mcmc_update_tau(gph_mcmc *m, int32_t iteration, const double *finetunes, int32_t *accepted);
+int gph_mcmc_update_sample_age(gph_mcmc *m, int32_t iteration, const double *finetunes, int32_t *accepted);
+int gph_mcmc_mixing(gph_mcmc *m, int32_t iteration, double finetune, int64_t *accepted);
+int gph_mcmc_synchronize_events(gph_mcmc *m, int32_t iteration, int32_t refresh);
+int gph_mcmc_check_all(gph_mcmc *m, int32_t iteration, int32_t *ok);
+/* initializeMCMC's per-locus loop (GPhoCS.c:1197-1214) for a caller that has sampled the population parameters itself
+ * (samplePopParameters) and handed them over with gph_mcmc_set_chain: genealogies, event chains, statistics,
+ * likelihoods; the chain state then holds dataLogLikelihood / logLikelihood as :1216-1224 leave them */
+int gph_mcmc_initialize_genealogies(gph_mcmc *m);
+
 /* the same with a native communicator (RCCL or shared memory): what `G-PhoCS-hip -g N <control-file>` runs in each of
  * its N child processes */
 int gph_run_control_file_comm(const char *ctl_path, const char *secondary_ctl_path_or_null, int32_t device,
