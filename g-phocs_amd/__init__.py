@@ -54,7 +54,10 @@ VARIANTS = {  # name: (max leaves, max pops, max bands, waves per SIMD of the sw
     "s": (16, 9, 4, 6, "libgphocs_hip_s.so"),     # BASELINE configs[0..3]
     "l": (20, 13, 4, 5, "libgphocs_hip_l.so"),    # BASELINE configs[4] (20 leaves, 13 populations)
     "m": (24, 16, 8, 5, "libgphocs_hip.so"),
-    "x": (32, 32, 16, 4, "libgphocs_hip_x.so"),   # the engine's hard caps: one genealogy node per lane (2n-1 <= 63), 32-bit population masks
+    "x": (32, 32, 16, 4, "libgphocs_hip_x.so"),   # the largest variant with one genealogy node per lane (2n-1 <= 63) and 32-bit population sets
+    # the engine's hard caps: 64 leaves, the reference's own 39 populations (NSPECIES 20), 16 bands -- 128-bit node sets,
+    # 64-bit population sets, 16-bit event ids, list-driven pruning order instead of the lane-per-node wave programs
+    "h": (64, 40, 16, 2, "libgphocs_hip_h.so"),
 }
 
 
@@ -62,12 +65,12 @@ LIB_SOURCES = ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.c
 
 
 def variant_for(n, K, B):
-    for name in ("s", "l", "m", "x"):
+    for name in ("s", "l", "m", "x", "h"):
         cl, ck, cb, _, _ = VARIANTS[name]
         if n <= cl and K <= ck and B <= cb:
             return name
-    raise RuntimeError(f"model (leaves={n}, pops={K}, bands={B}) exceeds the engine's hard caps {VARIANTS['x'][:3]} "
-                       f"(one genealogy node per lane, 32-bit population masks); the reference's own compile-time caps are "
+    raise RuntimeError(f"model (leaves={n}, pops={K}, bands={B}) exceeds the engine's hard caps (64 leaves, 39 populations, "
+                       f"16 bands: 128-bit node sets, 4-bit band ids); the reference's own compile-time caps are "
                        f"200 leaves / 39 populations / 100 bands (upstream src/patch.h:17-22)")
 
 

@@ -394,10 +394,10 @@ static void build_model_static(gph_engine *e)
     m.popFather[p] = e->popFather[p];
     m.popSon0[p] = e->popSon0[p];
     m.popSon1[p] = e->popSon1[p];
-    uint32_t mask = 0;
+    gph_popmask mask = 0;
     for (int d = 0; d < c.K; d++) {           // isAncestralTo, self-inclusive (MCMCcontrol.c:851,977,1015-1024)
       int x = d;
-      while (x >= 0) { if (x == p) { mask |= 1u << d; break; } x = e->popFather[x]; }
+      while (x >= 0) { if (x == p) { mask |= (gph_popmask)1 << d; break; } x = e->popFather[x]; }
     }
     m.isAnc[p] = mask;
   }
@@ -793,7 +793,7 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
   if (cfg->n > 200 || cfg->K > 39 || cfg->B > 100)
     fprintf(stderr, "gphocs_hip: n=%d K=%d B=%d exceed even the reference's compile-time caps (NS 200, 2*NSPECIES-1 = 39, MAX_MIG_BANDS 100: upstream src/patch.h:17-22)\n", cfg->n, cfg->K, cfg->B);
   if (cfg->n < 2 || cfg->n > GPH_CAP_LEAVES || cfg->K > GPH_CAP_K || cfg->B > GPH_CAP_B || cfg->K != 2 * cfg->Kc - 1) {
-    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (this library variant: n<=%d leaves, K<=%d populations, B<=%d bands; the engine's hard caps are 32 / 32 / 16 -- one genealogy node per lane, 32-bit population masks -- against the reference's 200 / 39 / 100, upstream src/patch.h:17-22; rebuild with -DGPH_CAP_* up to the hard caps)\n",
+    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (this library variant: n<=%d leaves, K<=%d populations, B<=%d bands; the engine's hard caps are 64 / 39 / 16 -- 128-bit node sets, 4-bit band ids -- against the reference's 200 / 39 / 100, upstream src/patch.h:17-22; rebuild with -DGPH_CAP_* up to the hard caps)\n",
             cfg->n, cfg->K, cfg->B, GPH_CAP_LEAVES, GPH_CAP_K, GPH_CAP_B);
     return GPH_EARG;
   }
@@ -1465,8 +1465,10 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     // dynamic LDS of the scan: guest sequence block | reference sequence block | guest nodes | reference nodes | scratch
     const int seqb = align_up(GPH_Q_TERMS(Pmax, n) + (Pmax > GPH_WAVE ? 8 * Pmax : 0), 16), ndb = N * (int)sizeof(GphNode);
     const int fixed = 2 * seqb + 2 * ndb;
-    const int lfb = Pr >= 1 && Pr <= GPH_WAVE ? n * Pr * 32 : 0;      // the reference locus's leaves as conditional arrays
-    const int budget = 96 * 1024 - (int)sizeof(GphLds) - (n - 1) * GPH_WAVE * 16 - align_up(N * 8, 16) - lfb;
+    /* the compiled program of the reference locus is a lane-per-node construction: not in the big-tree variant */
+    const int progb = GPH_BIG_TREE ? 0 : (n - 1) * GPH_WAVE * 16;
+    const int lfb = !GPH_BIG_TREE && Pr >= 1 && Pr <= GPH_WAVE ? n * Pr * 32 : 0;      // the reference locus's leaves as conditional arrays
+    const int budget = 96 * 1024 - (int)sizeof(GphLds) - progb - align_up(N * 8, 16) - lfb;
     int Pscr = (budget - fixed) / ((n - 1) * 32);
     if (const char *ov = getenv("GPH_LR_PSCR")) Pscr = atoi(ov) < Pscr ? atoi(ov) : Pscr;   /* tests: force the global-scratch path */
     if (Pscr > Pmax) Pscr = Pmax;
@@ -1478,7 +1480,7 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     e->lr.o_rseq = seqb; e->lr.o_gnd = 2 * seqb; e->lr.o_rnd = 2 * seqb + ndb; e->lr.o_scr = fixed; e->lr.Pscr = Pscr;
     // behind the scratch: the reference locus's compiled program (one 16-byte entry per step and lane) and edge probabilities
     e->lr.o_prog = fixed + (n - 1) * Pscr * 32;
-    e->lr.o_pe = e->lr.o_prog + (n - 1) * GPH_WAVE * 16;
+    e->lr.o_pe = e->lr.o_prog + progb;
     e->lr.o_lf = lfb ? e->lr.o_pe + align_up(N * 8, 16) : 0;
     e->lr_lds_bytes = e->lr.o_pe + align_up(N * 8, 16) + lfb;
     e->lr.ref_seq_bytes = GPH_Q_BYTES(Pr, n);
@@ -1817,7 +1819,6 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
     const GphNode *nd = (const GphNode *)(pg + y.o_nd);
     const int16_t *ne = (const int16_t *)(pg + y.o_nev);
     const int16_t *first = (const int16_t *)(pg + y.o_first);
-    const uint64_t cbits = (uint64_t)(uint32_t)is[IS_CBIT0] | ((uint64_t)(uint32_t)is[IS_CBIT1] << 32);
     const GphEv *evr = (const GphEv *)(pg + y.o_ev);
     fprintf(f, "LOCUS %lld root %d dataLnL %a genLnL %a rng %u %u %u\n", (long long)(go + e->cfg.locus_begin), is[IS_ROOT],
             fs[FS_DATALNL], fs[FS_GENLNL], (unsigned)is[IS_RX], (unsigned)is[IS_RY], (unsigned)is[IS_RZ]);
@@ -1849,7 +1850,7 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
       int P = e->h_P[g];
       const char *cb = cond.data() + e->h_cond_off[g];
       for (int i = y.n; i < y.N; i++) {
-        const double *c = (const double *)(cb + ((size_t)((int)((cbits >> i) & 1) * (y.n - 1) + (i - y.n)) * P) * 32);
+        const double *c = (const double *)(cb + ((size_t)((int)(((uint32_t)is[IS_CBIT0 + (i >> 5)] >> (i & 31)) & 1) * (y.n - 1) + (i - y.n)) * P) * 32);
         fprintf(f, "K %d", i);
         for (int k = 0; k < 4 * P; k++) fprintf(f, " %a", c[k]);
         fprintf(f, "\n");

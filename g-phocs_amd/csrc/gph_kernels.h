@@ -750,7 +750,11 @@ GPH_DEV void kb_lrate_prep(const GphDev &D, int g, double finetune, GphLrPre *pr
 GPH_DEV void lr_load(const char *pg, const char *seqp, int seqbytes, int o_nd, int o_seq, int &root, double &rate, double &lnl, GphRng &rng)
 {
   static_assert(sizeof(GphNode) == 16, "one 16-byte word per node");
+#if GPH_BIG_TREE
+  gph_copy16_in(GPH_SMB + o_nd, pg + g_lay.o_nd, g_lay.N);
+#else
   gph_copy16_in1(GPH_SMB + o_nd, pg + g_lay.o_nd, g_lay.N);
+#endif
   copy16_g2l(o_seq, seqp, seqbytes);
   const double *fs = (const double *)(pg + g_lay.o_fscal);
   const int32_t *is = (const int32_t *)(pg + g_lay.o_iscal);
@@ -761,7 +765,7 @@ GPH_DEV void lr_load(const char *pg, const char *seqp, int seqbytes, int o_nd, i
   GPH_SYNC();
 }
 
-#ifndef GPH_HOSTEMU
+#if GPH_LANE_NODES
 // ---- the reference locus of the scan: its tree does not change while the scan runs, only its rate does, and it is
 // evaluated once per locus by a lone wavefront (at most one instruction every 4 cycles, whatever its type).  The
 // pruning order is therefore compiled ONCE per scan into a per-lane table: the internal nodes are sorted by height
@@ -971,7 +975,7 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
   double dataLnL = A.dataLnL, logL = A.logL, rateVar = A.rateVar;
   const double Ld = (double)D.Ltot;
   gdbl *gs = (gdbl *)A.gscr;
-#ifndef GPH_HOSTEMU
+#if GPH_LANE_NODES
   GphRefProg RP;
   lr_ref_compile(A, Pr, RP);
 #endif
@@ -1009,7 +1013,7 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
         lg = lik_private(A.o_gnd, 0, P, root, rnew, A.o_scr, P > A.Pscr ? gs : (gdbl *)0);
       }
       lnLd += lg;
-#ifndef GPH_HOSTEMU
+#if GPH_LANE_NODES
       const double lr = RP.T > 0 && Pr <= A.Pscr ? lr_ref_eval(A, RP, Pr, rrefnew)
                                                   : lik_private(A.o_rnd, A.o_rseq, Pr, rootr, rrefnew, A.o_scr, Pr > A.Pscr ? gs : (gdbl *)0);
 #else

@@ -35,7 +35,28 @@ template <bool GPH_GM> struct GphCtxT {
   // ever walked to visit the members of the set).
 #define m_dirty_get() pad64(IS_DIRTY0)
 #define m_cbit_get() pad64(IS_CBIT0)
-#define m_saved_get() pad64(IS_SAVED0)
+  // gph_nset: a set of genealogy nodes -- one 64-bit scalar up to 32 leaves, a pair beyond (GPH_BIG_TREE)
+#if GPH_BIG_TREE
+  struct gph_nset { uint64_t lo, hi; };
+  GPH_DEV static gph_nset ns_none() { gph_nset r = {0, 0}; return r; }
+  GPH_DEV static bool ns_has(const gph_nset &s, int i) { return (((i < 64 ? s.lo : s.hi) >> (i & 63)) & 1) != 0; }
+  GPH_DEV static gph_nset ns_with(gph_nset s, int i) { if (i < 64) s.lo |= (uint64_t)1 << i; else s.hi |= (uint64_t)1 << (i - 64); return s; }
+  GPH_DEV static gph_nset ns_flip(gph_nset s, int i) { if (i < 64) s.lo ^= (uint64_t)1 << i; else s.hi ^= (uint64_t)1 << (i - 64); return s; }
+  GPH_DEV static gph_nset ns_xor(gph_nset a, const gph_nset &b) { a.lo ^= b.lo; a.hi ^= b.hi; return a; }
+  GPH_DEV static bool ns_any(const gph_nset &s) { return (s.lo | s.hi) != 0; }
+#define NS_GET(k) ns_get_((k))
+#define NS_PUT(k, v) do { const gph_nset nsv_ = (v); setpad64((k), nsv_.lo); setpad64((k) + 2, nsv_.hi); } while (0)
+#else
+  typedef uint64_t gph_nset;
+  GPH_DEV static gph_nset ns_none() { return 0; }
+  GPH_DEV static bool ns_has(gph_nset s, int i) { return ((s >> i) & 1) != 0; }
+  GPH_DEV static gph_nset ns_with(gph_nset s, int i) { return s | ((uint64_t)1 << i); }
+  GPH_DEV static gph_nset ns_flip(gph_nset s, int i) { return s ^ ((uint64_t)1 << i); }
+  GPH_DEV static gph_nset ns_xor(gph_nset a, gph_nset b) { return a ^ b; }
+  GPH_DEV static bool ns_any(gph_nset s) { return s != 0; }
+#define NS_GET(k) pad64(k)
+#define NS_PUT(k, v) setpad64((k), (v))
+#endif
 
 // ---------------------------------------------------------------- accessors
 #define AGE(i) (gph_lds.nd[i].age)
@@ -91,7 +112,7 @@ template <bool GPH_GM> struct GphCtxT {
 #define setRBI(k, i, v) si16(&GphLds::rb_i, (k) * GPH_CAP_RB + (i), (v))
 #define ISC(k) GPH_PADGET(k)
 #define setISC(k, v) GPH_PADSET((k), (v))
-#define CBIT(i) ((int)((m_cbit_get() >> (i)) & 1))
+#define CBIT(i) ((int)ns_has(NS_GET(IS_CBIT0), (i)))
 // scratch
 #define DEV(inst, i) RFL((int)gph_lds.s_dev[inst][i])
 #define setDEV(inst, i, v) (gph_lds.s_dev[inst][i] = (uint8_t)(v))
@@ -214,6 +235,9 @@ GPH_DEV int gph_errcode() { return CNT(CN_ERROR); }
 
 #define pad64(k) ((uint64_t)(uint32_t)ISC(k) | ((uint64_t)(uint32_t)ISC((k) + 1) << 32))
 #define setpad64(k, v) do { const uint64_t pv64_ = (v); setISC((k), (int)(uint32_t)pv64_); setISC((k) + 1, (int)(uint32_t)(pv64_ >> 32)); } while (0)
+#if GPH_BIG_TREE
+GPH_DEV gph_nset ns_get_(int k) { gph_nset r; r.lo = pad64(k); r.hi = pad64(k + 2); return r; }
+#endif
 GPH_DEV void load_scalars() { r_pad.load(gph_lds.iscal, IS_COUNT); }
 GPH_DEV void flush_scalars() { r_pad.store(gph_lds.iscal, IS_COUNT); }
 
@@ -386,17 +410,17 @@ GPH_DEV double l_reflect(double x, double a, double b)
 // half of its double buffer
 GPH_DEV int lik_mark_cond(int node)
 {
-  const uint64_t bit = (uint64_t)1 << node, d = m_dirty_get();
-  if (CNT(CN_P) <= 0 || (d & bit)) return 1;
-  setpad64(IS_DIRTY0, d | bit);
-  setpad64(IS_CBIT0, m_cbit_get() ^ bit);
+  const gph_nset d = NS_GET(IS_DIRTY0);
+  if (CNT(CN_P) <= 0 || ns_has(d, node)) return 1;
+  NS_PUT(IS_DIRTY0, ns_with(d, node));
+  NS_PUT(IS_CBIT0, ns_flip(NS_GET(IS_CBIT0), node));
   return 0;
 }
 // copyNodeToSaved, LocusDataLikelihood.c:1864-1876
 GPH_DEV void lik_save_node(int node, int recalc)
 {
   if (recalc) lik_mark_cond(node);
-  setpad64(IS_SAVED0, m_saved_get() | ((uint64_t)1 << node));
+  NS_PUT(IS_SAVED0, ns_with(NS_GET(IS_SAVED0), node));
   gph_lds.sv[node] = gph_lds.nd[node];   /* one 16-byte record: age, father, left, right */
 }
 // adjustGenNodeAge, LocusDataLikelihood.c:875-882
@@ -408,8 +432,8 @@ GPH_DEV void lik_adjust_age(int node, double age)
 // resetSaved, LocusDataLikelihood.c:852-864
 GPH_DEV void lik_reset_saved()
 {
-  setISC(IS_SAVED0, 0); setISC(IS_SAVED1, 0);
-  setISC(IS_DIRTY0, 0); setISC(IS_DIRTY1, 0);
+  NS_PUT(IS_SAVED0, ns_none());
+  NS_PUT(IS_DIRTY0, ns_none());
   setISC(IS_SV_ROOT, -1);
   setFS(FS_SV_DATALNL, FS(FS_DATALNL));
 }
@@ -421,19 +445,24 @@ GPH_DEV void lik_revert()
 {
   setFS(FS_DATALNL, FS(FS_SV_DATALNL));
   if (ISC(IS_SV_ROOT) >= 0) { setISC(IS_ROOT, ISC(IS_SV_ROOT)); setISC(IS_SV_ROOT, -1); }
-  const uint64_t sv_ = m_saved_get();
-  if (sv_ != 0) {
-    GPH_EACH1(k, g_lay.N) {
-      if ((sv_ >> k) & 1) {
+  const gph_nset sv_ = NS_GET(IS_SAVED0);
+  if (ns_any(sv_)) {
+#if GPH_BIG_TREE
+    GPH_EACH(k, g_lay.N)
+#else
+    GPH_EACH1(k, g_lay.N)
+#endif
+    {
+      if (ns_has(sv_, k)) {
         GphNode r = gph_lds.sv[k];
         r.npop = gph_lds.nd[k].npop;     /* nodePops is not part of the saved version */
         gph_lds.nd[k] = r;
       }
     }
   }
-  setpad64(IS_CBIT0, m_cbit_get() ^ m_dirty_get());
-  setISC(IS_DIRTY0, 0); setISC(IS_DIRTY1, 0);
-  setISC(IS_SAVED0, 0); setISC(IS_SAVED1, 0);
+  NS_PUT(IS_CBIT0, ns_xor(NS_GET(IS_CBIT0), NS_GET(IS_DIRTY0)));
+  NS_PUT(IS_DIRTY0, ns_none());
+  NS_PUT(IS_SAVED0, ns_none());
 }
 
 // computeEdgeConditionalJC, LocusDataLikelihood.c:1831-1848
@@ -530,6 +559,12 @@ GPH_DEV void prune_node(int node)
   GPH_SYNC();
 }
 
+// GPH_LANE_NODES: the wave programs that keep one genealogy node per lane (2n - 1 <= 63): device builds up to 32 leaves
+#if !defined(GPH_HOSTEMU) && !GPH_BIG_TREE
+#define GPH_LANE_NODES 1
+#else
+#define GPH_LANE_NODES 0
+#endif
 #ifndef GPH_HOSTEMU
 GPH_DEV double bperm64(int byteaddr, double v)
 {
@@ -697,6 +732,8 @@ GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo,
   }
 }
 
+#endif   /* !GPH_HOSTEMU */
+#if GPH_LANE_NODES
 // computeLocusDataLikelihood, LocusDataLikelihood.c:426-483.  Device form: the genealogy
 // (father/left/right/age, one node per lane) and the dirty / current-buffer sets (64-bit
 // masks) are pulled into registers once; "which nodes must be recomputed" is a ballot
@@ -904,7 +941,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   (void)warm;
   useOld = RFL(useOld);
   int P = CNT(CN_P), i, node, k, sp, nord, U;
-  uint64_t need = 0;
+  gph_nset need = ns_none();
   double lnl;
   if (P == 0) return 0.0;
   const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n);
@@ -912,14 +949,14 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     for (node = n; node < N; node++) lik_mark_cond(node);
   setFS(FS_SV_DATALNL, FS(FS_DATALNL));
   if (!useOld) {
-    for (node = n; node < N; node++) need |= (uint64_t)1 << node;
+    for (node = n; node < N; node++) need = ns_with(need, node);
   } else {
     for (i = 0; i < N; i++) {
-      if (!((m_dirty_get() >> i) & 1)) continue;
+      if (!ns_has(NS_GET(IS_DIRTY0), i)) continue;
       node = i;
       int guard = 0;
-      while (node >= 0 && !((need >> node) & 1)) {
-        need |= (uint64_t)1 << node;
+      while (node >= 0 && !ns_has(need, node)) {
+        need = ns_with(need, node);
         node = FATH(node);
         if (++guard > N) { gph_fail(99); return FS(FS_DATALNL); }
       }
@@ -927,7 +964,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   }
   if (useOld) setCNT(CN_EVALS, CNT(CN_EVALS) + 1);
   node = ISC(IS_ROOT);
-  if (!((need >> node) & 1)) return FS(FS_DATALNL);
+  if (!ns_has(need, node)) return FS(FS_DATALNL);
   /* pre-order list of needed internal nodes */
   nord = 0;
   sp = 0;
@@ -937,9 +974,9 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     if (nord >= N) { gph_fail(100); return FS(FS_DATALNL); }
     si16(&GphLds::s_ord, nord++, node);
     k = LEFT(node);
-    if (k >= n && ((need >> k) & 1)) si16(&GphLds::s_stack, sp++, k);
+    if (k >= n && ns_has(need, k)) si16(&GphLds::s_stack, sp++, k);
     k = RGHT(node);
-    if (k >= n && ((need >> k) & 1)) si16(&GphLds::s_stack, sp++, k);
+    if (k >= n && ns_has(need, k)) si16(&GphLds::s_stack, sp++, k);
   }
   for (i = nord - 1; i >= 0; i--) {
     node = gi16(&GphLds::s_ord, i);
@@ -982,7 +1019,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
 // [n-1][P][4] (dynamic LDS at o_scr, or global memory when gscr != NULL).  Same arithmetic, same order of
 // operations as lik_compute(0): the serial scan of UpdateLocusRate (kb_lrate_scan) uses it to decide, the
 // accepted loci are then recomputed in place by lik_compute(0) and must reproduce the value bit for bit.
-#ifndef GPH_HOSTEMU
+#if GPH_LANE_NODES
 typedef GPH_LDS gph_d2 ld2;
 template <class DP, class DP2>
 GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rate, DP scr)
@@ -1108,8 +1145,8 @@ GPH_DEV double lik_private(int o_nd, int o_seq, int P, int root, double rate, in
   const int n = g_lay.n, N = g_lay.N;
   if (P == 0) return 0.0;
   const int q_leaf = o_seq + GPH_Q_LEAF, q_phases = o_seq + GPH_Q_PHASES(P, n), q_count = o_seq + GPH_Q_COUNT(P, n);
-  const GphNode *nds = (const GphNode *)(gph_sm + o_nd);
-  double *scr = gscr ? gscr : (double *)(gph_sm + o_scr);
+  const GphNode *nds = (const GphNode *)((char *)gph_sm + o_nd);
+  double *scr = gscr ? (double *)gscr : (double *)(gph_sm + o_scr);
   int ord[GPH_CAP_N], st[GPH_CAP_N], nord = 0, sp = 0, i, p;
   st[sp++] = root;
   while (sp > 0) {
@@ -1217,7 +1254,7 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
 {
   int node, mig, pop1, num = 0, f;
   if (UNI(g_model.popAge[pop] > time + 0.0000001)) return 0;
-#ifndef GPH_HOSTEMU
+#if GPH_LANE_NODES
   {
     const int lane = GPH_LANE;
     bool in = false;
@@ -1686,13 +1723,13 @@ GPH_DEVHOT double rubber_band(int pop, double age0, double static_point, double 
 GPH_DEV double rubber_band_ripple(int do_or_redo)
 {
   int i, pop, nw, orig, nmoved = ISC(IS_RB_NUM);
-  uint32_t affected = 0;
+  gph_popmask affected = 0;
   double delta = 0.0;
   if (nmoved == 0) return 0.0;
   for (i = 0; i < nmoved; i++) {
     pop = RBI(2, i);
     orig = RBI(0, i);
-    affected |= 1u << pop;
+    affected |= (gph_popmask)1 << pop;
     if (do_or_redo) {
       nw = create_event(pop, RBAGE(i));
       setRBI(1, i, nw);

@@ -21,14 +21,39 @@
 #pragma once
 #include <stdint.h>
 
-#define GPH_MAXK 32        // populations   (reference cap 39, patch.h:19)
+// Compile-time capacities of this build of the library (variants: g-phocs_amd/__init__.py).  Up to 32 leaves / 32
+// populations the per-locus code keeps one genealogy node per lane and 32-bit population sets; the largest variant
+// (64 leaves, the reference's own 39 populations) uses 128-bit node sets, 64-bit population sets, 16-bit event ids and
+// the list-driven forms of the functions that are lane-per-node programs below that size.
+#ifndef GPH_CAP_LEAVES
+#define GPH_CAP_LEAVES 24
+#endif
+#ifndef GPH_CAP_K
+#define GPH_CAP_K 16
+#endif
+#ifndef GPH_CAP_B
+#define GPH_CAP_B 8
+#endif
+#if GPH_CAP_K > 32
+#define GPH_MAXK 40        // populations (reference cap 2 * NSPECIES - 1 = 39, patch.h:19)
+typedef uint64_t gph_popmask;
+#else
+#define GPH_MAXK 32
+typedef uint32_t gph_popmask;
+#endif
 #define GPH_MAXB 16        // migration bands (reference cap 100, patch.h:17)
 #define GPH_MAX_MIGS 10    // migration events per genealogy (patch.h:18)
-#define GPH_MAXN 63        // genealogy nodes per locus (n <= 32 leaves)
+#if GPH_CAP_LEAVES > 32
+#define GPH_BIG_TREE 1     // 2n - 1 > 64 genealogy nodes: no lane-per-node programs, node sets of 128 bits
+#define GPH_NSW 4          // 32-bit page words per node set
+#else
+#define GPH_BIG_TREE 0
+#define GPH_NSW 2
+#endif
 #define GPH_OLDAGE 999.0   // patch.h:21
 #define GPH_WAVE 64
 #define FS_COUNT_ 5
-#define IS_COUNT_ 16
+#define IS_COUNT_ (10 + 3 * GPH_NSW)
 
 enum { GPH_COAL = 0, GPH_IN_MIG, GPH_OUT_MIG, GPH_MIG_BAND_START, GPH_MIG_BAND_END,
        GPH_SAMPLES_START, GPH_END_CHAIN, GPH_DUMMY };
@@ -43,7 +68,7 @@ struct GphModel {
   // and a ~50-instruction wave-uniform logarithm twice per proposal.  Kept current by gg_set_theta / gg_set_mig.
   double logTwoTheta[GPH_MAXK], logMigRate[GPH_MAXB];
   double migRate[GPH_MAXB], bandStart[GPH_MAXB], bandEnd[GPH_MAXB];
-  uint32_t isAnc[GPH_MAXK];            // bit d of isAnc[a]: a is ancestral to (or is) d
+  gph_popmask isAnc[GPH_MAXK];         // bit d of isAnc[a]: a is ancestral to (or is) d
   // 32-bit entries: a scalar load cannot fetch 16 bits, and a 16-bit table would be read with vector loads
   // (a VMEM round trip on the chain's critical path for a wave-uniform value)
   int32_t popFather[GPH_MAXK], popSon0[GPH_MAXK], popSon1[GPH_MAXK], samplesPerPop[GPH_MAXK];
@@ -113,8 +138,9 @@ enum { FS_DATALNL = 0, FS_SV_DATALNL, FS_GENLNL, FS_GENDELTA, FS_MUTRATE, FS_COU
 // conditionals were recomputed by the pending proposal (savedVersion.recalcConditionals, LocusDataLikelihood.c:75-104),
 // the half of the double buffer that holds each node's CURRENT conditionals, and the nodes whose record was saved
 // (savedVersion.changedNodeIds).  While a kernel works on the locus they are three scalar registers (GphCtx).
-enum { IS_ROOT = 0, IS_SV_ROOT, IS_DIRTY0, IS_DIRTY1, IS_CBIT0, IS_CBIT1, IS_SAVED0, IS_SAVED1, IS_FREE, IS_NUM_MIGS,
-       IS_RB_NUM, IS_CONFLICT_LOG, IS_RX, IS_RY, IS_RZ, IS_COUNT };
+enum { IS_ROOT = 0, IS_SV_ROOT, IS_DIRTY0, IS_CBIT0 = IS_DIRTY0 + GPH_NSW, IS_SAVED0 = IS_CBIT0 + GPH_NSW,
+       IS_FREE = IS_SAVED0 + GPH_NSW, IS_NUM_MIGS, IS_RB_NUM, IS_CONFLICT_LOG, IS_RX, IS_RY, IS_RZ, IS_COUNT };
+static_assert(IS_COUNT <= IS_COUNT_, "page scalars");
 // i16 fields per migration node (o_mig_i + 6*mig)
 enum { MG_BRANCH = 0, MG_BAND, MG_SPOP, MG_TPOP, MG_SEV, MG_TEV, MG_COUNT };
 
@@ -130,15 +156,6 @@ enum { OUT_ACCEPT = 0, OUT_DDATA, OUT_DLOG, OUT_EVALS, OUT_EVALNODES, OUT_EVALBY
 // offsets every access cost an extra scalar add + v_mov and serialised behind every store.
 // The HBM page is the page part of this struct verbatim (one coalesced copy in, one out).
 // Capacities cover every BASELINE config (config 5: 20 leaves, 13 populations, 4 bands).
-#ifndef GPH_CAP_LEAVES
-#define GPH_CAP_LEAVES 24
-#endif
-#ifndef GPH_CAP_K
-#define GPH_CAP_K 16
-#endif
-#ifndef GPH_CAP_B
-#define GPH_CAP_B 8
-#endif
 #define GPH_CAP_N (2 * GPH_CAP_LEAVES - 1)
 #define GPH_CAP_E (2 * GPH_CAP_LEAVES + 4 * GPH_MAX_MIGS + 3 * GPH_CAP_B + GPH_CAP_K + 10)
 #define GPH_CAP_RB (GPH_MAX_MIGS + 2 * GPH_CAP_B)
@@ -162,6 +179,11 @@ struct alignas(16) GphNode {
   int16_t npop;           // nodePops[gen][node] (unused in the saved copy)
 };
 
+#if GPH_CAP_E <= 255
+typedef uint8_t gph_evid;    // event ids of the pending-delta lists
+#else
+typedef uint16_t gph_evid;
+#endif
 struct alignas(16) GphLds {
   // ---- page (mirrors the HBM page arrays, GphLayout o_*)
   GphEv ev[GPH_CAP_E];
@@ -183,13 +205,13 @@ struct alignas(16) GphLds {
   uint32_t s_condptr[2];
   int16_t s_dpops[2][GPH_CAP_K], s_dbands[2][GPH_CAP_B], s_spri16[4 * GPH_MAX_MIGS];
   int16_t s_ord[GPH_CAP_N + 1], s_stack[GPH_CAP_N + 1], s_targets[GPH_CAP_N + 1], s_chknc[GPH_CAP_K], s_chknm[GPH_CAP_B];
-  uint8_t s_dev[2][GPH_CAP_E];   // event lists of the two pending deltas (event ids < 256)
+  gph_evid s_dev[2][GPH_CAP_E];  // event lists of the two pending deltas
 #ifdef GPH_PAD
   char s_pad[GPH_PAD];           // LDS-size sensitivity experiments only
 #endif
 };
 
-static_assert(GPH_CAP_E <= 255, "event ids are stored in 8 bits (s_dev)");
+static_assert(GPH_CAP_LEAVES <= 64 && GPH_CAP_K <= GPH_MAXK && GPH_CAP_B <= GPH_MAXB, "capacities beyond the engine's hard caps (64 leaves, 39 populations, 16 bands)");
 
 // arguments of the tau-evaluate kernel (host part of UpdateTau, GPhoCS.c:3224-3461)
 struct GphTauArgs {

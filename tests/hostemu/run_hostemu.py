@@ -13,15 +13,18 @@ import gphocs_amd as G  # noqa: E402
 HOSTEMU = os.path.join(REPO, "tests", "hostemu", "libgphocs_hostemu.so")
 
 
-def build_hostemu(sanitize=False):
+def build_hostemu(sanitize=False, big=False):
+    """big: the 64-leaf / 39-population capacities (library variant `h`: 128-bit node sets, 64-bit population sets,
+    16-bit event ids) -- a separate host build, as the capacities are compile-time"""
     csrc = os.path.join(REPO, "g-phocs_amd", "csrc")
     srcs = [os.path.join(csrc, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp", "gph_readtrace.cpp", "gph_comm.cpp")]
     deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.abspath(__file__)]
-    out = HOSTEMU.replace(".so", "_san.so") if sanitize else HOSTEMU
+    out = HOSTEMU.replace(".so", "_san.so") if sanitize else HOSTEMU.replace(".so", "_h.so") if big else HOSTEMU
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     # the engine's hard caps (library variant `x`): every golden fits, the image size does not matter on the host
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU", "-DGPH_CAP_LEAVES=32", "-DGPH_CAP_K=32", "-DGPH_CAP_B=16",
+    caps = ["-DGPH_CAP_LEAVES=64", "-DGPH_CAP_K=40", "-DGPH_CAP_B=16"] if big else ["-DGPH_CAP_LEAVES=32", "-DGPH_CAP_K=32", "-DGPH_CAP_B=16"]
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU"] + caps + [
            "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
            "-x", "c++"] + srcs + ["-lrt", "-o", out]
     if sanitize:

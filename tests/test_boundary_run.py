@@ -21,7 +21,7 @@ import pytest
 
 from conftest import GOLDEN, ORACLE_DIR, REPO
 
-CASES = ["g1", "m3", "a7", "f3", "v8", "w2", "x8"]
+CASES = ["g1", "m3", "a7", "f3", "v8", "w2", "x8"]   # (y9 needs the big-tree build of the engine sources: tests/test_host_logic.py, -m gpu)
 
 
 def _build():

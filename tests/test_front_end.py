@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
 import gphocs_amd as G  # noqa: E402
 import run_hostemu as R  # noqa: E402
 
-CASES = ["g1", "g2", "m3", "m4", "c5", "s3", "a6", "a7", "z0", "stress", "v8", "v9"]
+CASES = ["g1", "g2", "m3", "m4", "c5", "s3", "a6", "a7", "z0", "stress", "v8", "v9", "y9"]
 
 
 @pytest.fixture(scope="module")
@@ -252,3 +252,58 @@ def test_program_prints_the_reference_log(name, tmp_path):
         if name == "a7" and w != g and w.split()[:6] == g.split()[:6] and w.split()[7:] == g.split()[7:]:
             continue      # the uninitialised TAU entry of the first period
         assert w == g, (i, w, g)
+
+
+def test_reference_sample_control_file_end_to_end(lib, ref_cli, tmp_path):
+    """BASELINE configs[0]: the reference's OWN sample-control-file.ctl (read where it lies under /root/reference; it is
+    not copied into the repo, so this runs in the build container only).  Its sequence file is absent upstream
+    (.MISSING_LARGE_BLOBS), so a small synthetic one with the file's sample names is written here; a secondary control
+    file gives the seed and a short run.  The model, the priors, every phased pattern table and the trace file must equal
+    the real reference's for the same three files."""
+    import random
+    import subprocess
+    src = "/root/reference/sample-control-file.ctl"
+    if not os.path.exists(src) or ref_cli is None:
+        pytest.skip("the reference tree is absent on this box")
+    shutil.copy(src, tmp_path / "sample.ctl")
+    rnd = random.Random(20261002)
+    names = ["one", "two", "three", "five"]           # the `samples ... d` entries of the file's four current populations
+    with open(tmp_path / "seqs-sample.txt", "w") as f:
+        f.write("9\n\n")
+        for g in range(9):
+            L = 220
+            base = [rnd.choice("TCAG") for _ in range(L)]
+            f.write(f"locus{g + 1} {len(names)} {L}\n")
+            for s in names:
+                row = []
+                for b in base:
+                    u = rnd.random()
+                    row.append(b if u < 0.93 else rnd.choice("TCAG") if u < 0.96 else rnd.choice("YRMKSW") if u < 0.995 else "N")
+                f.write(f"{s}\t{''.join(row)}\n")
+            f.write("\n")
+    (tmp_path / "short.ctl").write_text("GENERAL-INFO-START\n\trandom-seed 4711\n\tmcmc-iterations 40\n\titerations-per-log 10\n"
+                                        "\tlogs-per-line 2\nGENERAL-INFO-END\n")
+    env = dict(os.environ, GPH_REF_CTL2="short.ctl")
+    subprocess.run([ref_cli, "pack", "sample.ctl", "ref.gpk"], cwd=tmp_path, check=True, capture_output=True, timeout=300, env=env)
+    ref = G.Pack.load(str(tmp_path / "ref.gpk"))
+    with _in_dir(tmp_path):
+        got = G.Pack.from_control("sample.ctl", lib=lib, secondary="short.ctl")
+    assert (got.n, got.Kc, got.K, got.B) == (8, 4, 7, 1) == (ref.n, ref.Kc, ref.K, ref.B)
+    for f in ("rootPop", "L", "seed", "samplesPerLog", "numParameters", "ftCoalTime", "ftMigTime", "ftTheta", "ftMigRate", "ftMixing", "popName"):
+        assert getattr(ref, f) == getattr(got, f), f
+    for f in ("samplesPerPop", "popFather", "popSon0", "popSon1", "thetaAlpha", "thetaBeta", "thetaStart", "ageAlpha", "ageBeta",
+              "ageStart", "ftTaus", "printFactors", "pattern_offsets", "leafcodes", "numPhases", "counts"):
+        assert np.array_equal(np.asarray(getattr(ref, f)), np.asarray(getattr(got, f))), f
+    # the whole program: the real binary's trace file (mcmc.log) against gph_run_control_file's
+    subprocess.run([ref_cli, "main", "-n", "1", "sample.ctl", "short.ctl"], cwd=tmp_path, check=True, capture_output=True, timeout=600)
+    want = open(tmp_path / "mcmc.log").read()
+    os.remove(tmp_path / "mcmc.log")
+    with _in_dir(tmp_path):
+        assert lib.gph_run_control_file(b"sample.ctl", b"short.ctl", 0, 0) == 0
+    got_t = open(tmp_path / "mcmc.log").read()
+    w, g = want.splitlines(), got_t.splitlines()
+    assert w[0] == g[0] and len(w) == len(g) == 41
+    for a, b in zip(w[1:], g[1:]):
+        if a != b:
+            af, bf = [float(x) for x in a.split()], [float(x) for x in b.split()]
+            assert all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(af, bf)), (a, b)

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, "a7": 100, "z0": 12, "v8": 60, "v9": 60,
          "w2": 50,   # w2: model from a primary + a secondary control file
-         "x8": 24}   # x8: the engine's hard caps (32 leaves, 31 populations, 16 bands; library variant x)
+         "x8": 24,   # x8: 32 leaves, 31 populations, 16 bands: the largest lane-per-node build (library variant x)
+         "y9": 16}   # y9: 40 leaves, 39 populations (the reference's NSPECIES cap), 16 bands: library variant h
 
 
 @pytest.fixture(scope="module")
@@ -322,7 +323,7 @@ def test_native_library_is_the_path(G):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "y9"])
 def test_program_trace_file(name, tmp_path):
     """G-PhoCS-hip <control-file> on the MI355X: the trace file of the real G-PhoCS binary for the same
     control + sequence files (tests/golden/*.trace), to the printed precision (%8.5f / %.6f)."""

@@ -35,6 +35,21 @@ def test_hostemu_matches_reference_goldens(hostemu, name, iters, tmp_path):
     assert worst < 1e-12
 
 
+@pytest.mark.parametrize("name,iters", [("y9", 16), ("x8", 24), ("m3", 120), ("a7", 100), ("v8", 60)])
+def test_big_tree_build_matches_reference_goldens(name, iters, tmp_path):
+    """the 64-leaf / 39-population capacities (library variant `h`: 128-bit node sets, 64-bit population sets, 16-bit
+    event ids, list-driven forms instead of the lane-per-node programs): golden y9 -- 40 leaves, 20 current populations
+    = the reference's NSPECIES cap (patch.h:19), 16 bands, from the real reference -- and goldens of the smaller builds"""
+    import run_hostemu as R
+    import gphocs_amd as G
+    lib = G.load_library(R.build_hostemu(big=True))
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(os.path.join(GOLDEN, name + ".gpk"), iters, str(tr), str(st), iters - 1, lib=lib)
+    worst = compare_records(tr, os.path.join(GOLDEN, name + ".rtrace"))
+    compare_states(st, os.path.join(GOLDEN, name + ".state"))
+    assert worst < 1e-12
+
+
 def test_c_abi_library_exports_every_declared_symbol():
     """build the real HIP library (hipcc cross-compiles without a GPU) and check that every function
     declared in include/gphocs_hip.h is exported (no compute calls: there is no GPU here)"""

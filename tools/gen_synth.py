@@ -35,6 +35,8 @@ CONFIGS = {
     7: dict(pops=[2, 1, 2], bands=[(0, 1), (1, 0), (2, 1)], loci=1000, ancient=1, ancient_est=True),
     # the engine's hard caps: 32 leaves (16 diploids, one per population), 31 populations, 16 migration bands
     8: dict(pops=[1] * 16, bands=[(i, i + 1) for i in range(8)] + [(i + 1, i) for i in range(8)], loci=1000, tau_factor=1.3),
+    # the reference's own population cap (NSPECIES 20, patch.h:19): 20 current populations (39 in all), 40 leaves, 16 bands
+    9: dict(pops=[1] * 20, bands=[(i, i + 1) for i in range(8)] + [(i + 1, i) for i in range(8)], loci=1000, tau_factor=1.25),
 }
 
 
