@@ -404,6 +404,11 @@ static void build_model_static(gph_engine *e)
   int cum = 0;
   for (int p = 0; p < c.Kc; p++) { m.samplesPerPop[p] = e->samplesPerPop[p]; cum += e->samplesPerPop[p]; m.cumSamples[p] = cum; }
   for (int b = 0; b < c.B; b++) { m.bandSrc[b] = e->bandSrc[b]; m.bandTgt[b] = e->bandTgt[b]; }
+  for (int p = 0; p < c.K; p++) {
+    uint32_t over = 0;
+    for (int b = 0; b < c.B; b++) if ((m.isAnc[e->bandTgt[b]] >> p) & 1) over |= 1u << b;
+    m.bandsOver[p] = over;
+  }
   // populationPostOrder(rootPop), patch.c:1936-1951
   std::vector<int> order;
   struct Rec { static void go(gph_engine *e, int pop, std::vector<int> &o) {

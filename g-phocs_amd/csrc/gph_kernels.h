@@ -217,12 +217,13 @@ template <class RNG> GPH_DEV void sweep_internal(const GphDev &D, int g, double 
     tb0 = g_model.popAge[pop];
     if (pop != g_lay.rootPop) tb1 = g_model.popAge[g_model.popFather[pop]];
     else tb1 = GPH_OLDAGE;
-    mig = find_first_mig(inode, -1);
+    int migs[2];
+    mig_bounds(inode, me.left, me.right, mig, migs[0], migs[1]);
     if (mig >= 0) tb1 = gmin2(tb1, MAGE(mig));
     else if (inode != ISC(IS_ROOT)) tb1 = gmin2(tb1, AGE(me.father));
     for (i = 0; i < 2; i++) {
       son = i == 0 ? me.left : me.right;
-      mig = find_last_mig(son, -1);
+      mig = migs[i];
       if (mig >= 0) tb0 = gmax2(tb0, MAGE(mig));
       else tb0 = gmax2(tb0, AGE(son));
     }
@@ -334,7 +335,7 @@ template <class RNG> GPH_DEV void sweep_spr(const GphDev &D, int g, RNG &rng)
         if (target == father) target = sibling;
         if (MG(mig, MG_BRANCH) == target && MAGE(mig) >= t_new) setMG(mig, MG_BRANCH, father);
       }
-      remove_event(SPRI(SI_FEV_OLD));
+      remove_event(SPRI(SI_FEV_OLD), father_pop_old);
       fen = SPRI(SI_FEV_NEW);
       setETYPE(fen, GPH_COAL);
       setENODE(fen, father);
@@ -355,10 +356,11 @@ template <class RNG> GPH_DEV void sweep_spr(const GphDev &D, int g, RNG &rng)
       STAMPC_END(2);
     } else {
       STAMPC_BEGIN(3);
-      if (res >= 0) remove_event(SPRI(SI_FEV_NEW));
+      if (res >= 0) remove_event(SPRI(SI_FEV_NEW), SPRI(SI_FPOP_NEW));
       for (i = 0; i < SPRI(SI_NNEW); i++) {
-        remove_event(SPRA(SA_NEWIN, i));
-        remove_event(SPRA(SA_NEWOUT, i));
+        b = SPRA(SA_NEWBAND, i);
+        remove_event(SPRA(SA_NEWIN, i), g_model.bandTgt[b]);
+        remove_event(SPRA(SA_NEWOUT, i), g_model.bandSrc[b]);
       }
       GPH_EACH(k, DI(0, DI_NEV)) { const int q = gph_lds.s_dev[0][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + 1); }
       lik_revert();
@@ -569,7 +571,7 @@ GPH_DEV void tau_commit_body(gph_cfin &F)
     } else if (ETYPE(nw) == GPH_OUT_MIG) {
       setMG(mig, MG_SEV, nw);
     }
-    remove_event(RBI(0, i));
+    remove_event(RBI(0, i), RBI(2, i));
   }
   setISC(IS_RB_NUM, 0);
   if (F.isRoot) {

@@ -1247,6 +1247,21 @@ GPH_DEV int find_first_mig(int node, double age)
   }
   return first;
 }
+// findFirstMig(inode, -1), findLastMig(left, -1), findLastMig(right, -1) (patch.c:374-414) in ONE pass over the
+// locus's migration nodes: the three searches of UpdateGB_InternalNode's bounds (GPhoCS.c:2334-2352) filter on three
+// different branches, so every migration node feeds at most one of them and the results are the ones of three passes
+GPH_DEV void mig_bounds(int inode, int left, int right, int &first_up, int &last_l, int &last_r)
+{
+  int i, mig, br, nm = ISC(IS_NUM_MIGS);
+  first_up = last_l = last_r = -1;
+  for (i = 0; i < nm; i++) {
+    mig = LIVING(i);
+    br = MG(mig, MG_BRANCH);
+    if (br == inode) { if (MAGE(mig) > -1 && (first_up < 0 || MAGE(mig) < MAGE(first_up))) first_up = mig; }
+    else if (br == left) { if (last_l < 0 || MAGE(mig) > MAGE(last_l)) last_l = mig; }
+    else if (br == right) { if (last_r < 0 || MAGE(mig) > MAGE(last_r)) last_r = mig; }
+  }
+}
 // getEdgesForTimePop, patch.c:526-571 (targets written to s_targets, increasing node id).
 // Device form: one lane per genealogy node evaluates the membership test, a ballot yields the
 // candidate set in node order (the order decides which edge a sampled coalescence picks).
@@ -1293,17 +1308,22 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
 }
 
 // ---------------------------------------------------------------- event chain
-// removeEvent, patch.c:1666-1700
-GPH_DEV void remove_event(int ev)
+// removeEvent, patch.c:1666-1700.  pop = the population whose chain holds the event: upstream finds it, when the event
+// heads its chain, by walking to the chain's END_CHAIN event (:1680-1686); every caller here knows it (the host build
+// of the tests still walks and checks the caller's claim on every golden)
+GPH_DEV void remove_event(int ev, int pop)
 {
   const GphEvS R = ld_ev(ev);
   int nx = R.next, pv = R.prev;
   setEVT(nx, EVT(nx) + R.time);
   setEPREV(nx, pv);
   if (pv < 0) {
+#ifdef GPH_HOSTEMU
     int guard = 0;
     for (pv = nx; ETYPE(pv) != GPH_END_CHAIN; pv = ENEXT(pv)) { if (++guard > g_lay.E || ENEXT(pv) < 0) { gph_fail(91); return; } }
-    setFIRSTEV(ENODE(pv), nx);
+    if (ENODE(pv) != pop) { gph_fail(91); return; }
+#endif
+    setFIRSTEV(pop, nx);
   } else {
     setENEXT(pv, nx);
   }
@@ -1509,8 +1529,10 @@ GPH_DEV void mig_stats_delta(int inst, double bottom_age, int bottom_pop, double
 {
   int b, nb = 0;
   double dt, lo, hi;
-  for (b = 0; b < g_lay.B; b++) {
-    if (!((g_model.isAnc[g_model.bandTgt[b]] >> bottom_pop) & 1)) continue;
+  /* the bands whose target population is bottom_pop or above it, in band order (the filter of patch.c:1846 as one
+   * table word per population) */
+  for (uint32_t over = g_model.bandsOver[bottom_pop]; over != 0; over &= over - 1) {
+    b = __builtin_ctz(over);
     hi = gmin2(g_model.bandEnd[b], top_age);
     lo = gmax2(g_model.bandStart[b], bottom_age);
     dt = hi - lo;
@@ -1570,6 +1592,8 @@ GPH_DEVHOT double consider_event_move(int inst, int event_id, int source_pop, do
   if (new_event < 0) { gph_fail(13); return 0.0; }
   setDI(inst, DI_ORIG, event_id);
   setDI(inst, DI_UPD, new_event);
+  setDI(inst, DI_SRCPOP, source_pop);
+  setDI(inst, DI_TGTPOP, target_pop);
   if (new_age > original_age) {
     dlin = (ETYPE(event_id) == GPH_OUT_MIG) ? (-1) : (1);
     bottom_event = ENEXT(event_id);
@@ -1624,14 +1648,14 @@ GPH_DEV void accept_event_chain_changes(int inst)
     case GPH_IN_MIG: setMG(ENODE(ue), MG_TEV, ue); break;
     default: gph_fail(14); break;
     }
-    remove_event(oe);
+    remove_event(oe, DI(inst, DI_SRCPOP));
   }
   delta_clear(inst);
 }
 // rejectEventChainChanges, patch.c:1639-1661
 GPH_DEV void reject_event_chain_changes(int inst)
 {
-  if (DI(inst, DI_UPD) >= 0) remove_event(DI(inst, DI_UPD));
+  if (DI(inst, DI_UPD) >= 0) remove_event(DI(inst, DI_UPD), DI(inst, DI_TGTPOP));
   delta_clear(inst);
 }
 
@@ -1741,7 +1765,7 @@ GPH_DEV double rubber_band_ripple(int do_or_redo)
       nw = RBI(1, i);
       setETYPE(orig, ETYPE(nw));
       if (FIRSTEV(pop) == nw) setENLIN(ENEXT(nw), ENLIN(nw));
-      remove_event(nw);
+      remove_event(nw, pop);
     }
   }
   for (pop = 0; pop < g_lay.K; pop++)
@@ -2032,8 +2056,8 @@ GPH_DEV void replace_mig_nodes(int node)
   for (i = 0; i < mx; i++) {
     if (i < nold) {
       mig = SPRA(SA_OLD, i);
-      remove_event(MG(mig, MG_SEV));
-      remove_event(MG(mig, MG_TEV));
+      remove_event(MG(mig, MG_SEV), MG(mig, MG_SPOP));
+      remove_event(MG(mig, MG_TEV), MG(mig, MG_TPOP));
       b = MG(mig, MG_BAND);
       setNMIGB(b, NMIGB(b) - 1);
     } else {

@@ -69,6 +69,7 @@ struct GphModel {
   double logTwoTheta[GPH_MAXK], logMigRate[GPH_MAXB];
   double migRate[GPH_MAXB], bandStart[GPH_MAXB], bandEnd[GPH_MAXB];
   gph_popmask isAnc[GPH_MAXK];         // bit d of isAnc[a]: a is ancestral to (or is) d
+  uint32_t bandsOver[GPH_MAXK];        // bit b of bandsOver[p]: band b's target population is p or an ancestor of p (computeMigStatsDelta's filter, patch.c:1846)
   // 32-bit entries: a scalar load cannot fetch 16 bits, and a 16-bit table would be read with vector loads
   // (a VMEM round trip on the chain's critical path for a wave-uniform value)
   int32_t popFather[GPH_MAXK], popSon0[GPH_MAXK], popSon1[GPH_MAXK], samplesPerPop[GPH_MAXK];
@@ -124,7 +125,7 @@ struct GphKargs {
 #define GPH_Q_BYTES(P, n) ((GPH_Q_COUNT(P, n) + 4 * (P) + 15) & ~15)
 #define GPH_Q_TERMS(P, n) GPH_Q_BYTES(P, n)
 // delta scalars (s_di[inst])
-enum { DI_ORIG = 0, DI_UPD, DI_DLIN, DI_NEV, DI_NPOPS, DI_NBANDS, DI_COUNT };
+enum { DI_ORIG = 0, DI_UPD, DI_DLIN, DI_NEV, DI_NPOPS, DI_NBANDS, DI_SRCPOP, DI_TGTPOP, DI_COUNT };   // DI_SRCPOP / DI_TGTPOP: the populations of the original / the new event
 // spr scalars (register lanes, GphCtx), i16 arrays (s_spri16 + 10*k), f64 (s_sprf: new_ages[0..9], dlnLd[10..11])
 enum { SI_FEV_OLD = 0, SI_FEV_NEW, SI_FPOP_NEW, SI_TARGET, SI_NOLD, SI_NNEW, SI_COUNT };
 enum { SA_OLD = 0, SA_NEWIN, SA_NEWOUT, SA_NEWBAND };
