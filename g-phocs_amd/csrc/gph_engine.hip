@@ -27,6 +27,7 @@ GphLayout g_lay;
 GphModel g_model;
 GphGlobal *gph_G_emu = nullptr;
 #define GPH_KERNEL(name, ...) static void name(int gph_blk, __VA_ARGS__)
+#define GPH_SWEEP_WAVES_ 6
 #define GPH_SWEEP_ATTR
 #define GPH_BLK gph_blk
 #else
@@ -37,6 +38,7 @@ GphGlobal *gph_G_emu = nullptr;
 #define GPH_SWEEP_WAVES 5
 #endif
 #define GPH_SWEEP_ATTR __attribute__((amdgpu_waves_per_eu(GPH_SWEEP_WAVES, GPH_SWEEP_WAVES)))
+#define GPH_SWEEP_WAVES_ GPH_SWEEP_WAVES
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "gphocs_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return GPH_EHIP; } } while (0)
 #endif
 
@@ -382,7 +384,7 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   // dynamic LDS: the locus' sequence block (same bytes as its HBM block, laid out by its own P: GPH_Q_* in
   // gph_types.h) + per-pattern terms of the root reduction for loci with more than one pattern per lane
   y.Pmax = Pmax;
-  y.lds_bytes = GPH_Q_TERMS(Pmax, n) + (Pmax > GPH_WAVE ? 8 * Pmax : 0);
+  y.lds_bytes = GPH_Q_TERMS(Pmax, n) + (Pmax > GPH_WAVE ? 8 * Pmax : 8 * GPH_WAVE);
 }
 
 static void build_model_static(gph_engine *e)
@@ -937,6 +939,17 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
       gph_engine::Bucket bk;
       bk.j0 = (int)nwide; bk.count = (int)(L - nwide);
       bk.lds_bytes = GPH_Q_BYTES(pn, n);
+      /* the per-lane terms of the root reduction through LDS (ordered_sum64_lds: one vector instruction per pattern
+       * instead of three) take 512 more bytes per workgroup: only when that does not cost a resident workgroup.  LDS is
+       * handed out in 1280-byte granules (160 KB / 128, measured: DESIGN.md section 8.2); the sweep kernel keeps at
+       * most GPH_SWEEP_WAVES workgroups per SIMD */
+      {
+        auto resident = [](int bytes) { const int g = (bytes + 1279) / 1280; const int w = 128 / g; return w < 4 * GPH_SWEEP_WAVES_ ? w : 4 * GPH_SWEEP_WAVES_; };
+        const int base = (int)sizeof(GphLds) + bk.lds_bytes;
+        e->lay.lds_sum = resident(base + 8 * GPH_WAVE) == resident(base) ? 1 : 0;
+        if (const char *ov = getenv("GPH_LDS_SUM")) e->lay.lds_sum = atoi(ov) != 0;   /* tests: force either form */
+        if (e->lay.lds_sum) bk.lds_bytes += 8 * GPH_WAVE;
+      }
       e->buckets.push_back(bk);
     }
   }

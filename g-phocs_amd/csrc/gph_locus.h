@@ -596,6 +596,33 @@ GPH_DEVHOT double ordered_sum64(double term, int P)
   return s;
 }
 #endif
+// the same sum with the terms handed over through LDS: every lane stores its term once, then every lane reads term k
+// at a uniform address (a broadcast read, two terms per 16-byte read) and adds it -- ONE vector instruction per pattern
+// instead of three (two lane reads + the add), at the price of one LDS read per two patterns.  The reads are
+// independent of the running sum and are issued ahead of it.  q_terms: 512 bytes of the dynamic LDS behind the sequence
+// block, allocated by the host when they do not cost a resident workgroup (g_lay.lds_sum, gph_engine_load_loci).
+// Measured: -4 % vector instructions per sweep wavefront, -1.0 % sweep time.
+#if !defined(GPH_HOSTEMU)
+GPH_DEVHOT double ordered_sum64_lds(double term, int P, int q_terms)
+{
+  lf64 *t = (lf64 *)(GPH_SMB + q_terms);
+  t[GPH_LANE] = term;
+  GPH_WAVE_FENCE();
+  double s = 0.0;
+#define GPH_ADD8L(b) s += t[(b) + 0]; s += t[(b) + 1]; s += t[(b) + 2]; s += t[(b) + 3]; s += t[(b) + 4]; s += t[(b) + 5]; s += t[(b) + 6]; s += t[(b) + 7];
+  GPH_ADD8L(0)
+  if (P > 8) { GPH_ADD8L(8)
+  if (P > 16) { GPH_ADD8L(16)
+  if (P > 24) { GPH_ADD8L(24)
+  if (P > 32) { GPH_ADD8L(32)
+  if (P > 40) { GPH_ADD8L(40)
+  if (P > 48) { GPH_ADD8L(48)
+  if (P > 56) { GPH_ADD8L(56) } } } } } } }
+#undef GPH_ADD8L
+  GPH_WAVE_FENCE();
+  return s;
+}
+#endif
 // prune_node() with every tree scalar already in (scalar) registers
 template <class DP>
 GPH_DEV void prune_node_r(int node, int l, int r, double pl, double pr, int cbn, int cbl, int cbr, int P, DP cb,
@@ -908,7 +935,8 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       term = gph_log(avg) * gi32v(q_count, lane);
     }
     U = __builtin_popcountll(__ballot(ph > 0));
-    lnl = ordered_sum64(term, P);
+    if (g_lay.lds_sum) lnl = ordered_sum64_lds(term, P, q_terms);
+    else lnl = ordered_sum64(term, P);
   } else {
     GPH_WAVE_FENCE();
     for (int p = lane; p < P; p += GPH_NLANES) {

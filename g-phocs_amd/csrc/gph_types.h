@@ -95,6 +95,7 @@ struct GphLayout {
   int32_t page_bytes;      // multiple of 16: the page part of GphLds
   int32_t Pmax;            // max phased patterns of any locus on this device
   int32_t lds_bytes;       // largest dynamic-LDS allocation of a launch (sequence block [+ terms])
+  int32_t lds_sum;         // 1: the root reduction hands its per-pattern terms over through 512 bytes of dynamic LDS (ordered_sum64_lds)
 };
 struct GphGlobal;
 // model + layout tables travel BY VALUE as the first argument of every kernel: in the kernarg segment every

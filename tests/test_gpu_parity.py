@@ -533,3 +533,16 @@ def test_fused_finish_equals_separate_finish_kernels(G, tmp_path, name):
     assert open(a + ".state").read() == open(b + ".state").read()
     compare_records(a, os.path.join(GOLDEN, name + ".rtrace"))
     assert hs_a["launches"] < hs_b["launches"], (hs_a, hs_b)
+
+
+@pytest.mark.parametrize("name", ["m3", "g2", "x8"])
+def test_root_sum_through_lds_equals_lane_reads(G, tmp_path, name):
+    """the ordered per-pattern sum of the root reduction with the terms handed over through LDS (one vector instruction
+    per pattern) against the lane-read form: the same additions in the same order -- byte-identical records and state"""
+    pack = os.path.join(GOLDEN, name + ".gpk")
+    a, b = str(tmp_path / "lds.rec"), str(tmp_path / "lane.rec")
+    _records(G, pack, CASES[name], a, env={"GPH_LDS_SUM": "1"})
+    _records(G, pack, CASES[name], b, env={"GPH_LDS_SUM": "0"})
+    assert open(a).read() == open(b).read()
+    assert open(a + ".state").read() == open(b + ".state").read()
+    compare_records(a, os.path.join(GOLDEN, name + ".rtrace"))

@@ -42,3 +42,25 @@ try:
 except OSError:
     pass
 print(json.dumps({k2: b[k2] for k2 in ("value", "ms_per_step", "mcmc_iters_per_sec")}), b["roofline"]["frac"], b.get("cpu_baseline", {}).get("value"))
+
+# BASELINE configs[4] at its stated size (tools/profile_config5.sh), when its outputs are there: ONE run per file.  The data
+# set has loci with more than 64 phased patterns, so every kernel class is TWO dispatches per launch point (the few
+# pattern-rich loci first, then everything else): the per-dispatch average of the kernel-stats CSV is not a per-sweep
+# time -- the per-sweep figure below is the summed duration of the class divided by the iterations of the run.
+import csv
+import os
+if os.path.exists("gpurun_out/config5_bench.json") and os.path.exists("gpurun_out/config5_kstats/k_kernel_stats.csv"):
+    cb = json.load(open("gpurun_out/config5_bench.json"))
+    rows = {r["Name"].split("(")[0]: r for r in csv.DictReader(open("gpurun_out/config5_kstats/k_kernel_stats.csv"))}
+    iters = cb.get("preroll_iterations", 0) + 15
+    sw = rows["k_sweep"]
+    cb["rocprofv3_kernel_stats"] = {
+        "k_sweep_dispatches": int(sw["Calls"]), "iterations_of_the_run": iters, "dispatches_per_sweep": int(sw["Calls"]) / iters,
+        "k_sweep_ms_per_sweep": float(sw["TotalDurationNs"]) / iters / 1e6,
+        "k_sweep_max_dispatch_ms": float(sw["MaxNs"]) / 1e6, "k_sweep_min_dispatch_ms": float(sw["MinNs"]) / 1e6,
+        "note": "two dispatches per sweep (loci with > 64 phased patterns, then the rest): compare ms_per_sweep with sweep_ms"}
+    json.dump(cb, open(f"profiles/{rnd}_config5_bench.json", "w"), indent=1)
+    shutil.copy("gpurun_out/config5_kstats/k_kernel_stats.csv", f"profiles/{rnd}_config5_kernel_stats.csv")
+    if os.path.exists("gpurun_out/config5_pmc.json"):
+        shutil.copy("gpurun_out/config5_pmc.json", f"profiles/{rnd}_config5_pmc.json")
+    print("config5:", cb["evals_per_s"], cb["sweep_ms"], cb["sweep_roofline_frac"], cb["rocprofv3_kernel_stats"])
