@@ -186,10 +186,27 @@ def test_other_configs_at_full_size(G, oracle_cli, tmp_path, idx):
     pth = str(tmp_path / "full.gpk")
     synth.write_pack(pk, pth)
     mine, theirs = str(tmp_path / "hip.rec"), str(tmp_path / "oracle.rec")
-    cnt, _ = _run(G, pk, 4, mine)
-    subprocess.run([oracle_cli, "run", pth, "4", theirs], check=True, timeout=1800)
+    # per-locus state too (genealogy, event chains with ids and lineage counts, statistics, RNG slots) of every 50th
+    # locus after the last iteration, field by field
+    os.environ["GPH_DUMP_STRIDE"] = "50"
+    try:
+        s = G.Sampler(pk)
+        s.set_record_file(mine)
+        s.initialize()
+        for it in range(4):
+            s.iteration(it)
+        s.dump_state(mine + ".state", False)
+        s.set_record_file(None)
+        cnt = s.counters()
+        s.close()
+        subprocess.run([oracle_cli, "run", pth, "4", theirs, theirs + ".state", "3", "0"], check=True, timeout=1800)
+    finally:
+        os.environ.pop("GPH_DUMP_STRIDE", None)
     os.unlink(pth)
     worst = compare_records(mine, theirs)
+    from parity_util import compare_states
+    compare_states(mine + ".state", theirs + ".state")
+    assert sum(1 for l in open(mine + ".state") if l.startswith("LOCUS ")) == c["L"] // 50
     assert any(l.startswith("IT 3 CHECK") for l in open(mine).read().splitlines())
     # (b)
     iters, spl = 12, 4
