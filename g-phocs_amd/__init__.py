@@ -57,6 +57,7 @@ VARIANTS = {  # name: (max leaves, max pops, max bands, waves per SIMD of the sw
     "x": (32, 32, 16, 4, "libgphocs_hip_x.so"),   # the largest variant with one genealogy node per lane (2n-1 <= 63) and 32-bit population sets
     # the engine's hard caps: 64 leaves, the reference's own 39 populations (NSPECIES 20), 16 bands -- 128-bit node sets,
     # 64-bit population sets, 16-bit event ids, list-driven pruning order instead of the lane-per-node wave programs
+    "g": (48, 16, 8, 3, "libgphocs_hip_g.so"),    # many samples, few populations (e.g. 20 diploids over 5 populations): the big-tree forms with a 9-KB image
     "h": (64, 40, 16, 2, "libgphocs_hip_h.so"),
 }
 
@@ -65,7 +66,7 @@ LIB_SOURCES = ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.c
 
 
 def variant_for(n, K, B):
-    for name in ("s", "l", "m", "x", "h"):
+    for name in ("s", "l", "m", "x", "g", "h"):
         cl, ck, cb, _, _ = VARIANTS[name]
         if n <= cl and K <= ck and B <= cb:
             return name

@@ -1006,6 +1006,72 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     k = RGHT(node);
     if (k >= n && ns_has(need, k)) si16(&GphLds::s_stack, sp++, k);
   }
+#if !defined(GPH_HOSTEMU) && GPH_BIG_TREE
+  if (P <= GPH_WAVE) {
+    /* the big-tree build on the device, at most one pattern per lane: the ORDER of the recomputation comes from the
+     * list above (there is no lane per node to schedule it by ballots), everything else is the vector form of the
+     * smaller builds -- every edge probability of the evaluation in one vector exp (lanes = child nodes, two rounds),
+     * lanes = patterns with the four base entries of a pattern in the lane's registers, the conditionals of the node
+     * just computed forwarded in registers when the next node is its parent, per-pattern logarithms on the lanes,
+     * the ordered pattern sum.  Same operations in the same order as prune_node / the loop below. */
+    const int lane = GPH_LANE, nint = n - 1;
+    gdbl *cb = cond_base();
+    const double mut = FS(FS_MUTRATE);
+    for (int c = lane; c < N; c += GPH_NLANES) {
+      const int fa = gph_lds.nd[c].father;
+      double pe = 0.0;
+      if (fa >= 0 && ns_has(need, fa)) pe = edge_prob_v(mut * (gph_lds.nd[fa].age - gph_lds.nd[c].age));
+      gph_lds.s_pe[c] = pe;
+    }
+    GPH_WAVE_FENCE();
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    int prev = -1;
+    const int lc = lane < P ? lane : P - 1;
+    for (i = nord - 1; i >= 0; i--) {
+      node = gi16(&GphLds::s_ord, i);
+      if (useOld) lik_mark_cond(node);
+      const int l = LEFT(node), r = RGHT(node);
+      const double pl = gph_lds.s_pe[l], pr = gph_lds.s_pe[r];
+      const gph_nset cb_ = NS_GET(IS_CBIT0);
+      const int po = (((int)ns_has(cb_, node) * nint + (node - n)) * P) * 4;
+      const int lo = l >= n ? (((int)ns_has(cb_, l) * nint + (l - n)) * P) * 4 : 0;
+      const int ro = r >= n ? (((int)ns_has(cb_, r) * nint + (r - n)) * P) * 4 : 0;
+      prune_node_q<gdbl *, gdbl2 *>(l, r, pl, pr, po, lo, ro, P, lc, cb, prev, q0, q1, q2, q3);
+      prev = node;
+    }
+    setCNT(CN_NODES, CNT(CN_NODES) + nord);
+    /* root reduction (LocusDataLikelihood.c:466-479): the root was computed last, its conditionals of pattern `lane`
+     * are q0..q3; further phases come from the next lanes' registers, in the reference's order */
+    double term = 0.0;
+    const int ph = lane < P ? gu16v(q_phases, lane) : 0;
+    double prob = q0;
+    prob += q1;
+    prob += q2;
+    prob += q3;
+    for (int k2 = 1; __ballot(ph > k2) != 0; k2++) {
+      const int src = ((lane + k2) & (GPH_WAVE - 1)) << 2;
+      const double r0 = bperm64(src, q0), r1 = bperm64(src, q1), r2 = bperm64(src, q2), r3 = bperm64(src, q3);
+      if (ph > k2) {
+        prob += r0;
+        prob += r1;
+        prob += r2;
+        prob += r3;
+      }
+    }
+    if (ph > 0) {
+      const int nc = 4 * ph;
+      double avg;
+      if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
+      else avg = prob / nc;
+      term = gph_log(avg) * gi32v(q_count, lane);
+    }
+    U = __builtin_popcountll(__ballot(ph > 0));
+    lnl = ordered_sum64(term, P);
+    setFS(FS_DATALNL, lnl);
+    if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (double)(96 * nord * P + 20 * N + 8 * U + 8));
+    return lnl;
+  }
+#endif
   for (i = nord - 1; i >= 0; i--) {
     node = gi16(&GphLds::s_ord, i);
     if (useOld) lik_mark_cond(node);
@@ -1319,6 +1385,35 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
     uint64_t m = __ballot(in);
     num = __builtin_popcountll(m);
     if (in) gph_lds.s_targets[__builtin_popcountll(m & (((uint64_t)1 << lane) - 1))] = (int16_t)lane;
+    GPH_SYNC();
+    return num;
+  }
+#elif !defined(GPH_HOSTEMU)
+  /* the big-tree build on the device: the same membership test with a lane per node, 64 nodes a round; the candidates
+   * of a round go behind those of the rounds before it (node order, as the reference lists them) */
+  {
+    const int lane = GPH_LANE;
+    for (int base = 0; base < g_lay.N; base += GPH_NLANES) {
+      const int nd_ = base + lane;
+      bool in = false;
+      if (nd_ < g_lay.N && nd_ != exc) {
+        f = gph_lds.nd[nd_].father;
+        in = !(gph_lds.nd[nd_].age > time) && !(f >= 0 && gph_lds.nd[f].age <= time);
+        if (in && pop != g_lay.rootPop) {
+          int last = -1, nm = ISC(IS_NUM_MIGS);
+          for (int i = 0; i < nm; i++) {
+            mig = LIVING(i);
+            if (MG(mig, MG_BRANCH) != nd_) continue;
+            if ((time < 0 || MAGE(mig) < time) && (last < 0 || MAGE(mig) > MAGE(last))) last = mig;
+          }
+          pop1 = (last >= 0) ? (int)gph_lds.mig_i[last * MG_COUNT + MG_SPOP] : (int)gph_lds.nd[nd_].npop;
+          in = ((g_model.isAnc[pop] >> pop1) & 1) != 0;
+        }
+      }
+      const uint64_t m = __ballot(in);
+      if (in) gph_lds.s_targets[num + __builtin_popcountll(m & (((uint64_t)1 << lane) - 1))] = (int16_t)nd_;
+      num += __builtin_popcountll(m);
+    }
     GPH_SYNC();
     return num;
   }

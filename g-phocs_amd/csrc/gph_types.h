@@ -208,6 +208,9 @@ struct alignas(16) GphLds {
   int16_t s_dpops[2][GPH_CAP_K], s_dbands[2][GPH_CAP_B], s_spri16[4 * GPH_MAX_MIGS];
   int16_t s_ord[GPH_CAP_N + 1], s_stack[GPH_CAP_N + 1], s_targets[GPH_CAP_N + 1], s_chknc[GPH_CAP_K], s_chknm[GPH_CAP_B];
   gph_evid s_dev[2][GPH_CAP_E];  // event lists of the two pending deltas
+#if GPH_BIG_TREE
+  double s_pe[GPH_CAP_N];        // edge transition probabilities of an evaluation, by child node (the smaller builds keep them in the lane of the node)
+#endif
 #ifdef GPH_PAD
   char s_pad[GPH_PAD];           // LDS-size sensitivity experiments only
 #endif

@@ -22,6 +22,10 @@ CONFIGS = {  # diploid samples per current pop, migration bands (src, tgt), anci
     # estimated ("e") sample ages: UpdateSampleAge is live and mixing stays on (tools/gen_synth.py configs 6, 7)
     6: dict(pops=[2, 2, 2, 1], bands=[(0, 1), (3, 2), (2, 3)], ancient=3, ancient_est=True),
     7: dict(pops=[2, 1, 2], bands=[(0, 1), (1, 0), (2, 1)], ancient=1, ancient_est=True),
+    # more than 16 diploid samples (an ordinary G-PhoCS data set): 20 diploids = 40 leaves over 5 populations -- library
+    # variant h (128-bit node sets); and many populations: 12 current (23 in all), 24 leaves
+    10: dict(pops=[4, 4, 4, 4, 4], bands=[(0, 1), (1, 0), (3, 2), (4, 3)]),
+    11: dict(pops=[1] * 12, bands=[(0, 1), (1, 0), (3, 2), (4, 3), (6, 5), (8, 7)]),
 }
 
 

@@ -81,7 +81,9 @@ def test_many_patterns_against_live_oracle(G, oracle_cli, tmp_path):
 @pytest.mark.parametrize("config,loci,iters,mut,mig_beta", [(4, 3000, 24, 6.5, 1e-5), (5, 1500, 20, 3.0, 1e-5),
                                                              (3, 2000, 30, 1.0, 1e-5), (6, 1500, 24, 2.0, 4e-8),
                                                              (7, 1500, 24, 2.0, 4e-8), (4, 1500, 16, 3.0, 4e-8),
-                                                             (4, 600, 400, 3.0, 4e-8)])   # long trajectory
+                                                             (4, 600, 400, 3.0, 4e-8),    # long trajectory
+                                                             (10, 500, 12, 3.0, 4e-8),    # 40 leaves: library variant h
+                                                             (11, 800, 16, 3.0, 4e-8)])   # 23 populations, 6 bands: variant x
 def test_scale_parity_against_live_oracle(G, oracle_cli, tmp_path, config, loci, iters, mut, mig_beta):
     """thousands of loci of the benchmark's synthetic shape (configs[3] and [4], the 3-population one, the two
     estimated-sample-age ones and a high-migration prior: mig-rate-beta 4e-8 puts thousands of migration events

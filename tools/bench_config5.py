@@ -8,7 +8,8 @@ sys.path.insert(0, REPO)
 import numpy as np
 import gphocs_amd as G, bench
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
-pack = bench.build_workload(G, 5, L, 6.5, 20261007, os.path.join(REPO, "bench_cache"))
+CFG = int(os.environ.get("GPH_BENCH_CONFIG", "5"))      # another synthetic shape (g-phocs_amd/synth.py: CONFIGS), e.g. 10 = 40 leaves
+pack = bench.build_workload(G, CFG, L, 6.5, 20261002 + CFG, os.path.join(REPO, "bench_cache"))
 lib = G.load_library(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "-" else G.load_library(dims=(pack.n, pack.K, pack.B))
 s = G.Sampler(pack, lib=lib)
 PRE = int(sys.argv[3]) if len(sys.argv) > 3 else 200
@@ -26,7 +27,8 @@ dt = time.perf_counter() - t0
 c = s.counters()
 sw, te = s.class_stats(0), s.class_stats(1)
 P = np.diff(pack.pattern_offsets)
-print(json.dumps({"workload": f"BASELINE configs[4]: {L} loci, 20 leaves, 13 populations, 4 bands, fixed ancient sample",
+print(json.dumps({"workload": f"BASELINE configs[4]: {L} loci, 20 leaves, 13 populations, 4 bands, fixed ancient sample" if CFG == 5 else
+                              f"synthetic config {CFG}: {L} loci, {pack.n} leaves, {pack.K} populations, {pack.B} bands",
                   "mean_phased_patterns": float(P.mean()), "max_phased_patterns": int(P.max()),
                   "evals_per_s": c["evals"] / dt, "iters_per_s": N / dt, "ms_per_iteration": dt / N * 1e3,
                   "sweep_ms": sw["ms"] / sw["launches"], "sweep_algorithmic_bytes": sw["bytes"] / sw["launches"],
