@@ -123,3 +123,31 @@ def test_engine_sources_under_asan_ubsan(hostemu, tmp_path, name, ranks):
     r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
     _same_trace(os.path.join(GOLDEN, name + ".trace"), os.path.join(tmp_path, name + ".trace"))
+
+
+def test_shm_exchange_ignores_a_leftover_segment(hostemu, tmp_path):
+    """a segment of the same name left behind by a crashed run (right size, right magic, stale arrival counters) must not
+    be mistaken for this run's: a rank only settles on a segment whose live rank 0 answers its hello; rank 1 starts
+    first here and finds the leftover, rank 0 comes later and replaces it"""
+    import time
+    import gphocs_amd as G
+    from parity_util import compare_records
+    lib = G.load_library(hostemu)
+    name = f"/gphocs-test-stale-{os.getpid()}"
+    stale = lib.gph_comm_create_shm(name.encode(), 0, 1)      # world 1: returns at once; never destroyed = "crashed"
+    assert stale and os.path.exists("/dev/shm" + name)
+    # poison the leftover's arrival counters the way a run that died mid-exchange would leave them
+    with open("/dev/shm" + name, "r+b") as f:
+        f.seek(64 + 4 * 128)          # past magic/failed + pad and the hello/ack words: the per-rank sequence slots
+        f.write(b"\x07" * 64 * 8)
+    out = str(tmp_path / "rec")
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % dict(repo=REPO, lib=hostemu, name=name, pack=os.path.join(GOLDEN, "m3.gpk"), out=out, iters=20))
+    p1 = subprocess.Popen([sys.executable, str(script), "1", "2"])
+    time.sleep(1.5)
+    p0 = subprocess.Popen([sys.executable, str(script), "0", "2"])
+    assert p0.wait(timeout=300) == 0 and p1.wait(timeout=300) == 0
+    assert open(out + ".0").read() == open(out + ".1").read()
+    golden = open(os.path.join(GOLDEN, "m3.rtrace")).read().splitlines()[:len(open(out + ".0").read().splitlines())]
+    (tmp_path / "g").write_text("\n".join(golden) + "\n")
+    compare_records(out + ".0", str(tmp_path / "g"))
