@@ -46,7 +46,7 @@ GphGlobal *gph_G_emu = nullptr;
 // knows it when it launches: the genealogy sweep at the head of an iteration, the locus-rate kernels), GphCtxG from the
 // device-resident chain state KA.G (everything launched after a decision the host has not seen yet)
 GPH_KERNEL(k_init, GphKargs KA, GphDev D, int j0, uint32_t seedz, const double *mutRate, int preDraws) { GphCtxG lx; lx.kb_init(D, j0 + GPH_BLK, seedz, mutRate ? mutRate[j0 + GPH_BLK] : 1.0, preDraws); }
-GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphKargs KA, GphDev D, int j0, int flags, double ftCoal, double ftMig) { GphCtx lx; lx.kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig); }
+GPH_SWEEP_ATTR GPH_KERNEL(k_sweep, GphKargs KA, GphDev D, int j0, int flags, double ftCoal, double ftMig, double mix_c, double mix_lnc) { GphCtx lx; lx.kb_sweep(D, j0 + GPH_BLK, flags, ftCoal, ftMig, mix_c, mix_lnc); }
 GPH_KERNEL(k_tau_eval, GphKargs KA, GphDev D, int j0, int fuse) { GphCtxG lx; lx.kb_tau_eval(D, j0 + GPH_BLK, GPH_G->tau, fuse); }
 GPH_KERNEL(k_tau_finish, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_tau_finish(D, j0 + GPH_BLK); }
 GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, int fuse) { GphCtxG lx; lx.kb_mix_eval(D, j0 + GPH_BLK, GPH_G->mix_c, fuse); }
@@ -343,6 +343,7 @@ struct gph_engine {
   GphKargs ka;                 // first argument of every kernel: model, layout, math constants, table addresses
   bool sync_pending = false;   // synchronizeEvents of the finished iteration rides at the head of the next sweep kernel
   bool fin_owed = false;       // the commit / revert of the last decided tau / sample-age proposal has not run yet
+  bool mix_owed = false;       // the commit of the last decided mixing proposal has not run yet (it rides at the head of the next sweep kernel)
   gph_counters counters = {0, 0, 0.0, 0};
   double last_ms[16] = {0};
   // per kernel class: launches, summed HIP-event ms; evaluations / bytes / nodes live in the chain state
@@ -743,8 +744,16 @@ static int run_stage_now(gph_engine *e, int stage, int arg);
 // now = the caller is a stepwise entry point that goes on to edit the host mirror of the chain state and push it: the
 // stage that checks the pass (Fatal Error 0075/0076, the class-8 counters) must then have run -- on the host, result
 // checked -- before that, or the push would overwrite what a queued device-side stage wrote
+// the commit of a decided mixing proposal that was left for the next sweep kernel: as a kernel of its own, now (something
+// other than the sweep is about to read or write the pages)
+static int mix_finish_owed(gph_engine *e)
+{
+  if (e->mix_owed) { e->mix_owed = false; LAUNCH(e, 7, k_mix_finish, 0); }
+  return 0;
+}
 static int flush_sync(gph_engine *e, bool now)
 {
+  { int rcm = mix_finish_owed(e); if (rcm) return rcm; }     /* a mixing commit left for the next sweep kernel goes first */
   if (!e->sync_pending) return 0;
   e->sync_pending = false;
   PUSH_IF_DIRTY(e);
@@ -1082,7 +1091,9 @@ int gph_engine_genealogy_sweep(gph_engine *e, int32_t flags, double ftCoal, doub
   GphGlobal &G = *e->G_h;
   const double d0 = G.dataLogLikelihood, l0 = G.logLikelihood;
   const int64_t a0 = G.acc[0], a1 = G.acc[1], a2 = G.acc[2], a7 = G.acc[7];
-  LAUNCH(e, 0, k_sweep, (int)flags | with_sync, ftCoal, ftMig);
+  int with_mix = 0;
+  if (e->mix_owed) { e->mix_owed = false; if (e->G_h->mix_flag) with_mix = 16; }
+  LAUNCH(e, 0, k_sweep, (int)flags | with_sync | with_mix, ftCoal, ftMig, e->G_h->mix_c, e->G_h->mix_lnc);
   int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
   if (!rc) rc = reduce_stats(e);
   if (rc) return rc;
@@ -1235,6 +1246,7 @@ int gph_engine_get_totals(gph_engine *e, double *cs, double *nc, double *ms, dou
   SETDEV(e);
   const int K = e->cfg.K, B = e->cfg.B;
   PUSH_IF_DIRTY(e);
+  { int rcm = mix_finish_owed(e); if (rcm) return rcm; }    /* the statistics of an accepted mixing proposal are scaled by its commit */
   int rc = reduce_stats(e);
   if (rc) return rc;
   if ((rc = run_stage_now(e, GS_TOTALS, 0))) return rc;
@@ -1605,7 +1617,11 @@ static int part_sweep(gph_engine *e, int32_t iteration, double ftCoal, double ft
   // previous iteration rides at its head
   const int with_sync = e->sync_pending ? 8 : 0;
   e->sync_pending = false;
-  LAUNCH(e, 0, k_sweep, 7 | with_sync, ftCoal, ftMig);
+  /* a mixing commit left over from the previous iteration: the host mirror of the chain state is current here (the
+   * previous iteration ended with a synchronisation), so the flag and the factor travel as kernel arguments */
+  int with_mix = 0;
+  if (e->mix_owed) { e->mix_owed = false; if (e->G_h->mix_flag) with_mix = 16; }
+  LAUNCH(e, 0, k_sweep, 7 | with_sync | with_mix, ftCoal, ftMig, e->G_h->mix_c, e->G_h->mix_lnc);
   if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
   if ((rc = reduce_stats(e))) return rc;
   return run_stage(e, GS_SWEEP_DONE, with_sync, iteration);
@@ -1668,7 +1684,8 @@ static int part_mix(gph_engine *e, int32_t iteration)
     { const int fuse = e->fin_owed; e->fin_owed = false; LAUNCH(e, 2, k_mix_eval, fuse); }
     if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
     if ((rc = run_stage(e, GS_MIX_DECIDE, 0, iteration))) return rc;
-    LAUNCH(e, 7, k_mix_finish, 0);
+    if (no_fuse) { LAUNCH(e, 7, k_mix_finish, 0); }
+    else e->mix_owed = true;        /* at the head of the next sweep kernel (part_sweep), or mix_finish_owed() */
   }
   return 0;
 }
@@ -1718,6 +1735,7 @@ int gph_engine_iteration_(gph_engine *e, int32_t iteration, const double *lr_alp
   if ((rc = part_sage(e, iteration))) return rc;
   if (Gh.doMixing && (rc = part_mix(e, iteration))) return rc;
   if ((rc = finish_owed(e))) return rc;    /* no evaluate kernel followed the last decision */
+  if ((iteration == Gh.startMig || (iteration + 1) % Gh.samplesPerLog == 0) && (rc = mix_finish_owed(e))) return rc;   /* the refresh / checkAll pass reads the pages */
   if (iteration == Gh.startMig) {
     // sampleMigRates, then the genLogLikelihood refresh of every locus (GPhoCS.c:1738-1757) inside synchronizeEvents' pass
     if ((rc = run_stage(e, GS_STARTMIG, 0, iteration))) return rc;
@@ -1739,6 +1757,7 @@ int gph_engine_part_(gph_engine *e, int32_t part, int32_t iteration, const doubl
   int rc = 0;
   GphGlobal &Gh = *e->G_h;
   PUSH_IF_DIRTY(e);
+  if (part != GPH_PART_SWEEP && part != GPH_PART_SYNC) { int rcm = mix_finish_owed(e); if (rcm) return rcm; }
   if (part == GPH_PART_LRATE || part == GPH_PART_TAU || part == GPH_PART_SAGE || part == GPH_PART_MIX) {
     int rcs = flush_sync(e, true);    /* a deferred synchronizeEvents pass must not be overtaken by a kernel that edits the pages */
     if (rcs) return rcs;
@@ -1758,6 +1777,7 @@ int gph_engine_part_(gph_engine *e, int32_t part, int32_t iteration, const doubl
   }
   if (rc) return rc;
   if ((rc = finish_owed(e))) return rc;
+  if (part != GPH_PART_MIX && (rc = mix_finish_owed(e))) return rc;    /* (after GPH_PART_MIX the commit may wait for GPH_PART_SWEEP) */
   return finish_sync(e);
 }
 

@@ -375,10 +375,18 @@ template <class RNG> GPH_DEV void sweep_spr(const GphDev &D, int g, RNG &rng)
 // fused genealogy sweep: UpdateGB_InternalNode, UpdateGB_MigrationNode, UpdateGB_MigSPR
 // run back to back on the LDS-resident locus (GPhoCS.c:1495-1538 calls them in this
 // order with nothing in between) -- one load and one store of the locus instead of three
-GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double ftMig)
+// flag 16: the mixing proposal of the previous iteration was ACCEPTED and its commit (GPhoCS.c:4815-4848) has not run: the
+// evaluated state is taken from the shadow page and committed here, in LDS -- the page the sweep writes at its end is
+// the only one written, and the commit costs no launch and no page round trip of its own
+GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double ftMig, double mix_c, double mix_lnc)
 {
   STAMP_BEGIN(0);
-  stage_in(D, g, D.pages, 1);
+  if (flags & 16) {
+    stage_in(D, g, D.shadow, 1);
+    mix_commit_body(mix_c, mix_lnc);
+  } else {
+    stage_in(D, g, D.pages, 1);
+  }
   GphRngB rng;       /* uniforms in batches of 64: gph_locus.h */
   rng_load(rng);
   /* flag 8: synchronizeEvents of the previous iteration (patch.c:3548), deferred into this kernel */
@@ -642,12 +650,11 @@ GPH_DEV void kb_mix_eval(const GphDev &D, int g, double c, int fuse)
   out_common(D, g);
   stage_out(D, g, D.shadow, 2);
 }
-// commit loop of mixing(), GPhoCS.c:4815-4848 + adjustRootEvents (patch.c:1808)
-GPH_DEV void kb_mix_commit(const GphDev &D, int g, double c, double lnc)
+// commit loop of mixing(), GPhoCS.c:4815-4848 + adjustRootEvents (patch.c:1808), on the evaluated state in the LDS image
+GPH_DEV void mix_commit_body(double c, double lnc)
 {
   int i, pop, b, ev;
   double age;
-  stage_in(D, g, D.shadow, 0);
   lik_reset_saved();
   for (i = 0; i < ISC(IS_NUM_MIGS); i++) setMAGE(LIVING(i), MAGE(LIVING(i)) * c);
   setFS(FS_GENLNL, FS(FS_GENLNL) - lnc * (g_lay.n - 1 + ISC(IS_NUM_MIGS)));
@@ -665,6 +672,11 @@ GPH_DEV void kb_mix_commit(const GphDev &D, int g, double c, double lnc)
     while (ENEXT(ev) >= 0) { age += EVT(ev); ev = ENEXT(ev); if (++guard > g_lay.E) { gph_fail(97); break; } }
     setEVT(ev, GPH_OLDAGE - age);
   }
+}
+GPH_DEV void kb_mix_commit(const GphDev &D, int g, double c, double lnc)
+{
+  stage_in(D, g, D.shadow, 0);
+  mix_commit_body(c, lnc);
   out_common(D, g);
   stage_out(D, g, D.pages, 0);
 }
