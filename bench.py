@@ -522,6 +522,9 @@ def main():
                 elif tj.get("loci") == L_local:
                     traffic_src = (f"none: profiles/traffic_k_sweep.json was measured with build {tj.get('build_id')}, "
                                    f"the loaded library is {build_id}")
+                else:
+                    traffic_src = (f"none: profiles/traffic_k_sweep.json was measured with {tj.get('loci')} loci per launch, "
+                                   f"this rank holds {L_local}")
             except Exception:
                 pass
         nsync = (hs1["syncs"] - hs0["syncs"]) / a.steps
