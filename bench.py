@@ -250,7 +250,12 @@ def launch_ranks(a):
             print(f"bench: --gpus {n} but this node shows {nd} HIP device(s)", file=sys.stderr)
             return 2
     import gphocs_amd as G
-    G.build()                                   # once, before the ranks race for the build lock
+    if a.host_emulation:
+        sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
+        import run_hostemu
+        run_hostemu.build_hostemu()             # once, before the ranks ask for it
+    else:
+        G.build()                               # once, before the ranks race for the build lock
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = []

@@ -20,16 +20,39 @@ def build_hostemu(sanitize=False, big=False):
     srcs = [os.path.join(csrc, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp", "gph_readtrace.cpp", "gph_comm.cpp")]
     deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.abspath(__file__)]
     out = HOSTEMU.replace(".so", "_san.so") if sanitize else HOSTEMU.replace(".so", "_h.so") if big else HOSTEMU
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+
+    def fresh():
+        return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)
+    if fresh():
         return out
+    # several processes may ask at once (the ranks of `bench.py --gpus N --host-emulation`): one builds, into a
+    # temporary file that is renamed when complete; the others wait for the lock and find the library up to date
+    import fcntl
+    with open(out + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if fresh():
+                return out
+            return _build(out, srcs, sanitize, big)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build(out, srcs, sanitize, big):
     # the engine's hard caps (library variant `x`): every golden fits, the image size does not matter on the host
     caps = ["-DGPH_CAP_LEAVES=64", "-DGPH_CAP_K=40", "-DGPH_CAP_B=16"] if big else ["-DGPH_CAP_LEAVES=32", "-DGPH_CAP_K=32", "-DGPH_CAP_B=16"]
+    tmp = f"{out}.tmp.{os.getpid()}"
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU"] + caps + [
            "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
-           "-x", "c++"] + srcs + ["-lrt", "-o", out]
+           "-x", "c++"] + srcs + ["-lrt", "-o", tmp]
     if sanitize:
         cmd[1:1] = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
-    subprocess.run(cmd, check=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
     return out
 
 
