@@ -67,3 +67,18 @@ def test_bench_refuses_more_gpus_than_devices():
     r = subprocess.run([sys.executable, BENCH, "--gpus", str(max(n, 2)), "--loci", "400", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 2 and "HIP device" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_as_ranks_of_torch_distributed_run(one_rank):
+    """the driver's other launch form: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` -- the
+    script finds RANK / WORLD_SIZE in its environment and is ONE rank (it must not start ranks of its own)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29677", BENCH, "--gpus", "2"] + ARGS
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["loci_this_rank"] == 200
+    assert line["config"]["accept_counts_timed"] == one_rank["config"]["accept_counts_timed"]
