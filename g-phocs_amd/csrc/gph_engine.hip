@@ -144,6 +144,24 @@ __global__ void __launch_bounds__(GPH_RED_THREADS) k_global(GphKargs KA, const d
 // order and combined in sub-sequence order; the final pass adds the 256 block partials in a fixed shape.
 // mode 0 = per-locus outputs (GPH_OUT_SLOTS columns), mode 1 = compact statistics (2K+2B columns)
 // part: [3][GPH_RED_BLOCKS][GPH_RED_COLS] (sum, min, max) per section
+// one sub-sequence of a column (g, g + step, ... below g1) folded in index order.  The loads of GPH_RED_UNROLL steps are
+// issued together and folded as they arrive: one load in flight per thread made these loops a chain of memory
+// latencies (a dozen to fifty of them per reduction, six reductions per iteration)
+#define GPH_RED_UNROLL 16
+__device__ __forceinline__ void reduce_run(const double *src, int stride, int col, int g, int g1, int step, double &s, double &mn, double &mx)
+{
+  for (; g < g1; g += step * GPH_RED_UNROLL) {
+    double v[GPH_RED_UNROLL];
+#pragma unroll
+    for (int u = 0; u < GPH_RED_UNROLL; u++) {
+      const int gg = g + u * step;
+      v[u] = gg < g1 ? src[(size_t)gg * stride + col] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < GPH_RED_UNROLL; u++)
+      if (g + u * step < g1) { s += v[u]; mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+  }
+}
 __device__ void reduce_partial_body(const GphDev &D, int mode, int ncols, double *part, double (*sh)[GPH_RED_SUBS * 4][16])
 {
   /* a wavefront covers 64 / cw loci at a time (cw = columns rounded up to 16, 32 or 64): every lane has work */
@@ -159,11 +177,7 @@ __device__ void reduce_partial_body(const GphDev &D, int mode, int ncols, double
     for (int half = 0; half < 2; half++) {
       const int col = lane + 64 * half;
       double s = 0.0, mn = 1e300, mx = -1e300;
-      if (col < ncols)
-        for (int g = g0 + q; g < g1; g += GPH_RED_SUBS) {
-          double v = src[(size_t)g * stride + col];
-          s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
-        }
+      if (col < ncols) reduce_run(src, stride, col, g0 + q, g1, GPH_RED_SUBS, s, mn, mx);
       for (int c0 = 64 * half; c0 < ncols && c0 < 64 * (half + 1); c0 += 16) {
         __syncthreads();
         if (col >= c0 && col < c0 + 16) { sh[0][q][col - c0] = s; sh[1][q][col - c0] = mn; sh[2][q][col - c0] = mx; }
@@ -188,13 +202,7 @@ __device__ void reduce_partial_body(const GphDev &D, int mode, int ncols, double
   const int ng = 64 / cw, Q = GPH_RED_SUBS * ng;
   const int lane = threadIdx.x & 63, col = lane % cw, q = (threadIdx.x >> 6) * ng + lane / cw;
   double s = 0.0, mn = 1e300, mx = -1e300;
-  if (col < ncols)
-    for (int g = g0 + q; g < g1; g += Q) {
-      double v = src[(size_t)g * stride + col];
-      s += v;
-      mn = v < mn ? v : mn;
-      mx = v > mx ? v : mx;
-    }
+  if (col < ncols) reduce_run(src, stride, col, g0 + q, g1, Q, s, mn, mx);
   /* combine the Q sub-sequences of a column in sub-sequence order; 16 columns at a time through shared memory */
   for (int c0 = 0; c0 < ncols; c0 += 16) {
     __syncthreads();
@@ -216,22 +224,30 @@ __device__ void reduce_partial_body(const GphDev &D, int mode, int ncols, double
   __syncthreads();
 }
 // final pass: column c's block partials in block order, as GPH_RED_SUBS contiguous runs combined in run order -- a
-// fixed shape, so the result does not depend on scheduling.  512 threads: thread (h, c) sums runs h and h + 4.
+// fixed shape, so the result does not depend on scheduling.  Up to 64 columns (every variant but the largest): thread
+// (run, column), one run each; beyond: thread (h, column) folds runs h and h + 4.  A run's 3 x 32 partials are fetched
+// 48 loads at a time: these are reads of other XCDs' writes, a microsecond or two each
 __device__ void reduce_final_body(int ncols, const double *part, double *red, double (*sh)[GPH_RED_SUBS][GPH_RED_COLS])
 {
-  const int col = threadIdx.x % GPH_RED_COLS, h = threadIdx.x / GPH_RED_COLS;
+  const int cw = ncols <= 64 ? 64 : GPH_RED_COLS;
+  const int col = threadIdx.x % cw, h = threadIdx.x / cw;
   const int per = GPH_RED_BLOCKS / GPH_RED_SUBS;
-  for (int sub = h; sub < GPH_RED_SUBS; sub += GPH_RED_THREADS / GPH_RED_COLS) {
+  static_assert((GPH_RED_BLOCKS / GPH_RED_SUBS) % 16 == 0, "the final pass folds sixteen block partials per step");
+  for (int sub = h; sub < GPH_RED_SUBS; sub += GPH_RED_THREADS / cw) {
     double s = 0.0, mn = 1e300, mx = -1e300;
     if (col < ncols)
-      for (int b = sub * per; b < (sub + 1) * per; b++) {
-        s += part[(0 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
-        double v = part[(1 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
-        mn = v < mn ? v : mn;
-        v = part[(2 * GPH_RED_BLOCKS + b) * GPH_RED_COLS + col];
-        mx = v > mx ? v : mx;
+      for (int b0 = sub * per; b0 < (sub + 1) * per; b0 += 16) {
+        double vs[16], vn[16], vx[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          vs[u] = part[(0 * GPH_RED_BLOCKS + b0 + u) * GPH_RED_COLS + col];
+          vn[u] = part[(1 * GPH_RED_BLOCKS + b0 + u) * GPH_RED_COLS + col];
+          vx[u] = part[(2 * GPH_RED_BLOCKS + b0 + u) * GPH_RED_COLS + col];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) { s += vs[u]; mn = vn[u] < mn ? vn[u] : mn; mx = vx[u] > mx ? vx[u] : mx; }
       }
-    sh[0][sub][col] = s; sh[1][sub][col] = mn; sh[2][sub][col] = mx;
+    if (col < GPH_RED_COLS) { sh[0][sub][col] = s; sh[1][sub][col] = mn; sh[2][sub][col] = mx; }
   }
   __syncthreads();
   if (h == 0 && col < ncols) {
