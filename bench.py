@@ -516,10 +516,12 @@ def main():
                     if tj.get("valu_per_wave") and sweep_ms > 0:
                         # issue roofline: a CU issues at most one VALU and one SALU wave-instruction per cycle (4 SIMDs x
                         # 16 lanes: a wave64 instruction holds its SIMD for 4 cycles); cycles a CU has per locus at the
-                        # nominal 2.4 GHz (the clock under load is lower: the fractions are lower bounds)
+                        # nominal 2.4 GHz -- which is what the kernel runs at (2.34-2.41 GHz: shader-clock over real-time
+                        # counter read inside k_sweep by a probe build)
                         cyc = sweep_ms * 1e-3 * 2.4e9 / (L_local / 256.0)
                         issue = {"valu_per_wave": tj["valu_per_wave"], "salu_per_wave": tj["salu_per_wave"],
                                  "lds_per_wave": tj.get("lds_per_wave"), "clock_ghz_assumed": 2.4,
+                                 "clock_ghz_measured_in_kernel": "2.34-2.41 (round-3 probe build, not this run)",
                                  "cycles_per_locus_per_cu": cyc, "valu_issue_frac": tj["valu_per_wave"] / cyc,
                                  "salu_issue_frac": tj["salu_per_wave"] / cyc,
                                  "floor_ms": max(tj["valu_per_wave"], tj["salu_per_wave"]) * (L_local / 256.0) / 2.4e9 * 1e3,

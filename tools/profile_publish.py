@@ -36,6 +36,15 @@ shutil.copy(f"gpurun_out/kstats_{tag}/k_kernel_stats.csv", f"profiles/{rnd}_benc
 b["roofline"]["traffic"] = fetch + write
 b["roofline"]["traffic_source"] = f"profiles/traffic_k_sweep.json ({rnd} {tag}: rocprofv3 --pmc passes of the same command on the same box)"
 b["roofline"]["hbm_counter_frac"] = (fetch + write) / (b["roofline"]["avg_launch_ms"] * 1e-3) / 8e12
+if not b["roofline"].get("issue"):
+    # the bench ran before this file existed for its build: the same arithmetic as bench.py
+    valu, salu = s["SQ_INSTS_VALU"]["sum"] / n, s["SQ_INSTS_SALU"]["sum"] / n
+    cyc = b["roofline"]["avg_launch_ms"] * 1e-3 * 2.4e9 / (100000 / 256.0)
+    b["roofline"]["issue"] = {"valu_per_wave": valu, "salu_per_wave": salu, "lds_per_wave": s["SQ_INSTS_LDS"]["sum"] / n,
+                              "clock_ghz_assumed": 2.4, "clock_ghz_measured_in_kernel": "2.34-2.41 (round-3 probe build, not this run)",
+                              "cycles_per_locus_per_cu": cyc, "valu_issue_frac": valu / cyc, "salu_issue_frac": salu / cyc,
+                              "floor_ms": max(valu, salu) * (100000 / 256.0) / 2.4e9 * 1e3,
+                              "source": b["roofline"]["traffic_source"]}
 json.dump(b, open(f"profiles/{rnd}_bench_{tag}.json", "w"), indent=1)
 try:
     shutil.copy(f"gpurun_out/bench_{tag}_12500.json", f"profiles/{rnd}_bench_{tag}_12500loci.json")
