@@ -130,18 +130,30 @@ def _build_locked(verbose):
         return h.hexdigest()[:12]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
         [os.path.join(REPO, "include", "gphocs_hip.h")]
+    hdr = hashlib.sha256(open(deps[-1], "rb").read()).hexdigest()[:8]
+
+    def library(out, tag, fl):
+        """up to date = built from exactly these sources with these flags by this compiler: the id the library was built
+        with sits in a sidecar file next to it (time stamps do not survive checkouts and snapshot copies reliably, and a
+        rebuild on the GPU box costs minutes of the measurement budget)"""
+        want = f"{tag}-{build_id(fl)}"
+        side = out + ".buildid"
+        try:
+            if os.path.exists(out) and open(side).read().strip() == f"{want}:{hdr}":
+                return
+        except OSError:
+            pass
+        _run_to(["hipcc"] + fl + [f'-DGPH_BUILD_ID="{want}"'] + srcs + HIPCC_LIBS, out, verbose)
+        with open(side, "w") as f:
+            f.write(f"{want}:{hdr}\n")
+
     for name, (cl, ck, cb, waves, fn) in VARIANTS.items():
-        out = os.path.join(_HERE, fn)
-        if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
-            continue
-        fl = HIPCC_FLAGS + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"]
-        _run_to(["hipcc"] + fl + [f'-DGPH_BUILD_ID="{name}-{build_id(fl)}"'] + srcs + HIPCC_LIBS, out, verbose)
+        library(os.path.join(_HERE, fn), name,
+                HIPCC_FLAGS + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"])
     # control build without the backend switches (parity tests only)
-    out = os.path.join(_HERE, PLAIN_LIB)
-    if not (os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)):
-        cl, ck, cb, waves, _ = VARIANTS["m"]
-        fl = HIPCC_BASE + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"]
-        _run_to(["hipcc"] + fl + [f'-DGPH_BUILD_ID="plain-{build_id(fl)}"'] + srcs + HIPCC_LIBS, out, verbose)
+    cl, ck, cb, waves, _ = VARIANTS["m"]
+    library(os.path.join(_HERE, PLAIN_LIB), "plain",
+            HIPCC_BASE + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"])
     # the program: same command line as the reference's G-PhoCS binary (GPhoCS.c:84-238)
     exe, main = os.path.join(_HERE, "G-PhoCS-hip"), os.path.join(CSRC, "gph_main.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(main), os.path.getmtime(deps[-1])):

@@ -21,8 +21,19 @@ def build_hostemu(sanitize=False, big=False):
     deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.abspath(__file__)]
     out = HOSTEMU.replace(".so", "_san.so") if sanitize else HOSTEMU.replace(".so", "_h.so") if big else HOSTEMU
 
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(deps):
+        h.update(os.path.basename(d).encode() + b"\0" + open(d, "rb").read())
+    want = h.hexdigest()[:16]
+    side = out + ".buildid"
+
     def fresh():
-        return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)
+        # by content, not by time stamp (checkouts and snapshot copies shuffle those): the id sits next to the library
+        try:
+            return os.path.exists(out) and open(side).read().strip() == want
+        except OSError:
+            return False
     if fresh():
         return out
     # several processes may ask at once (the ranks of `bench.py --gpus N --host-emulation`): one builds, into a
@@ -33,7 +44,10 @@ def build_hostemu(sanitize=False, big=False):
         try:
             if fresh():
                 return out
-            return _build(out, srcs, sanitize, big)
+            r = _build(out, srcs, sanitize, big)
+            with open(side, "w") as f:
+                f.write(want + "\n")
+            return r
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
