@@ -51,14 +51,14 @@ PLAIN_LIB = "libgphocs_hip_plain.so"    # capacities of variant `m`, no -mllvm s
 # sized by compile-time capacities (csrc/gph_types.h), and a tighter image means more resident
 # wavefronts per CU.  `load_library(dims=...)` picks the smallest variant that fits the model.
 VARIANTS = {  # name: (max leaves, max pops, max bands, waves per SIMD of the sweep kernel, file)
-    "s": (16, 9, 4, 6, "libgphocs_hip_s.so"),     # BASELINE configs[0..3]
-    "l": (20, 13, 4, 5, "libgphocs_hip_l.so"),    # BASELINE configs[4] (20 leaves, 13 populations)
-    "m": (24, 16, 8, 5, "libgphocs_hip.so"),
-    "x": (32, 32, 16, 4, "libgphocs_hip_x.so"),   # the largest variant with one genealogy node per lane (2n-1 <= 63) and 32-bit population sets
+    "s": (16, 9, 4, 8, "libgphocs_hip_s.so"),     # BASELINE configs[0..3]; its image + a 64-pattern block fit 4 LDS granules: 32 loci per CU, 8 wavefronts per SIMD (64 VGPRs, spills outside the inner loops: measured faster than 7 and 6)
+    "l": (20, 13, 4, 6, "libgphocs_hip_l.so"),    # BASELINE configs[4] (20 leaves, 13 populations)
+    "m": (24, 16, 8, 6, "libgphocs_hip.so"),
+    "x": (32, 32, 16, 6, "libgphocs_hip_x.so"),   # the largest variant with one genealogy node per lane (2n-1 <= 63) and 32-bit population sets
     # the engine's hard caps: 64 leaves, the reference's own 39 populations (NSPECIES 20), 16 bands -- 128-bit node sets,
     # 64-bit population sets, 16-bit event ids, list-driven pruning order instead of the lane-per-node wave programs
-    "g": (48, 16, 8, 3, "libgphocs_hip_g.so"),    # many samples, few populations (e.g. 20 diploids over 5 populations): the big-tree forms with a 9-KB image
-    "h": (64, 40, 16, 2, "libgphocs_hip_h.so"),
+    "g": (48, 16, 8, 6, "libgphocs_hip_g.so"),    # many samples, few populations (e.g. 20 diploids over 5 populations): the big-tree forms with a 9-KB image
+    "h": (64, 40, 16, 6, "libgphocs_hip_h.so"),
 }
 
 

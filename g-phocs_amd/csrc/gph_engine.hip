@@ -33,9 +33,10 @@ GphGlobal *gph_G_emu = nullptr;
 #else
 #define GPH_KERNEL(name, ...) __global__ __launch_bounds__(GPH_WAVE) void name(__VA_ARGS__)
 #define GPH_BLK ((int)blockIdx.x)
-// 5 waves per SIMD (<= 96 VGPRs): the sweep is a latency-bound dependent chain per wave, LDS allows 20 waves/CU
+// wavefronts per SIMD the sweep kernel is compiled for (the build passes it per capacity variant): 6 = 80 VGPRs, which
+// every variant reaches without a spill -- beyond that LDS decides how many loci are resident; variant s is built for 8
 #ifndef GPH_SWEEP_WAVES
-#define GPH_SWEEP_WAVES 5
+#define GPH_SWEEP_WAVES 6
 #endif
 #define GPH_SWEEP_ATTR __attribute__((amdgpu_waves_per_eu(GPH_SWEEP_WAVES, GPH_SWEEP_WAVES)))
 #define GPH_SWEEP_WAVES_ GPH_SWEEP_WAVES
@@ -336,6 +337,7 @@ struct gph_engine {
   std::vector<uint64_t> h_seq_off;
   GphLrArgs lr;
   int lr_lds_bytes = 0;
+  int lds_pad[16] = {0};             // GPH_LDS_PAD="class:bytes,...": extra dynamic LDS per kernel class (occupancy experiments)
   // reductions: block partials, this rank's reduced row (GPH_RED_ROW doubles) and every rank's row after the all-gather
   double *d_part = nullptr, *d_red = nullptr, *d_gather = nullptr;
 #ifndef GPH_HOSTEMU
@@ -381,7 +383,7 @@ static int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
 // page + LDS layout for (n, K, B): everything sized by the ACTUAL dimensions, not by the
 // reference's MAX_* caps (sizeof(Locus_SuperStruct) alone is 9.7 KB there)
-static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop, int Pmax)
+static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop, int Pmax, int cnt16)
 {
   memset(&y, 0, sizeof y);
   y.n = n; y.N = 2 * n - 1; y.K = K; y.Kc = Kc; y.B = B; y.rootPop = rootPop;
@@ -401,7 +403,9 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   // dynamic LDS: the locus' sequence block (same bytes as its HBM block, laid out by its own P: GPH_Q_* in
   // gph_types.h) + per-pattern terms of the root reduction for loci with more than one pattern per lane
   y.Pmax = Pmax;
-  y.lds_bytes = GPH_Q_TERMS(Pmax, n) + (Pmax > GPH_WAVE ? 8 * Pmax : 8 * GPH_WAVE);
+  y.cnt16 = cnt16;
+  y.dyn_bytes = 0;
+  y.lds_bytes = GPH_Q_TERMS(Pmax, n, cnt16) + (Pmax > GPH_WAVE ? 8 * Pmax : 8 * GPH_WAVE);
 }
 
 static void build_model_static(gph_engine *e)
@@ -506,7 +510,8 @@ static void tm_end(gph_engine *e, int slot) { if (slot >= 0) (void)hipEventRecor
 #define LAUNCH(e, which, name, ...) do { { int rcf_ = flush_pending(e); if (rcf_) return rcf_; } LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
     const int tms_ = tm_begin((e), (which)); \
     for (auto &bk_ : (e)->buckets) { \
-      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes, (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
+      ka_.lay.dyn_bytes = bk_.lds_bytes; \
+      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes + (e)->lds_pad[which], (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
       HIPCHK(hipGetLastError()); (e)->n_launches++; } \
     tm_end((e), tms_); \
     (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
@@ -937,7 +942,12 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   const int n = e->cfg.n;
   int Pmax = 1;
   for (int64_t g = 0; g < L; g++) { int P = (int)(poff[g + 1] - poff[g]); if (P > Pmax) Pmax = P; if (P < 0) return GPH_EARG; }   /* P == 0: a locus with no informative column (all N) is legal upstream */
-  build_layout(e->lay, n, e->cfg.Kc, e->cfg.K, e->cfg.B, e->cfg.rootPop, Pmax);
+  /* pattern counts as 16-bit words when every count of the data set allows it (a count is at most the length of its
+   * locus): 2 bytes per pattern of every resident sequence block */
+  int cnt16 = 1;
+  for (int64_t i = 0; i < poff[L]; i++) if (counts[i] < 0 || counts[i] > 65535) { cnt16 = 0; break; }
+  if (const char *ov = getenv("GPH_CNT16")) cnt16 = cnt16 && atoi(ov) != 0;     /* tests: the 32-bit form */
+  build_layout(e->lay, n, e->cfg.Kc, e->cfg.K, e->cfg.B, e->cfg.rootPop, Pmax, cnt16);
   if (e->lay.lds_bytes + (int)sizeof(GphLds) > 160 * 1024) {
     fprintf(stderr, "gphocs_hip: a locus with %d phased patterns needs %d bytes of LDS (> 160 KiB)\n", Pmax, e->lay.lds_bytes);
     return GPH_EARG;
@@ -956,24 +966,37 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
     if (nwide > 0) {
       gph_engine::Bucket bk;
       bk.j0 = 0; bk.count = (int)nwide;
-      bk.lds_bytes = GPH_Q_TERMS(Pmax, n) + 8 * Pmax;
+      bk.lds_bytes = GPH_Q_TERMS(Pmax, n, cnt16) + 8 * Pmax;
       e->buckets.push_back(bk);
     }
     if (nwide < L) {
       const int pn = (int)(poff[e->h_orig[nwide] + 1] - poff[e->h_orig[nwide]]);
       gph_engine::Bucket bk;
       bk.j0 = (int)nwide; bk.count = (int)(L - nwide);
-      bk.lds_bytes = GPH_Q_BYTES(pn, n);
+      bk.lds_bytes = GPH_Q_BYTES(pn, n, cnt16);
       /* the per-lane terms of the root reduction through LDS (ordered_sum64_lds: one vector instruction per pattern
-       * instead of three) take 512 more bytes per workgroup: only when that does not cost a resident workgroup.  LDS is
-       * handed out in 1280-byte granules (160 KB / 128, measured: DESIGN.md section 8.2); the sweep kernel keeps at
-       * most GPH_SWEEP_WAVES workgroups per SIMD */
+       * instead of three) take 8 bytes per pattern behind a locus's block: never at the price of a resident workgroup.
+       * LDS is handed out in 1280-byte granules (160 KB / 128, measured: DESIGN.md section 8.2) and the sweep kernel keeps
+       * at most GPH_SWEEP_WAVES workgroups per SIMD: the group gets the room of the granules its largest block needs
+       * anyway, or -- when even the largest locus's terms do not cost a workgroup -- room for everybody's; a locus takes
+       * the LDS form when its terms end inside the allocation (gph_locus.h: lik_compute) */
       {
         auto resident = [](int bytes) { const int g = (bytes + 1279) / 1280; const int w = 128 / g; return w < 4 * GPH_SWEEP_WAVES_ ? w : 4 * GPH_SWEEP_WAVES_; };
         const int base = (int)sizeof(GphLds) + bk.lds_bytes;
-        e->lay.lds_sum = resident(base + 8 * GPH_WAVE) == resident(base) ? 1 : 0;
-        if (const char *ov = getenv("GPH_LDS_SUM")) e->lay.lds_sum = atoi(ov) != 0;   /* tests: force either form */
-        if (e->lay.lds_sum) bk.lds_bytes += 8 * GPH_WAVE;
+        const int full = 8 * ((pn + 7) & ~7);
+        e->lay.lds_sum = 1;
+        if (resident(base + full) == resident(base)) bk.lds_bytes += full;
+        else {
+          /* the largest size with as many resident workgroups as the bare block: granules first, then the step of the
+           * wavefront cap (4 * GPH_SWEEP_WAVES workgroups per CU do not need whole granules to themselves) */
+          int room = (base + 1279) / 1280 * 1280;
+          while (resident(room + 1280) == resident(base)) room += 1280;
+          bk.lds_bytes = (room - (int)sizeof(GphLds)) & ~15;
+        }
+        if (const char *ov = getenv("GPH_LDS_SUM")) {     /* tests: force either form for every locus */
+          e->lay.lds_sum = atoi(ov) != 0;
+          bk.lds_bytes = GPH_Q_BYTES(pn, n, cnt16) + (e->lay.lds_sum ? full : 0);
+        }
       }
       e->buckets.push_back(bk);
     }
@@ -990,7 +1013,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
     e->h_cond_off[j] = off;
     off += (uint64_t)2 * (n - 1) * P * 32;
     seq_off[j] = soff;
-    soff += GPH_Q_BYTES(P, n);
+    soff += GPH_Q_BYTES(P, n, cnt16);
     if (mutRates) rates[j] = mutRates[g];
   }
   e->h_cond_off[L] = off;
@@ -1005,10 +1028,11 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
       for (int i = 0; i < n; i++) {
         uint8_t c = leafcodes[(size_t)(poff[g] + p) * n + i];
         if (c > 4) return GPH_EARG;
-        blk[GPH_Q_LEAF + p * n + i] = (char)c;
+        blk[GPH_Q_LEAF + p * GPH_Q_NH(n) + (i >> 1)] |= (char)(c << ((i & 1) << 2));
       }
       ((uint16_t *)(blk + GPH_Q_PHASES(P, n)))[p] = numPhases[poff[g] + p];
-      ((int32_t *)(blk + GPH_Q_COUNT(P, n)))[p] = counts[poff[g] + p];
+      if (cnt16) ((uint16_t *)(blk + GPH_Q_COUNT(P, n)))[p] = (uint16_t)counts[poff[g] + p];
+      else ((int32_t *)(blk + GPH_Q_COUNT(P, n)))[p] = counts[poff[g] + p];
     }
   }
   e->cond_bytes = off;
@@ -1051,7 +1075,17 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
                       (const void *)k_mix_eval, (const void *)k_mix_finish,
                       (const void *)k_sync, (const void *)k_check, (const void *)k_lrate_apply, (const void *)k_lrate_prep,
                       (const void *)k_unit};
-  for (auto k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, e->lay.lds_bytes));
+  int pad_max = 0;
+  if (const char *pe = getenv("GPH_LDS_PAD")) {
+    for (const char *q = pe; *q;) {
+      int w = -1, by = 0;
+      if (sscanf(q, "%d:%d", &w, &by) == 2 && w >= 0 && w < 16 && by >= 0) { e->lds_pad[w] = by; pad_max = by > pad_max ? by : pad_max; }
+      while (*q && *q != ',') q++;
+      if (*q == ',') q++;
+    }
+  }
+  if (e->lay.lds_bytes + pad_max + (int)sizeof(GphLds) > 160 * 1024) { fprintf(stderr, "gphocs_hip: GPH_LDS_PAD is beyond the LDS\n"); return GPH_EARG; }
+  for (auto k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, e->lay.lds_bytes + pad_max));
 #endif
   return 0;
 }
@@ -1509,7 +1543,7 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     std::vector<int32_t> slot_of(e->L);
     for (int64_t j = 0; j < e->L; j++) slot_of[e->h_orig[j]] = (int32_t)j;
     // dynamic LDS of the scan: guest sequence block | reference sequence block | guest nodes | reference nodes | scratch
-    const int seqb = align_up(GPH_Q_TERMS(Pmax, n) + (Pmax > GPH_WAVE ? 8 * Pmax : 0), 16), ndb = N * (int)sizeof(GphNode);
+    const int seqb = align_up(GPH_Q_TERMS(Pmax, n, y.cnt16) + (Pmax > GPH_WAVE ? 8 * Pmax : 0), 16), ndb = N * (int)sizeof(GphNode);
     const int fixed = 2 * seqb + 2 * ndb;
     /* the compiled program of the reference locus is a lane-per-node construction: not in the big-tree variant */
     const int progb = GPH_BIG_TREE ? 0 : (n - 1) * GPH_WAVE * 16;
@@ -1529,7 +1563,7 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     e->lr.o_pe = e->lr.o_prog + progb;
     e->lr.o_lf = lfb ? e->lr.o_pe + align_up(N * 8, 16) : 0;
     e->lr_lds_bytes = e->lr.o_pe + align_up(N * 8, 16) + lfb;
-    e->lr.ref_seq_bytes = GPH_Q_BYTES(Pr, n);
+    e->lr.ref_seq_bytes = GPH_Q_BYTES(Pr, n, y.cnt16);
     rc |= dev_alloc((void **)&e->d_lrec, sizeof(GphLrRec) * e->L);
     rc |= dev_alloc((void **)&e->d_lpre, sizeof(GphLrPre) * e->L);
     rc |= dev_alloc((void **)&e->d_slot_of, sizeof(int32_t) * e->L);

@@ -132,10 +132,10 @@ GPH_DEV void random_gtree(GphRng &rng)
         setAGE(node1 + node2, g_model.sampleAge[pop]);
       }
     } else {
-      base = gi16(&GphLds::s_ord, g_model.popSon0[pop]);
+      base = gi16(&GphLds::s_dpops, 0, g_model.popSon0[pop]);   /* (the pending-delta lists are free here) */
       num = cur - base;
     }
-    si16(&GphLds::s_ord, pop, base);
+    si16(&GphLds::s_dpops, 0, pop, base);
     T = g_model.popAge[pop];
     if (pop < g_lay.Kc) T = g_model.sampleAge[pop];
     for (; num > 1; num--, nextId++) {
@@ -843,7 +843,7 @@ GPH_DEVHOT void lr_ref_compile(const GphLrArgs &A, int P, GphRefProg &R)
   const int q_leaf = A.o_rseq + GPH_Q_LEAF;
   for (int i = lane; i < n * P; i += GPH_NLANES) {
     const int leaf = i / P, pat = i - leaf * P;
-    const int code = gu8v(q_leaf, pat * n + leaf);
+    const int code = GPH_LEAFCODE(q_leaf, pat, leaf);
     ld2 *o2 = (ld2 *)(GPH_SMB + A.o_lf + i * 32);
     gph_d2 a = {code == 4 || code == 0 ? 1.0 : 0.0, code == 4 || code == 1 ? 1.0 : 0.0};
     gph_d2 b = {code == 4 || code == 2 ? 1.0 : 0.0, code == 4 || code == 3 ? 1.0 : 0.0};
@@ -958,7 +958,7 @@ GPH_DEVHOT double lr_ref_eval(const GphLrArgs &A, const GphRefProg &R, int P, do
     double avg;
     if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
     else avg = prob / nc;
-    term = gph_log(avg) * gi32v(q_count, lane);
+    term = gph_log(avg) * GPH_PATCOUNT(q_count, lane);
   }
   lnl = ordered_sum64(term, P);
 #ifdef GPH_LRSTAMP

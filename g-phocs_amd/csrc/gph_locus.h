@@ -510,7 +510,7 @@ GPH_DEV double child_factor(int child, CP cnd, int p, int a, double pe, double q
 {
   double s0, s1, s2, s3, sa, S, Sp;
   if (child < g_lay.n) {
-    int code = gu8v(q_leaf, p * g_lay.n + child);
+    int code = GPH_LEAFCODE(q_leaf, p, child);
     s0 = (code == 4 || code == 0) ? 1.0 : 0.0;
     s1 = (code == 4 || code == 1) ? 1.0 : 0.0;
     s2 = (code == 4 || code == 2) ? 1.0 : 0.0;
@@ -599,14 +599,15 @@ GPH_DEVHOT double ordered_sum64(double term, int P)
 // the same sum with the terms handed over through LDS: every lane stores its term once, then every lane reads term k
 // at a uniform address (a broadcast read, two terms per 16-byte read) and adds it -- ONE vector instruction per pattern
 // instead of three (two lane reads + the add), at the price of one LDS read per two patterns.  The reads are
-// independent of the running sum and are issued ahead of it.  q_terms: 512 bytes of the dynamic LDS behind the sequence
-// block, allocated by the host when they do not cost a resident workgroup (g_lay.lds_sum, gph_engine_load_loci).
+// independent of the running sum and are issued ahead of it.  q_terms: 8 bytes per pattern (rounded up to eight patterns)
+// of the dynamic LDS behind the sequence block, for the loci that have them inside the launch group's allocation -- the
+// host sizes that so that the terms do not cost a resident workgroup (g_lay.lds_sum, g_lay.dyn_bytes, gph_engine_load_loci).
 // Measured: -4 % vector instructions per sweep wavefront, -1.0 % sweep time.
 #if !defined(GPH_HOSTEMU)
 GPH_DEVHOT double ordered_sum64_lds(double term, int P, int q_terms)
 {
   lf64 *t = (lf64 *)(GPH_SMB + q_terms);
-  t[GPH_LANE] = term;
+  if (GPH_LANE < ((P + 7) & ~7)) t[GPH_LANE] = term;     /* the terms the sum below reads: P rounded up to its groups of eight */
   GPH_WAVE_FENCE();
   double s = 0.0;
 #define GPH_ADD8L(b) s += t[(b) + 0]; s += t[(b) + 1]; s += t[(b) + 2]; s += t[(b) + 3]; s += t[(b) + 4]; s += t[(b) + 5]; s += t[(b) + 6]; s += t[(b) + 7];
@@ -665,7 +666,7 @@ GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1,
    * are never stored or summed, and no execution mask / fill value is needed around the loads */
   if (child < g_lay.n) {
     /* leaf: one-hot (or N).  S = 1 exactly, so S*pe = pe and sa*qe is qe or 0: bit-identical shortcut */
-    const int code = (int)gu8v(q_leaf, lc * g_lay.n + child);
+    const int code = GPH_LEAFCODE(q_leaf, lc, child);
     const double hit = pe + qe;
     const double other = code == 4 ? 1.0 : pe;   /* N: every base gets 1.0 (no code matches below) */
     f0 = code == 0 ? hit : other;
@@ -774,7 +775,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   useOld = RFL(useOld);
   const int P = CNT(CN_P);
   if (P == 0) return 0.0;
-  const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n);
+  const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n, g_lay.cnt16);
   (void)q_terms;
   STAMPB_BEGIN(2);
   const bool isnode = lane < N;
@@ -932,10 +933,10 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       double avg;
       if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
       else avg = prob / nc;
-      term = gph_log(avg) * gi32v(q_count, lane);
+      term = gph_log(avg) * GPH_PATCOUNT(q_count, lane);
     }
     U = __builtin_popcountll(__ballot(ph > 0));
-    if (g_lay.lds_sum) lnl = ordered_sum64_lds(term, P, q_terms);
+    if (g_lay.lds_sum && q_terms + 8 * ((P + 7) & ~7) <= g_lay.dyn_bytes) lnl = ordered_sum64_lds(term, P, q_terms);
     else lnl = ordered_sum64(term, P);
   } else {
     GPH_WAVE_FENCE();
@@ -945,7 +946,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
         int nc = 4 * ph;
         double prob = 0.0;
         for (int c = 0; c < nc; c++) prob += rc[p * 4 + c];
-        sf64(q_terms, p, gph_log(prob / nc) * gi32v(q_count, p));
+        sf64(q_terms, p, gph_log(prob / nc) * GPH_PATCOUNT(q_count, p));
       }
     }
     GPH_SYNC();
@@ -972,7 +973,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   gph_nset need = ns_none();
   double lnl;
   if (P == 0) return 0.0;
-  const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n);
+  const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n, g_lay.cnt16);
   if (!useOld)
     for (node = n; node < N; node++) lik_mark_cond(node);
   setFS(FS_SV_DATALNL, FS(FS_DATALNL));
@@ -1063,7 +1064,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       double avg;
       if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
       else avg = prob / nc;
-      term = gph_log(avg) * gi32v(q_count, lane);
+      term = gph_log(avg) * GPH_PATCOUNT(q_count, lane);
     }
     U = __builtin_popcountll(__ballot(ph > 0));
     lnl = ordered_sum64(term, P);
@@ -1089,7 +1090,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
         int nc = 4 * ph, c;
         double prob = 0.0;
         for (c = 0; c < nc; c++) prob += rc[p * 4 + c];
-        sf64(q_terms, p, gph_log(prob / nc) * gi32v(q_count, p));
+        sf64(q_terms, p, gph_log(prob / nc) * GPH_PATCOUNT(q_count, p));
       }
     }
     GPH_SYNC();
@@ -1120,7 +1121,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
 {
   const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
   const int q_leaf = o_seq + GPH_Q_LEAF, q_phases = o_seq + GPH_Q_PHASES(P, n), q_count = o_seq + GPH_Q_COUNT(P, n),
-            q_terms = o_seq + GPH_Q_TERMS(P, n);
+            q_terms = o_seq + GPH_Q_TERMS(P, n, g_lay.cnt16);
   const bool isnode = lane < N;
 #ifdef GPH_LRSTAMP
   const uint64_t st0 = __builtin_readcyclecounter();
@@ -1201,7 +1202,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
       double avg;
       if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
       else avg = prob / nc;
-      term = gph_log(avg) * gi32v(q_count, lane);
+      term = gph_log(avg) * GPH_PATCOUNT(q_count, lane);
     }
     lnl = ordered_sum64(term, P);
   } else {
@@ -1212,7 +1213,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
         int nc = 4 * ph;
         double prob = 0.0;
         for (int c = 0; c < nc; c++) prob += rc[p * 4 + c];
-        sf64(q_terms, p, gph_log(prob / nc) * gi32v(q_count, p));
+        sf64(q_terms, p, gph_log(prob / nc) * GPH_PATCOUNT(q_count, p));
       }
     }
     GPH_SYNC();
@@ -1264,7 +1265,7 @@ GPH_DEV double lik_private(int o_nd, int o_seq, int P, int root, double rate, in
       int nc = 4 * ph, c;
       double prob = 0.0;
       for (c = 0; c < nc; c++) prob += rc[p * 4 + c];
-      lnl += gph_log(prob / nc) * gi32v(q_count, p);
+      lnl += gph_log(prob / nc) * GPH_PATCOUNT(q_count, p);
     }
   }
   return lnl;
@@ -1993,16 +1994,13 @@ GPH_DEVHOT int trace_lineage(int node, RNG &rng)
             through = true;
           } else {
             const double u = l_rndu(rng);
-#ifndef GPH_HOSTEMU
             /* t = -(1/rate) log(u) is only USED when it falls inside the interval.  -log(u) >= y + y^2/2 for
              * y = 1 - u in (0, 1]: when that bound clears rate*et with a margin far above the rounding errors of
              * either side (each a few 1e-16 relative), t >= et is certain and neither the logarithm nor the
              * reciprocal is evaluated -- about three of four draws of a walk pass through their interval */
             const double y = 1.0 - u;
             through = UNI(y + 0.5 * y * y >= (rate * et) * (1.0 + 1e-9));
-            if (!through)
-#endif
-            {
+            if (!through) {
               t = -(1 / rate) * gph_log_u(u);
               through = UNI(t >= et);
             }
@@ -2259,13 +2257,13 @@ GPH_DEV int check_gtree_structure()
   int i, n, pop, b, ev, id, res = 1, nc;
   LiveList live = {0, 0};
   double age, dt, PREC = 0.0000000001, cs;
-  /* lineages entering each population: LDS work list (s_stack is free here) */
-  for (pop = 0; pop < g_lay.K; pop++) si16(&GphLds::s_stack, pop, 0);
+  /* lineages entering each population: LDS work list (s_targets is free here) */
+  for (pop = 0; pop < g_lay.K; pop++) si16(&GphLds::s_targets, pop, 0);
   for (i = 0; i < g_lay.K; i++) {
     pop = g_model.postOrder[i];
     cs = 0.0;
     nc = 0;
-    n = gi16(&GphLds::s_stack, pop);
+    n = gi16(&GphLds::s_targets, pop);
     age = g_model.popAge[pop];
     live.n = 0;
     int guard = 0;
@@ -2315,7 +2313,7 @@ GPH_DEV int check_gtree_structure()
       case GPH_END_CHAIN:
         if (id != pop || live.n != 0 || ENEXT(ev) >= 0) res = 0;
         if (pop != g_lay.rootPop) {
-          si16(&GphLds::s_stack, g_model.popFather[pop], gi16(&GphLds::s_stack, g_model.popFather[pop]) + n);
+          si16(&GphLds::s_targets, g_model.popFather[pop], gi16(&GphLds::s_targets, g_model.popFather[pop]) + n);
           if (fabs(g_model.popAge[g_model.popFather[pop]] - age) > PREC) res = 0;
         }
         break;

@@ -275,3 +275,6 @@ GPH_DEV int gu8v(int off, int i) { return ((lu8 *)(GPH_SMB + off))[i]; }
 GPH_DEV int gu16v(int off, int i) { return ((GPH_LDS uint16_t *)(GPH_SMB + off))[i]; }
 GPH_DEV int gu16(int off, int i) { return RFL(((GPH_LDS uint16_t *)(GPH_SMB + off))[i]); }
 GPH_DEV int gi32v(int off, int i) { return ((li32 *)(GPH_SMB + off))[i]; }
+// leaf code (4 bits) of leaf `child` for pattern p, and pattern p's count (16 or 32 bits): gph_types.h, sequence block
+#define GPH_LEAFCODE(q_leaf, p, child) ((gu8v((q_leaf), (p) * GPH_Q_NH(g_lay.n) + ((child) >> 1)) >> (((child) & 1) << 2)) & 15)
+#define GPH_PATCOUNT(q_count, p) (g_lay.cnt16 ? gu16v((q_count), (p)) : gi32v((q_count), (p)))

@@ -42,7 +42,9 @@ typedef uint64_t gph_popmask;
 typedef uint32_t gph_popmask;
 #endif
 #define GPH_MAXB 16        // migration bands (reference cap 100, patch.h:17)
-#define GPH_MAX_MIGS 10    // migration events per genealogy (patch.h:18)
+#ifndef GPH_MAX_MIGS
+#define GPH_MAX_MIGS 10    // migration events per genealogy (patch.h:18); smaller only in LDS-size experiments
+#endif
 #if GPH_CAP_LEAVES > 32
 #define GPH_BIG_TREE 1     // 2n - 1 > 64 genealogy nodes: no lane-per-node programs, node sets of 128 bits
 #define GPH_NSW 4          // 32-bit page words per node set
@@ -95,7 +97,9 @@ struct GphLayout {
   int32_t page_bytes;      // multiple of 16: the page part of GphLds
   int32_t Pmax;            // max phased patterns of any locus on this device
   int32_t lds_bytes;       // largest dynamic-LDS allocation of a launch (sequence block [+ terms])
-  int32_t lds_sum;         // 1: the root reduction hands its per-pattern terms over through 512 bytes of dynamic LDS (ordered_sum64_lds)
+  int32_t lds_sum;         // 1: the root reduction hands its per-pattern terms over through dynamic LDS (ordered_sum64_lds) for the loci whose terms fit behind their block
+  int32_t cnt16;           // 1: pattern counts are stored as u16 (every count of the data set is below 65536)
+  int32_t dyn_bytes;       // dynamic LDS of THIS launch (set per launch group)
 };
 struct GphGlobal;
 // model + layout tables travel BY VALUE as the first argument of every kernel: in the kernarg segment every
@@ -116,15 +120,21 @@ struct GphKargs {
 };
 
 // Sequence block of one locus (HBM block format == dynamic-LDS image), sized by the locus' OWN number of
-// phased patterns P: leaf codes u8[P][n] | (pad to 2) phases u16[P] | (pad to 4) counts i32[P] | (pad to 16);
-// behind it, for loci with more than one pattern per lane only, f64[P] terms of the root reduction.
+// phased patterns P: leaf codes, 4 bits each, u8[P][(n + 1) / 2] (leaf i of pattern p: nibble i & 1 of byte
+// p * ((n + 1) / 2) + i / 2; codes are 0..3 = T C A G, 4 = N) | (pad to 2) phases u16[P] | (pad to 4) pattern counts
+// u16[P] (c16: every count of the data set fits, GphLayout.cnt16) or i32[P] | (pad to 16); behind it f64 terms of the
+// root reduction: P of them for loci with more than one pattern per lane, up to 64 for the others when the launch
+// group's dynamic LDS has the room (GphLayout.dyn_bytes).  The block is what decides how many loci are resident per CU
+// next to the 4.3-KB static image (LDS comes in 1280-byte granules): a 64-pattern block is 768 bytes this way, 1424 with
+// a byte per code and 32-bit counts.
 // Phase counts are 16 bits: the reference keeps an int, and 8 unbroken heterozygotes in one repeated alignment
 // column already give 2^8 = 256 phases (AlignmentProcessor.c:998-1158)
 #define GPH_Q_LEAF 0
-#define GPH_Q_PHASES(P, n) (((P) * (n) + 1) & ~1)
+#define GPH_Q_NH(n) (((n) + 1) >> 1)
+#define GPH_Q_PHASES(P, n) (((P) * GPH_Q_NH(n) + 1) & ~1)
 #define GPH_Q_COUNT(P, n) ((GPH_Q_PHASES(P, n) + 2 * (P) + 3) & ~3)
-#define GPH_Q_BYTES(P, n) ((GPH_Q_COUNT(P, n) + 4 * (P) + 15) & ~15)
-#define GPH_Q_TERMS(P, n) GPH_Q_BYTES(P, n)
+#define GPH_Q_BYTES(P, n, c16) ((GPH_Q_COUNT(P, n) + ((c16) ? 2 : 4) * (P) + 15) & ~15)
+#define GPH_Q_TERMS(P, n, c16) GPH_Q_BYTES(P, n, c16)
 // delta scalars (s_di[inst])
 enum { DI_ORIG = 0, DI_UPD, DI_DLIN, DI_NEV, DI_NPOPS, DI_NBANDS, DI_SRCPOP, DI_TGTPOP, DI_COUNT };   // DI_SRCPOP / DI_TGTPOP: the populations of the original / the new event
 // spr scalars (register lanes, GphCtx), i16 arrays (s_spri16 + 10*k), f64 (s_sprf: new_ages[0..9], dlnLd[10..11])
@@ -198,15 +208,24 @@ struct alignas(16) GphLds {
   int16_t mig_i[GPH_MAX_MIGS * 6], living[GPH_MAX_MIGS], ncoal[GPH_CAP_K], nmig[GPH_CAP_B], rb_i[3 * GPH_CAP_RB];
   // ---- LDS-only scratch: pending-proposal storage of GENETREE_STATS_DELTA x2 (patch.h:60-72),
   // MIG_SPR_STATS (patch.h:97-105), genetree_stats_check (patch.h:109), pruning work lists
-  double s_dcoal[2][GPH_CAP_K], s_dmig[2][GPH_CAP_B], s_sprf[GPH_MAX_MIGS + 2];
-  double s_chkcoal[GPH_CAP_K], s_chkmig[GPH_CAP_B], s_cntf[8];   // s_cntf: 0 algorithmic bytes, 2..6 sweep accumulators, 7 step size
+  double s_dcoal[2][GPH_CAP_K], s_dmig[2][GPH_CAP_B];
+  double s_cntf[8];   // s_cntf: 0 algorithmic bytes, 2..6 sweep accumulators, 7 step size
+  // the SPR's scalars (sweep kernel, one proposal at a time) and the statistics being re-derived (recalcStats,
+  // computeGenetreeStats, checkAll: tau / sample-age / refresh / check code, never inside an SPR) share their bytes
+  union {
+    struct { double s_sprf[GPH_MAX_MIGS + 2]; int16_t s_spri16[4 * GPH_MAX_MIGS]; };
+    struct { double s_chkcoal[GPH_CAP_K], s_chkmig[GPH_CAP_B]; int16_t s_chknc[GPH_CAP_K], s_chknm[GPH_CAP_B]; };
+  };
 #if defined(GPH_STAMPS) || defined(GPH_HOSTEMU)
   double s_stamp[8];          // diagnostic cycle sums (tools/stamp_breakdown.py); not in production device builds
 #endif
   int32_t s_di[2][8];   /* the SPR scalars and the counters (SI_*, CN_*) live in register lanes: GphCtx, gph_locus.h */
   uint32_t s_condptr[2];
-  int16_t s_dpops[2][GPH_CAP_K], s_dbands[2][GPH_CAP_B], s_spri16[4 * GPH_MAX_MIGS];
-  int16_t s_ord[GPH_CAP_N + 1], s_stack[GPH_CAP_N + 1], s_targets[GPH_CAP_N + 1], s_chknc[GPH_CAP_K], s_chknm[GPH_CAP_B];
+  int16_t s_dpops[2][GPH_CAP_K], s_dbands[2][GPH_CAP_B];
+  int16_t s_targets[GPH_CAP_N + 1];   // candidate edges of a regraft (getEdgesForTimePop); a per-population work list of init / check code
+#if GPH_BIG_TREE || defined(GPH_HOSTEMU)
+  int16_t s_ord[GPH_CAP_N + 1], s_stack[GPH_CAP_N + 1];   // the list-driven pruning (the lane-per-node builds have no lists)
+#endif
   gph_evid s_dev[2][GPH_CAP_E];  // event lists of the two pending deltas
 #if GPH_BIG_TREE
   double s_pe[GPH_CAP_N];        // edge transition probabilities of an evaluation, by child node (the smaller builds keep them in the lane of the node)
