@@ -548,3 +548,17 @@ def test_root_sum_through_lds_equals_lane_reads(G, tmp_path, name):
     assert open(a).read() == open(b).read()
     assert open(a + ".state").read() == open(b + ".state").read()
     compare_records(a, os.path.join(GOLDEN, name + ".rtrace"))
+
+
+@pytest.mark.parametrize("name", ["m3", "a7", "x8"])
+def test_sequence_block_forms_agree(G, tmp_path, name):
+    """the sequence block keeps pattern counts as 16-bit words when every count of the data set allows it and the root
+    sum takes its LDS form per locus, where the terms fit behind the block; the 32-bit counts (GPH_CNT16=0) and the
+    default group sizing (neither form forced) give byte-identical records and state, equal to the reference's"""
+    pack = os.path.join(GOLDEN, name + ".gpk")
+    a, b = str(tmp_path / "c16.rec"), str(tmp_path / "c32.rec")
+    _records(G, pack, CASES[name], a)
+    _records(G, pack, CASES[name], b, env={"GPH_CNT16": "0"})
+    assert open(a).read() == open(b).read()
+    assert open(a + ".state").read() == open(b + ".state").read()
+    compare_records(a, os.path.join(GOLDEN, name + ".rtrace"))

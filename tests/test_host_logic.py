@@ -35,6 +35,19 @@ def test_hostemu_matches_reference_goldens(hostemu, name, iters, tmp_path):
     assert worst < 1e-12
 
 
+@pytest.mark.parametrize("name,iters", [("m3", 120), ("v8", 60)])
+def test_sequence_block_with_32bit_counts(hostemu, name, iters, tmp_path, monkeypatch):
+    """the sequence block stores pattern counts as 16-bit words when every count of the data set allows it; the 32-bit
+    form (a locus longer than 65 535 sites can have such a count) must read the same values"""
+    R, lib = hostemu
+    monkeypatch.setenv("GPH_CNT16", "0")
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(os.path.join(GOLDEN, name + ".gpk"), iters, str(tr), str(st), iters - 1, lib=lib)
+    worst = compare_records(tr, os.path.join(GOLDEN, name + ".rtrace"))
+    compare_states(st, os.path.join(GOLDEN, name + ".state"))
+    assert worst < 1e-12
+
+
 @pytest.mark.parametrize("name,iters", [("y9", 16), ("x8", 24), ("m3", 120), ("a7", 100), ("v8", 60)])
 def test_big_tree_build_matches_reference_goldens(name, iters, tmp_path):
     """the 64-leaf / 39-population capacities (library variant `h`: 128-bit node sets, 64-bit population sets, 16-bit
@@ -93,6 +106,27 @@ def test_locus_rate_edge_cases_against_live_oracle(hostemu, oracle_cli, tmp_path
         pk.leafcodes, pk.numPhases, pk.counts = pk.leafcodes[p0:], pk.numPhases[p0:], pk.counts[p0:]
         pk.pattern_offsets = np.concatenate([[0], pk.pattern_offsets[1:] - p0]).astype(np.int64)
     pth = str(tmp_path / "ve.gpk")
+    synth.write_pack(pk, pth)
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(pth, 12, str(tr), str(st), 11, lib=lib)
+    ot, os_ = tmp_path / "o.t", tmp_path / "o.s"
+    subprocess.run([oracle_cli, "run", pth, "12", str(ot), str(os_), "11", "1"], check=True, timeout=300)
+    assert compare_records(tr, ot) < 1e-12
+    compare_states(st, os_)
+
+
+def test_pattern_counts_beyond_16_bits_against_live_oracle(hostemu, oracle_cli, tmp_path):
+    """a data set with pattern counts above 65 535 (long loci): the sequence block falls back to 32-bit counts by itself;
+    host build of the engine sources against the oracle's serial loop on the same pack"""
+    import subprocess
+    import numpy as np
+    import gphocs_amd as G
+    from gphocs_amd_pkg import synth
+    R, lib = hostemu
+    pk = synth.make_synthetic_pack(G.Pack, 3, 24, mut_scale=1.0, data_seed=11, mcmc_seed=7, samples_per_log=4)
+    pk.counts = (np.asarray(pk.counts, dtype=np.int64) * 400).astype(np.asarray(pk.counts).dtype)
+    assert int(np.max(pk.counts)) > 65535
+    pth = str(tmp_path / "big.gpk")
     synth.write_pack(pk, pth)
     tr, st = tmp_path / "t", tmp_path / "s"
     R.run(pth, 12, str(tr), str(st), 11, lib=lib)
