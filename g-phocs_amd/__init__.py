@@ -31,11 +31,14 @@ CSRC = os.path.join(_HERE, "csrc")
 # the extra merges with register copies in the loop bodies; leaving uniform regions as the plain scalar-branch CFG
 # they are: -5 % sweep time, -7..18 % static instructions per kernel.
 # -amdgpu-sched-strategy=max-ilp: the sweep kernel is issue-bound at a fixed occupancy (launch bounds), so the
-# scheduler has nothing to gain from trading latency hiding for registers: -0.7 %.
+# scheduler has nothing to gain from trading latency hiding for registers: -0.7 % -- for the variants built for 6
+# wavefronts per SIMD (80 VGPRs, no spill).  Variant s is built for 8 (64 VGPRs): there the default scheduler spills 18
+# vector registers instead of 23 and is the 0.7 % faster one (HIPCC_TUNING_SPILLING).
 HIPCC_BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
               "-Wno-unused-result", "-pthread"]
 HIPCC_TUNING = ["-mllvm", "-disable-machine-licm", "-mllvm", "-structurizecfg-skip-uniform-regions",
                 "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+HIPCC_TUNING_SPILLING = HIPCC_TUNING[:4]
 HIPCC_FLAGS = HIPCC_BASE + HIPCC_TUNING
 HIPCC_LIBS = ["-ldl", "-lrt"]        # after the sources: an --as-needed linker drops libraries named before their users
 # The tuning switches above are backend options of THIS compiler (uniformity analysis decides what
@@ -149,7 +152,8 @@ def _build_locked(verbose):
 
     for name, (cl, ck, cb, waves, fn) in VARIANTS.items():
         library(os.path.join(_HERE, fn), name,
-                HIPCC_FLAGS + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"])
+                HIPCC_BASE + (HIPCC_TUNING_SPILLING if waves > 6 else HIPCC_TUNING) +
+                [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"])
     # control build without the backend switches (parity tests only)
     cl, ck, cb, waves, _ = VARIANTS["m"]
     library(os.path.join(_HERE, PLAIN_LIB), "plain",

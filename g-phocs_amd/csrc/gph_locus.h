@@ -299,22 +299,27 @@ typedef GphRng GphRngB;
 struct GphRngB {
   uint32_t x, y, z;      // state after the last draw of the batch (uniform)
   int pos;               // draws of the batch handed out; GPH_WAVE = none left
-  uint32_t rx, ry, rz;   // per lane: state after draw `lane` of the batch
   double u;              // per lane: draw `lane` of the batch
 };
 GPH_DEV void rng_load(GphRngB &g)
 {
   g.x = (uint32_t)ISC(IS_RX); g.y = (uint32_t)ISC(IS_RY); g.z = (uint32_t)ISC(IS_RZ);
-  g.pos = GPH_WAVE; g.rx = g.ry = g.rz = 0; g.u = 0.0;
+  g.pos = GPH_WAVE; g.u = 0.0;
 }
+// The page scalars IS_RX / IS_RY / IS_RZ hold the state the current batch STARTED from (rng_refill); the state to leave
+// behind is the one after the last draw handed out: the recurrences replayed for `pos` steps, once per kernel (scalar
+// unit).  Keeping the per-lane states of the batch for this instead cost three vector registers for the whole kernel, and
+// the sweep kernel is compiled for 64 of them.
 GPH_DEV void rng_store(const GphRngB &g)
 {
   uint32_t x = g.x, y = g.y, z = g.z;
   if (g.pos < GPH_WAVE) {
-    const int l = g.pos - 1;    /* a batch is only made when a draw is wanted: pos >= 1 */
-    x = (uint32_t)__builtin_amdgcn_readlane((int)g.rx, l);
-    y = (uint32_t)__builtin_amdgcn_readlane((int)g.ry, l);
-    z = (uint32_t)__builtin_amdgcn_readlane((int)g.rz, l);
+    x = (uint32_t)ISC(IS_RX); y = (uint32_t)ISC(IS_RY); z = (uint32_t)ISC(IS_RZ);
+    for (int k = 0; k < g.pos; k++) {
+      x = 171u * x - 30269u * (x / 177u);
+      y = 172u * y - 30307u * (y / 176u);
+      z = 170u * z - 30323u * (z / 178u);
+    }
   }
   setISC(IS_RX, (int)x); setISC(IS_RY, (int)y); setISC(IS_RZ, (int)z);
 }
@@ -322,6 +327,7 @@ GPH_DEV void rng_refill(GphRngB &g)
 {
   uint32_t x = g.x, y = g.y, z = g.z;
   int vx = 0, vy = 0, vz = 0;
+  setISC(IS_RX, (int)x); setISC(IS_RY, (int)y); setISC(IS_RZ, (int)z);
 #pragma unroll 4
   for (int k = 0; k < GPH_WAVE; k++) {
     x = 171u * x - 30269u * (x / 177u);
@@ -333,7 +339,6 @@ GPH_DEV void rng_refill(GphRngB &g)
         : "+v"(vx), "+v"(vy), "+v"(vz) : "s"(x), "s"(y), "s"(z), "s"(k) : "m0");
   }
   g.x = x; g.y = y; g.z = z;
-  g.rx = (uint32_t)vx; g.ry = (uint32_t)vy; g.rz = (uint32_t)vz;
 #if defined(__HIP_DEVICE_COMPILE__)       /* (the host pass of hipcc only parses this) */
   {
     const gph_cdbl *RC = GPH_RNGC;
