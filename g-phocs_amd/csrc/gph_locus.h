@@ -297,22 +297,23 @@ GPH_DEV double l_rndu(GphRng &g)
 typedef GphRng GphRngB;
 #else
 struct GphRngB {
-  uint32_t x, y, z;      // state after the last draw of the batch (uniform)
   int pos;               // draws of the batch handed out; GPH_WAVE = none left
   double u;              // per lane: draw `lane` of the batch
 };
+// The generator's integer state is touched twice per 64 draws, so it lives in lanes of the scalar pad, not in scalar
+// registers that stay allocated (and get spilled) across the whole sweep: page scalars IS_RX / IS_RY / IS_RZ = the state
+// the current batch STARTED from, CN_RX / CN_RY / CN_RZ = the state after its 64th draw (where the next batch starts).
 GPH_DEV void rng_load(GphRngB &g)
 {
-  g.x = (uint32_t)ISC(IS_RX); g.y = (uint32_t)ISC(IS_RY); g.z = (uint32_t)ISC(IS_RZ);
+  setCNT(CN_RX, ISC(IS_RX)); setCNT(CN_RY, ISC(IS_RY)); setCNT(CN_RZ, ISC(IS_RZ));
   g.pos = GPH_WAVE; g.u = 0.0;
 }
-// The page scalars IS_RX / IS_RY / IS_RZ hold the state the current batch STARTED from (rng_refill); the state to leave
-// behind is the one after the last draw handed out: the recurrences replayed for `pos` steps, once per kernel (scalar
-// unit).  Keeping the per-lane states of the batch for this instead cost three vector registers for the whole kernel, and
-// the sweep kernel is compiled for 64 of them.
+// The state to leave behind is the one after the last draw handed out: the recurrences replayed from the batch's start
+// for `pos` steps, once per kernel (scalar unit).  Keeping the per-lane states of the batch for this instead cost three
+// vector registers for the whole kernel, and the sweep kernel is compiled for 64 of them.
 GPH_DEV void rng_store(const GphRngB &g)
 {
-  uint32_t x = g.x, y = g.y, z = g.z;
+  uint32_t x = (uint32_t)CNT(CN_RX), y = (uint32_t)CNT(CN_RY), z = (uint32_t)CNT(CN_RZ);
   if (g.pos < GPH_WAVE) {
     x = (uint32_t)ISC(IS_RX); y = (uint32_t)ISC(IS_RY); z = (uint32_t)ISC(IS_RZ);
     for (int k = 0; k < g.pos; k++) {
@@ -325,7 +326,7 @@ GPH_DEV void rng_store(const GphRngB &g)
 }
 GPH_DEV void rng_refill(GphRngB &g)
 {
-  uint32_t x = g.x, y = g.y, z = g.z;
+  uint32_t x = (uint32_t)CNT(CN_RX), y = (uint32_t)CNT(CN_RY), z = (uint32_t)CNT(CN_RZ);
   int vx = 0, vy = 0, vz = 0;
   setISC(IS_RX, (int)x); setISC(IS_RY, (int)y); setISC(IS_RZ, (int)z);
 #pragma unroll 4
@@ -338,7 +339,7 @@ GPH_DEV void rng_refill(GphRngB &g)
     asm("s_mov_b32 m0, %6\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
         : "+v"(vx), "+v"(vy), "+v"(vz) : "s"(x), "s"(y), "s"(z), "s"(k) : "m0");
   }
-  g.x = x; g.y = y; g.z = z;
+  setCNT(CN_RX, (int)x); setCNT(CN_RY, (int)y); setCNT(CN_RZ, (int)z);
 #if defined(__HIP_DEVICE_COMPILE__)       /* (the host pass of hipcc only parses this) */
   {
     const gph_cdbl *RC = GPH_RNGC;
