@@ -371,6 +371,12 @@ struct gph_engine {
   uint32_t timing_mask = 0xffffffffu;   // classes whose launches are bracketed by HIP events
 #ifndef GPH_HOSTEMU
   hipStream_t stream = nullptr;
+  // the launch group of the pattern-rich loci (P > 64: a few per cent of a data set, long wavefronts) runs NEXT TO the
+  // main group on a stream of its own, forked from and joined to the engine's stream with two events per launch point:
+  // one after the other, the small group cost a wavefront lifetime of its own per kernel class (configs[4]: 5 % of a sweep)
+  hipStream_t stream_wide = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_stream = true;            // GPH_SIDE_STREAM=0: the groups one after the other on the engine's stream (A/B, tests)
   struct Tm { hipEvent_t a, b; int which; };
   std::vector<Tm> tm;                // event pairs of the launches since the last synchronisation
   size_t tm_used = 0;
@@ -509,10 +515,13 @@ static void tm_end(gph_engine *e, int slot) { if (slot >= 0) (void)hipEventRecor
 #define LAUNCH_PRE(e) do { GphKargs &ka_ = (e)->ka; ka_.model = (e)->G_h->model; ka_.lay = (e)->lay; ka_.G = (e)->G_d; } while (0)
 #define LAUNCH(e, which, name, ...) do { { int rcf_ = flush_pending(e); if (rcf_) return rcf_; } LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
     const int tms_ = tm_begin((e), (which)); \
-    for (auto &bk_ : (e)->buckets) { \
+    const bool fork_ = (e)->side_stream && (e)->buckets.size() == 2; \
+    if (fork_) { HIPCHK(hipEventRecord((e)->ev_fork, (e)->stream)); HIPCHK(hipStreamWaitEvent((e)->stream_wide, (e)->ev_fork, 0)); } \
+    for (size_t bi_ = 0; bi_ < (e)->buckets.size(); bi_++) { auto &bk_ = (e)->buckets[bi_]; \
       ka_.lay.dyn_bytes = bk_.lds_bytes; \
-      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes + (e)->lds_pad[which], (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
+      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes + (e)->lds_pad[which], fork_ && bi_ == 0 ? (e)->stream_wide : (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
       HIPCHK(hipGetLastError()); (e)->n_launches++; } \
+    if (fork_) { HIPCHK(hipEventRecord((e)->ev_join, (e)->stream_wide)); HIPCHK(hipStreamWaitEvent((e)->stream, (e)->ev_join, 0)); } \
     tm_end((e), tms_); \
     (e)->last_which = (which); (e)->cls_launches[which] += 1; } while (0)
 #endif
@@ -863,7 +872,9 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
     delete e;
     return GPH_EHIP;
   }
-  if (hipStreamCreate(&e->stream) != hipSuccess ||
+  if (const char *ov = getenv("GPH_SIDE_STREAM")) e->side_stream = atoi(ov) != 0;
+  if (hipStreamCreate(&e->stream) != hipSuccess || hipStreamCreateWithFlags(&e->stream_wide, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc((void **)&e->G_h, sizeof(GphGlobal), hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void **)&e->G_d, sizeof(GphGlobal)) != hipSuccess ||
       hipHostMalloc((void **)&e->h_red, sizeof(double) * GPH_RED_ROW * 64, hipHostMallocDefault) != hipSuccess ||
@@ -902,6 +913,9 @@ void gph_engine_destroy(gph_engine *e)
   if (e->h_red) (void)hipHostFree(e->h_red);
   if (e->G_h) (void)hipHostFree(e->G_h);
   for (auto &t : e->tm) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->stream_wide) (void)hipStreamDestroy(e->stream_wide);
   if (e->stream) (void)hipStreamDestroy(e->stream);
 #endif
   delete e;

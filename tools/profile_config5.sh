@@ -10,6 +10,21 @@ python3 tools/bench_config5.py > $OUT/config5_bench.json 2> $OUT/config5_bench.e
 echo "bench rc=$?"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/config5_kstats -o k --output-format csv -- python3 $ROOT/tools/bench_config5.py > $OUT/config5_kstats.log 2>&1)
 echo "kstats rc=$?"
+# the two dispatches of a launch point overlap (side stream, gph_engine.hip): per sweep, first start to last end
+python3 - <<'PY'
+import csv, glob, json
+f = glob.glob("gpurun_out/config5_kstats/*kernel_trace.csv")
+if f:
+    rows = [r for r in csv.DictReader(open(f[0])) if r["Kernel_Name"].startswith("k_sweep")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    walls, sums = [], []
+    for i in range(0, len(rows) - 1, 2):
+        a, b = rows[i], rows[i + 1]
+        walls.append(max(int(a["End_Timestamp"]), int(b["End_Timestamp"])) - int(a["Start_Timestamp"]))
+        sums.append(int(a["End_Timestamp"]) - int(a["Start_Timestamp"]) + int(b["End_Timestamp"]) - int(b["Start_Timestamp"]))
+    json.dump({"sweeps": len(walls), "k_sweep_wall_ms_per_sweep": sum(walls) / len(walls) / 1e6,
+               "k_sweep_summed_dispatch_ms_per_sweep": sum(sums) / len(sums) / 1e6}, open("gpurun_out/config5_sweep_wall.json", "w"))
+PY
 find $OUT/config5_kstats -name "*kernel_trace.csv" -delete
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 900 rocprofv3 --pmc $c -d $OUT/config5_pmc/$c -o p --output-format csv -- python3 $ROOT/tools/bench_config5.py > $OUT/config5_pmc_$c.log 2>&1)

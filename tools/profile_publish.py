@@ -54,8 +54,8 @@ print(json.dumps({k2: b[k2] for k2 in ("value", "ms_per_step", "mcmc_iters_per_s
 
 # BASELINE configs[4] at its stated size (tools/profile_config5.sh), when its outputs are there: ONE run per file.  The data
 # set has loci with more than 64 phased patterns, so every kernel class is TWO dispatches per launch point (the few
-# pattern-rich loci first, then everything else): the per-dispatch average of the kernel-stats CSV is not a per-sweep
-# time -- the per-sweep figure below is the summed duration of the class divided by the iterations of the run.
+# pattern-rich loci on a side stream next to everything else): the per-dispatch average of the kernel-stats CSV is not a
+# per-sweep time, and the summed durations overlap -- the per-sweep wall time comes from the trace (profile_config5.sh).
 import csv
 import os
 if os.path.exists("gpurun_out/config5_bench.json") and os.path.exists("gpurun_out/config5_kstats/k_kernel_stats.csv"):
@@ -67,7 +67,11 @@ if os.path.exists("gpurun_out/config5_bench.json") and os.path.exists("gpurun_ou
         "k_sweep_dispatches": int(sw["Calls"]), "iterations_of_the_run": iters, "dispatches_per_sweep": int(sw["Calls"]) / iters,
         "k_sweep_ms_per_sweep": float(sw["TotalDurationNs"]) / iters / 1e6,
         "k_sweep_max_dispatch_ms": float(sw["MaxNs"]) / 1e6, "k_sweep_min_dispatch_ms": float(sw["MinNs"]) / 1e6,
-        "note": "two dispatches per sweep (loci with > 64 phased patterns, then the rest): compare ms_per_sweep with sweep_ms"}
+        "note": "two dispatches per sweep (loci with > 64 phased patterns on a side stream, next to the rest): the summed "
+                "durations overlap; compare k_sweep_wall_ms_per_sweep (first start to last end of a sweep's two dispatches, "
+                "from the same trace) with sweep_ms"}
+    if os.path.exists("gpurun_out/config5_sweep_wall.json"):
+        cb["rocprofv3_kernel_stats"].update(json.load(open("gpurun_out/config5_sweep_wall.json")))
     json.dump(cb, open(f"profiles/{rnd}_config5_bench.json", "w"), indent=1)
     shutil.copy("gpurun_out/config5_kstats/k_kernel_stats.csv", f"profiles/{rnd}_config5_kernel_stats.csv")
     if os.path.exists("gpurun_out/config5_pmc.json"):
