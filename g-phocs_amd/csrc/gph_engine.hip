@@ -1015,6 +1015,8 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
       e->buckets.push_back(bk);
     }
   }
+  /* (a group that was given the rest of its granules for the root sum's terms can be larger than block + 512 bytes) */
+  for (auto &bk : e->buckets) if (bk.lds_bytes > e->lay.lds_bytes) e->lay.lds_bytes = bk.lds_bytes;
   e->h_cond_off.resize(L + 1);
   e->h_P.resize(L);
   std::vector<uint64_t> seq_off(L + 1);
