@@ -550,6 +550,18 @@ def test_root_sum_through_lds_equals_lane_reads(G, tmp_path, name):
     compare_records(a, os.path.join(GOLDEN, name + ".rtrace"))
 
 
+def test_side_stream_equals_serial_launch_groups(G, tmp_path):
+    """the launch group of the pattern-rich loci (P > 64) runs next to the main group on a side stream, forked from and
+    joined to the engine's stream per launch point; GPH_SIDE_STREAM=0 runs the two groups one after the other:
+    byte-identical records and state (golden bigp: one locus with 75 patterns among 16)"""
+    pack = os.path.join(GOLDEN, "bigp.gpk")
+    a, b = str(tmp_path / "side.rec"), str(tmp_path / "serial.rec")
+    _records(G, pack, 40, a)
+    _records(G, pack, 40, b, env={"GPH_SIDE_STREAM": "0"})
+    assert open(a).read() == open(b).read()
+    assert open(a + ".state").read() == open(b + ".state").read()
+
+
 @pytest.mark.parametrize("name", ["m3", "a7", "x8"])
 def test_sequence_block_forms_agree(G, tmp_path, name):
     """the sequence block keeps pattern counts as 16-bit words when every count of the data set allows it and the root
