@@ -550,6 +550,17 @@ def test_root_sum_through_lds_equals_lane_reads(G, tmp_path, name):
     compare_records(a, os.path.join(GOLDEN, name + ".rtrace"))
 
 
+def test_odd_leaf_count_and_pattern_rich_loci_against_live_oracle(G, oracle_cli, tmp_path):
+    """13 leaves (an odd count: the last byte of a pattern's 4-bit leaf codes is half used) and loci with up to 485 phased
+    patterns, 30 of the 40 with more than 64 (the side-stream launch group is the larger one here)"""
+    pack = os.path.join(GOLDEN, "stress.gpk")
+    tr, _, st1, _ = _run(G, pack, 10, tmp_path, "stress")
+    ot, os_ = tmp_path / "o.trace", tmp_path / "o.state"
+    subprocess.run([oracle_cli, "run", pack, "10", str(ot), str(os_), "9", "1"], check=True, timeout=600)
+    compare_records(tr, ot)
+    compare_states(st1, os_)
+
+
 def test_side_stream_equals_serial_launch_groups(G, tmp_path):
     """the launch group of the pattern-rich loci (P > 64) runs next to the main group on a side stream, forked from and
     joined to the engine's stream per launch point; GPH_SIDE_STREAM=0 runs the two groups one after the other:

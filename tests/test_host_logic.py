@@ -115,6 +115,20 @@ def test_locus_rate_edge_cases_against_live_oracle(hostemu, oracle_cli, tmp_path
     compare_states(st, os_)
 
 
+def test_odd_leaf_count_and_pattern_rich_loci_against_live_oracle(hostemu, oracle_cli, tmp_path):
+    """13 leaves (an odd count: the last byte of a pattern's 4-bit leaf codes is half used) and loci with up to 485 phased
+    patterns (30 of the 40 with more than 64): the front end's `stress` pack through the engine sources, against the
+    oracle's serial loop on the same pack"""
+    R, lib = hostemu
+    pack = os.path.join(GOLDEN, "stress.gpk")
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(pack, 10, str(tr), str(st), 9, lib=lib)
+    ot, os_ = tmp_path / "o.t", tmp_path / "o.s"
+    subprocess.run([oracle_cli, "run", pack, "10", str(ot), str(os_), "9", "1"], check=True, timeout=300)
+    assert compare_records(tr, ot) < 1e-12
+    compare_states(st, os_)
+
+
 def test_pattern_counts_beyond_16_bits_against_live_oracle(hostemu, oracle_cli, tmp_path):
     """a data set with pattern counts above 65 535 (long loci): the sequence block falls back to 32-bit counts by itself;
     host build of the engine sources against the oracle's serial loop on the same pack"""
