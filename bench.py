@@ -238,10 +238,58 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+# Issue cost of one wave-instruction on its SIMD, by class, MEASURED on the MI355X with 8 wavefronts per SIMD
+# (tools/probe/class_probe.cpp -> profiles/r04_class_probe.txt; cycles at 2.4 GHz).  A CU has four SIMD-32s: a pure
+# vector-register 32-bit instruction takes 2.4 cycles, but everything fp64, and EVERY vector instruction that reads or
+# writes a scalar register (lane reads / writes, v_mov from an SGPR, compares into a lane mask, v_readfirstlane) holds the
+# SIMD 4.2 cycles; the scalar unit is one per CU (1 instruction per cycle = 4.35 cycles of each SIMD's share), the LDS pipe
+# takes one DS instruction per 4.1 cycles per CU (16.4 per SIMD share).
+CLASS_CYCLES = {"f64": 4.27, "trans_f64": 16.2, "int32_low": 2.5, "int32_high": 4.27, "int64": 4.27, "cvt": 4.22,
+                "other_low": 2.4, "other_high": 4.25, "salu": 4.35, "lds": 16.4}
+
+
+def issue_roofline(tj, sweep_ms, loci, source):
+    """Pipe occupancy of the sweep kernel from committed counter passes (profiles/traffic_k_sweep.json): instructions per
+    wavefront by class x measured issue cost / the SIMD-cycles one locus has (4 SIMDs per CU x the CU's cycles per locus at
+    the nominal 2.4 GHz, which is what the kernel runs at: 2.34-2.41 GHz read inside k_sweep by a probe build).  The
+    counters cannot tell a register-to-register move (2.4 cycles) from a lane read (4.25), so the vector pipe gets a
+    range: `other` priced low and high."""
+    cyc_cu = sweep_ms * 1e-3 * 2.4e9 / (loci / 256.0)
+    budget = 4.0 * cyc_cu
+    valu, salu, lds = tj["valu_per_wave"], tj["salu_per_wave"], tj.get("lds_per_wave") or 0.0
+    C = CLASS_CYCLES
+    mix = tj.get("valu_mix_per_wave")
+    if mix:
+        f64 = mix["add_f64"] + mix["mul_f64"] + mix["fma_f64"]
+        known = f64 + mix["trans_f64"] + mix["int32"] + mix["int64"] + mix["cvt"]
+        other = max(valu - known, 0.0)
+        fixed = f64 * C["f64"] + mix["trans_f64"] * C["trans_f64"] + mix["int64"] * C["int64"] + mix["cvt"] * C["cvt"]
+        lo = fixed + mix["int32"] * C["int32_low"] + other * C["other_low"]
+        hi = fixed + mix["int32"] * C["int32_high"] + other * C["other_high"]
+    else:
+        f64, other, lo, hi = None, None, valu * C["other_low"], valu * C["f64"]
+    pipes = {"valu_low": lo / budget, "valu_high": hi / budget, "salu": salu * C["salu"] / budget, "lds": lds * C["lds"] / budget}
+    busiest = max(("valu", pipes["valu_high"]), ("salu", pipes["salu"]), ("lds", pipes["lds"]), key=lambda kv: kv[1])
+    return {"valu_per_wave": valu, "salu_per_wave": salu, "lds_per_wave": lds, "valu_f64_per_wave": f64,
+            "valu_moves_lane_ops_compares_selects_per_wave": other,
+            "class_cycles": C, "class_cycles_source": "profiles/r04_class_probe.txt (tools/probe/class_probe.cpp, 8 wavefronts per SIMD)",
+            "clock_ghz_assumed": 2.4, "clock_ghz_measured_in_kernel": "2.34-2.41 (round-3 probe build, not this run)",
+            "cycles_per_locus_per_cu": cyc_cu, "simd_cycles_per_locus": budget,
+            "valu_busy_frac": [pipes["valu_low"], pipes["valu_high"]], "salu_busy_frac": pipes["salu"], "lds_busy_frac": pipes["lds"],
+            "floor_ms": sweep_ms * max(pipes["valu_low"], pipes["salu"], pipes["lds"]),
+            "binds": f"no pipe is saturated; the busiest is {busiest[0]} at {busiest[1]:.2f}: eight in-order wavefronts per SIMD alternate "
+                     "between the vector pipe, the CU's one scalar unit and the CU's LDS pipe (a closed queue: time follows the "
+                     "total instruction count of a wavefront)",
+            # kept for comparison with the round-3 lines (every vector instruction priced at 4 cycles, SALU at 1 per cycle per CU)
+            "valu_issue_frac": valu / cyc_cu, "salu_issue_frac": salu / cyc_cu,
+            "source": source}
+
+
 def launch_ranks(a):
     """`bench.py --gpus N` with no launcher around it: this process starts the N ranks (one process per GPU, RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment -- what torch.distributed.run would set), waits for them and
-    relays rank 0's JSON line.  It never initialises a GPU itself (counting devices does not)."""
+    relays rank 0's JSON line.  It only counts devices (torch.cuda.device_count(): hipGetDeviceCount on ROCm) and starts
+    child processes -- it never execs another program and never launches GPU work itself."""
     n = a.gpus
     if not a.host_emulation:
         import torch
@@ -259,10 +307,14 @@ def launch_ranks(a):
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = []
+    import tempfile
+    rank0_out = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout goes to a temporary FILE, read at the end: a pipe read only after every rank has exited would
+        # block rank 0 as soon as it (or a library under it) wrote more than the pipe holds
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+                                      stdout=rank0_out if r == 0 else sys.stderr))
     deadline = time.time() + a.launch_timeout
     bad = None
     while bad is None and any(p.poll() is None for p in procs):
@@ -289,7 +341,8 @@ def launch_ranks(a):
                 p.kill()
         print(f"bench: rank {bad[0]} failed ({bad[1]}); the job was stopped", file=sys.stderr)
         return 1
-    out = procs[0].stdout.read()
+    rank0_out.seek(0)
+    out = rank0_out.read()
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     if not lines:
         print("bench: rank 0 printed no result line", file=sys.stderr)
@@ -514,18 +567,7 @@ def main():
                     traffic = tj["hbm_bytes_per_launch"]
                     traffic_src = "profiles/traffic_k_sweep.json (%s)" % tj.get("build", "committed rocprofv3 --pmc passes, not this run")
                     if tj.get("valu_per_wave") and sweep_ms > 0:
-                        # issue roofline: a CU issues at most one VALU and one SALU wave-instruction per cycle (4 SIMDs x
-                        # 16 lanes: a wave64 instruction holds its SIMD for 4 cycles); cycles a CU has per locus at the
-                        # nominal 2.4 GHz -- which is what the kernel runs at (2.34-2.41 GHz: shader-clock over real-time
-                        # counter read inside k_sweep by a probe build)
-                        cyc = sweep_ms * 1e-3 * 2.4e9 / (L_local / 256.0)
-                        issue = {"valu_per_wave": tj["valu_per_wave"], "salu_per_wave": tj["salu_per_wave"],
-                                 "lds_per_wave": tj.get("lds_per_wave"), "clock_ghz_assumed": 2.4,
-                                 "clock_ghz_measured_in_kernel": "2.34-2.41 (round-3 probe build, not this run)",
-                                 "cycles_per_locus_per_cu": cyc, "valu_issue_frac": tj["valu_per_wave"] / cyc,
-                                 "salu_issue_frac": tj["salu_per_wave"] / cyc,
-                                 "floor_ms": max(tj["valu_per_wave"], tj["salu_per_wave"]) * (L_local / 256.0) / 2.4e9 * 1e3,
-                                 "source": traffic_src}
+                        issue = issue_roofline(tj, sweep_ms, L_local, traffic_src)
                 elif tj.get("loci") == L_local:
                     traffic_src = (f"none: profiles/traffic_k_sweep.json was measured with build {tj.get('build_id')}, "
                                    f"the loaded library is {build_id}")
@@ -567,6 +609,7 @@ def main():
                        "decisions": "device-resident (k_global)" if hs1["resident"] else "host",
                        "kernel_launches_per_iteration": (hs1["launches"] - hs0["launches"]) / a.steps,
                        "library_build_id": build_id,
+                       "compiler": lib.gph_build_compiler().decode(), "runtime": lib.gph_runtime_version().decode(),
                        "parallelism": f"loci sharded over {world} rank(s), one process per GPU"
                                       + (f", native {comm_kind} exchange of the reduced row" + (" on the engine's stream" if hs1["resident"] else "") if comm else
                                          (", torch.distributed hook" + (" (fallback: the RCCL communicator could not be created)" if comm_fallback else "") if dist else ""))},

@@ -120,35 +120,53 @@ def hipcc_version():
 
 def _build_locked(verbose):
     ver = hipcc_version()
-    if HIPCC_VALIDATED not in ver:
+    if ver and HIPCC_VALIDATED not in ver:
         print(f"gphocs_amd.build: hipcc is '{ver}', the backend switches {HIPCC_TUNING[1::2]} were validated with "
               f"'{HIPCC_VALIDATED}': run the -m gpu parity suite (it compares the tuned build with the plain one)")
     srcs = [os.path.join(CSRC, f) for f in LIB_SOURCES]
     import hashlib
+    hashed = sorted(set(LIB_SOURCES) | {f for f in os.listdir(CSRC) if f.endswith(".h")})
+
     def build_id(flags):
+        """sources + flags: what the binary is a function of besides the compiler.  The compiler's version is recorded next
+        to it (sidecar, bench line) and NOT hashed: a library that travelled to a box with another hipcc -- or none -- is
+        still the build of these sources, and recompiling it there would put an unvalidated compiler's code (and minutes
+        of build time) inside a measurement.  Only the translation units and headers count: an editor's backup file in
+        csrc/ does not make the libraries stale."""
         h = hashlib.sha256()
-        for f in sorted(os.listdir(CSRC)):
+        for f in hashed:
             h.update(f.encode() + b"\0" + open(os.path.join(CSRC, f), "rb").read())
-        h.update(" ".join(flags).encode() + ver.encode())
+        h.update(" ".join(flags).encode())
         return h.hexdigest()[:12]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
         [os.path.join(REPO, "include", "gphocs_hip.h")]
     hdr = hashlib.sha256(open(deps[-1], "rb").read()).hexdigest()[:8]
 
     def library(out, tag, fl):
-        """up to date = built from exactly these sources with these flags by this compiler: the id the library was built
-        with sits in a sidecar file next to it (time stamps do not survive checkouts and snapshot copies reliably, and a
-        rebuild on the GPU box costs minutes of the measurement budget)"""
+        """up to date = built from exactly these sources with these flags: the id the library was built with sits in a
+        sidecar file next to it (time stamps do not survive checkouts and snapshot copies reliably, and a rebuild on the
+        GPU box costs minutes of the measurement budget); the sidecar's third field is the compiler that built it"""
         want = f"{tag}-{build_id(fl)}"
         side = out + ".buildid"
         try:
-            if os.path.exists(out) and open(side).read().strip() == f"{want}:{hdr}":
-                return
+            if os.path.exists(out):
+                got = open(side).read().strip().split(":", 2)
+                if got[:2] == [want, hdr]:
+                    built_by = got[2] if len(got) > 2 else ""
+                    if ver and built_by and built_by != ver and verbose:
+                        print(f"gphocs_amd.build: {os.path.basename(out)} was built by '{built_by}', this box has '{ver}': kept")
+                    return
         except OSError:
             pass
+        if not ver:
+            if os.path.exists(out):
+                print(f"gphocs_amd.build: no hipcc here; using the existing {os.path.basename(out)} although its build id "
+                      f"cannot be confirmed as {want}")
+                return
+            raise RuntimeError(f"gphocs_amd.build: hipcc not found and {out} does not exist")
         _run_to(["hipcc"] + fl + [f'-DGPH_BUILD_ID="{want}"'] + srcs + HIPCC_LIBS, out, verbose)
         with open(side, "w") as f:
-            f.write(f"{want}:{hdr}\n")
+            f.write(f"{want}:{hdr}:{ver}\n")
 
     for name, (cl, ck, cb, waves, fn) in VARIANTS.items():
         library(os.path.join(_HERE, fn), name,
@@ -237,7 +255,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_comm_unique_id", "gph_comm_create_rccl", "gph_comm_create_shm", "gph_comm_attach_shm", "gph_comm_shm_bytes",
     "gph_comm_destroy", "gph_comm_world", "gph_comm_rank", "gph_comm_on_stream", "gph_comm_kind",
     "gph_comm_allgather_stream", "gph_comm_allreduce_host", "gph_run_control_file_comm", "gph_device_count",
-    "gph_engine_unit", "gph_build_id", "gph_comm_local_group", "gph_comm_create_local",
+    "gph_engine_unit", "gph_build_id", "gph_build_compiler", "gph_runtime_version", "gph_comm_local_group", "gph_comm_create_local",
     "gph_mcmc_get_chain", "gph_mcmc_set_chain", "gph_mcmc_update_gb", "gph_mcmc_update_locus_rate", "gph_mcmc_update_theta",
     "gph_mcmc_update_mig_rates", "gph_mcmc_update_tau", "gph_mcmc_update_sample_age", "gph_mcmc_mixing",
     "gph_mcmc_synchronize_events", "gph_mcmc_check_all", "gph_mcmc_initialize_genealogies",
@@ -322,6 +340,8 @@ def _load_library(path):
     lib.gph_engine_unit.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]
     lib.gph_run_control_file_comm.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.gph_build_id.restype = C.c_char_p
+    lib.gph_build_compiler.restype = C.c_char_p
+    lib.gph_runtime_version.restype = C.c_char_p
     lib.gph_comm_local_group.argtypes = [C.c_int32, C.c_int32]
     lib.gph_comm_local_group.restype = C.c_void_p
     lib.gph_comm_create_local.argtypes = [C.c_void_p, C.c_int32]

@@ -255,7 +255,18 @@ static int group_barrier(gph_comm_group *g)
     g->failed = true;
     g->cv.notify_all();
   }
-  return g->failed ? 1 : 0;
+  /* the barrier this rank waited at COMPLETED when the generation moved on: a peer that left right after it (gph_comm_destroy
+   * marks the group failed to release stragglers) must not turn a finished collective into an error */
+  return g->gen != my ? 0 : 1;
+}
+// a rank that cannot go on (a HIP call failed between the two barriers) releases the others instead of letting them wait out
+// the time limit
+static int group_fail(gph_comm_group *g)
+{
+  std::lock_guard<std::mutex> lk(g->m);
+  g->failed = true;
+  g->cv.notify_all();
+  return 1;
 }
 
 gph_comm_group *gph_comm_local_group(int32_t world, int32_t device)
@@ -335,17 +346,17 @@ int gph_comm_allgather_stream(gph_comm *c, const double *d_in, double *d_out, in
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = sizeof(double) * (size_t)count;
     g->src[c->rank] = d_in;
-    if (hipEventRecord(g->ready[c->rank], st) != hipSuccess) return 1;
+    if (hipEventRecord(g->ready[c->rank], st) != hipSuccess) return group_fail(g);
     if (group_barrier(g)) return 1;
     for (int r = 0; r < c->world; r++) {
-      if (r != c->rank && hipStreamWaitEvent(st, g->ready[r], 0) != hipSuccess) return 1;
+      if (r != c->rank && hipStreamWaitEvent(st, g->ready[r], 0) != hipSuccess) return group_fail(g);
       if (d_out + (size_t)r * count != g->src[r] &&
-          hipMemcpyAsync(d_out + (size_t)r * count, g->src[r], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+          hipMemcpyAsync(d_out + (size_t)r * count, g->src[r], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return group_fail(g);
     }
-    if (hipEventRecord(g->done[c->rank], st) != hipSuccess) return 1;
+    if (hipEventRecord(g->done[c->rank], st) != hipSuccess) return group_fail(g);
     if (group_barrier(g)) return 1;
     for (int r = 0; r < c->world; r++)
-      if (r != c->rank && hipStreamWaitEvent(st, g->done[r], 0) != hipSuccess) return 1;
+      if (r != c->rank && hipStreamWaitEvent(st, g->done[r], 0) != hipSuccess) return group_fail(g);
     return 0;
   }
   if (!c || c->kind != 1) return 1;

@@ -362,6 +362,8 @@ struct gph_engine {
   bool sync_pending = false;   // synchronizeEvents of the finished iteration rides at the head of the next sweep kernel
   bool fin_owed = false;       // the commit / revert of the last decided tau / sample-age proposal has not run yet
   bool mix_owed = false;       // the commit of the last decided mixing proposal has not run yet (it rides at the head of the next sweep kernel)
+  bool mirror_current = true;  // the host mirror G_h holds what the device-side stages last wrote (false between a queued stage and pull_G)
+  bool no_fuse = false;        // GPH_NO_FUSE=1 (tests): every finish as a kernel of its own; read once in gph_engine_create
   gph_counters counters = {0, 0, 0.0, 0};
   double last_ms[16] = {0};
   // per kernel class: launches, summed HIP-event ms; evaluations / bytes / nodes live in the chain state
@@ -562,7 +564,9 @@ static int pull_G(gph_engine *e)
   return 0;
 #else
   HIPCHK(hipMemcpyAsync(e->G_h, e->G_d, sizeof(GphGlobal), hipMemcpyDeviceToHost, e->stream));
-  return stream_sync(e);
+  { int rcs = stream_sync(e); if (rcs) return rcs; }
+  e->mirror_current = true;
+  return 0;
 #endif
 }
 #define PUSH_IF_DIRTY(e) do { if ((e)->G_dirty) { int rcp_ = push_G(e); if (rcp_) return rcp_; } } while (0)
@@ -712,6 +716,7 @@ static int run_stage(gph_engine *e, int stage, int arg, int iteration)
     e->pend_sl.arg[e->pend_sl.n] = arg;
     e->pend_sl.n++;
     e->pend_iteration = iteration;
+    e->mirror_current = false;     /* the stage writes the chain state on the device: the mirror is stale until pull_G */
     (void)reads;
     return 0;
   }
@@ -860,6 +865,7 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
   memset(&e->ka, 0, sizeof e->ka);
   fill_math_constants(e->ka);
   if (const char *fh = getenv("GPH_HOST_DECISIONS")) e->force_host = atoi(fh) != 0;
+  if (const char *nf = getenv("GPH_NO_FUSE")) e->no_fuse = atoi(nf) != 0;
 #ifndef GPH_HOSTEMU
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) {
@@ -1130,6 +1136,11 @@ int gph_engine_init_genealogies(gph_engine *e, double *sumGen, double *sumData)
 {
   if (!e || !e->loaded || !e->seeded || !e->model_set) return GPH_ESTATE;
   SETDEV(e);
+  /* the pages are rewritten from scratch: nothing decided on the old chain is owed to them any more (a commit left for the
+   * next sweep kernel would stage in the OLD chain's shadow page over the fresh genealogies) */
+  { int rcf = flush_pending(e); if (rcf) return rcf; }
+  e->mix_owed = e->fin_owed = e->sync_pending = false;
+  if (e->G_h->mix_flag || e->G_h->tau_flag) { e->G_h->mix_flag = 0; e->G_h->tau_flag = 0; e->G_dirty = true; }
   PUSH_IF_DIRTY(e);
   LAUNCH(e, 3, k_init, e->seedz, (const double *)e->d_mutRate, e->init_predraws);
   int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
@@ -1158,7 +1169,12 @@ int gph_engine_genealogy_sweep(gph_engine *e, int32_t flags, double ftCoal, doub
   const double d0 = G.dataLogLikelihood, l0 = G.logLikelihood;
   const int64_t a0 = G.acc[0], a1 = G.acc[1], a2 = G.acc[2], a7 = G.acc[7];
   int with_mix = 0;
-  if (e->mix_owed) { e->mix_owed = false; if (e->G_h->mix_flag) with_mix = 16; }
+  if (e->mix_owed) {
+    /* the owed decision (flag, factor) travels as kernel arguments off the host mirror: it must be what the decision stage wrote */
+    if (!e->mirror_current) { int rcm = finish_sync(e); if (rcm) return rcm; }
+    e->mix_owed = false;
+    if (e->G_h->mix_flag) with_mix = 16;
+  }
   LAUNCH(e, 0, k_sweep, (int)flags | with_sync | with_mix, ftCoal, ftMig, e->G_h->mix_c, e->G_h->mix_lnc);
   int rc = reduce_local(e, 0, GPH_OUT_SLOTS);
   if (!rc) rc = reduce_stats(e);
@@ -1268,8 +1284,17 @@ int gph_engine_mixing_commit(gph_engine *e, double c, double lnc)
 // the evaluated state only ever lived in the shadow pages -- nothing to do.
 int gph_engine_mixing_revert(gph_engine *e) { return e ? 0 : GPH_EARG; }
 
+static int finish_owed(gph_engine *e);
+// every finish that has been left for a later kernel, now (the caller is about to edit the main pages by other means)
+static int owed_finishes(gph_engine *e)
+{
+  int rc = finish_owed(e);
+  if (!rc) rc = mix_finish_owed(e);
+  return rc;
+}
 static int apply_list(gph_engine *e)
 {
+  { int rco = owed_finishes(e); if (rco) return rco; }
 #ifdef GPH_HOSTEMU
   for (int64_t g = 0; g < e->L; g++) apply_list_locus(e->dev.pages + (size_t)g * e->lay.page_bytes, e->lay, e->G_h->apply, e->G_h->napply);
 #else
@@ -1286,6 +1311,7 @@ int gph_engine_apply_theta(gph_engine *e, int32_t pop, double lnc, double thetao
 {
   if (!e || !e->initialized || pop < 0 || pop >= e->cfg.K) return GPH_EARG;
   SETDEV(e);
+  { int rco = owed_finishes(e); if (rco) return rco; }    /* the touch-up edits the MAIN page: a commit that still sits in the shadow page goes first */
   GphGlobal &G = *e->G_h;
   G.napply = 1;
   G.apply[0].kind = 0; G.apply[0].idx = pop; G.apply[0].lnc = lnc; G.apply[0].diff = (1 / thetanew - 1 / thetaold);
@@ -1298,6 +1324,7 @@ int gph_engine_apply_migrate(gph_engine *e, int32_t band, double lnc, double old
 {
   if (!e || !e->initialized || band < 0 || band >= e->cfg.B) return GPH_EARG;
   SETDEV(e);
+  { int rco = owed_finishes(e); if (rco) return rco; }    /* the touch-up edits the MAIN page: a commit that still sits in the shadow page goes first */
   GphGlobal &G = *e->G_h;
   G.napply = 1;
   G.apply[0].kind = 1; G.apply[0].idx = band; G.apply[0].lnc = lnc; G.apply[0].diff = (new_rate - old_rate);
@@ -1458,6 +1485,27 @@ int gph_debug_math(const double *x, const double *y, int32_t n, double *out, int
 #define GPH_BUILD_ID "unidentified"
 #endif
 const char *gph_build_id(void) { return GPH_BUILD_ID; }
+const char *gph_build_compiler(void)
+{
+#ifdef __clang_version__
+  return "clang " __clang_version__;
+#else
+  return "g++ " __VERSION__;
+#endif
+}
+const char *gph_runtime_version(void)
+{
+  static char buf[96];
+#ifdef GPH_HOSTEMU
+  snprintf(buf, sizeof buf, "host emulation (no HIP runtime)");
+#else
+  int rt = 0, dr = 0;
+  if (hipRuntimeGetVersion(&rt) != hipSuccess) rt = -1;
+  if (hipDriverGetVersion(&dr) != hipSuccess) dr = -1;
+  snprintf(buf, sizeof buf, "HIP runtime %d, driver %d", rt, dr);
+#endif
+  return buf;
+}
 
 int gph_engine_hbm_bytes(gph_engine *e, double *bytes)
 {
@@ -1686,7 +1734,11 @@ static int part_sweep(gph_engine *e, int32_t iteration, double ftCoal, double ft
   /* a mixing commit left over from the previous iteration: the host mirror of the chain state is current here (the
    * previous iteration ended with a synchronisation), so the flag and the factor travel as kernel arguments */
   int with_mix = 0;
-  if (e->mix_owed) { e->mix_owed = false; if (e->G_h->mix_flag) with_mix = 16; }
+  if (e->mix_owed) {
+    if (!e->mirror_current) { int rcm = finish_sync(e); if (rcm) return rcm; }
+    e->mix_owed = false;
+    if (e->G_h->mix_flag) with_mix = 16;
+  }
   LAUNCH(e, 0, k_sweep, 7 | with_sync | with_mix, ftCoal, ftMig, e->G_h->mix_c, e->G_h->mix_lnc);
   if ((rc = reduce_local(e, 0, GPH_OUT_SLOTS))) return rc;
   if ((rc = reduce_stats(e))) return rc;
@@ -1712,7 +1764,7 @@ static int part_tau(gph_engine *e, int32_t iteration, bool first_proposed)
   int rc;
   const GphGlobal &Gh = *e->G_h;
   const int K = Gh.K, Kc = Gh.Kc;
-  const bool no_fuse = getenv("GPH_NO_FUSE") && atoi(getenv("GPH_NO_FUSE")) != 0;
+  const bool no_fuse = e->no_fuse;
   for (int ap = Kc; ap < K; ++ap) {
     if ((ap > Kc || !first_proposed) && (rc = run_stage(e, GS_TAU_PROPOSE, ap, iteration))) return rc;
     if (no_fuse && (rc = finish_owed(e))) return rc;
@@ -1727,7 +1779,7 @@ static int part_sage(gph_engine *e, int32_t iteration)
 {
   int rc;
   const GphGlobal &Gh = *e->G_h;
-  const bool no_fuse = getenv("GPH_NO_FUSE") && atoi(getenv("GPH_NO_FUSE")) != 0;
+  const bool no_fuse = e->no_fuse;
   for (int pop = 0; pop < Gh.Kc; ++pop) {
     if (!Gh.updateSampleAge[pop]) continue;
     if ((rc = run_stage(e, GS_SAGE_PROPOSE, pop, iteration))) return rc;
@@ -1743,7 +1795,7 @@ static int part_mix(gph_engine *e, int32_t iteration)
 {
   int rc;
   const GphGlobal &Gh = *e->G_h;
-  const bool no_fuse = getenv("GPH_NO_FUSE") && atoi(getenv("GPH_NO_FUSE")) != 0;
+  const bool no_fuse = e->no_fuse;
   if ((rc = run_stage(e, GS_MIX_PROPOSE, 0, iteration))) return rc;
   if (Gh.ftMixing > 0.0) {
     if (no_fuse && (rc = finish_owed(e))) return rc;

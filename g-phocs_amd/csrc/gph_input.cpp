@@ -1049,18 +1049,23 @@ int gph_loci_read(const gph_control *c, const char *seq_path, int32_t threads, g
     Lc->unphased[g] = outs[g].unphased;
     Lc->names[g] = raw[g].name;
   }
-  // ---- readRateFile, GPhoCS.c:491-579 (locus-mut-rate FIXED): normalised to mean 1
+  // ---- readRateFile, GPhoCS.c:491-579 (locus-mut-rate FIXED): normalised to mean 1.  The message bodies are upstream's
+  // ("Error: " + body on stderr there, followed by "Error: Unable to reading rate file '<name>'. Aborting !!", GPhoCS.c:1149-1154)
   Lc->mutRates.assign((size_t)numLoci, 1.0);
   if (c->mutRateMode == 2) {
+    char m[192];
     FILE *f = fopen(c->rateFile.c_str(), "r");
-    if (!f) { set_err(err, errlen, "Could not find/read rate file " + c->rateFile); delete Lc; return GPH_EARG; }
+    if (!f) { set_err(err, errlen, "Could not find/read rate file " + c->rateFile + "."); delete Lc; return GPH_EARG; }
     double sum = 0.0, tmp;
     for (int g = 0; g < numLoci; g++) {
-      if (fscanf(f, "%lf", &Lc->mutRates[g]) != 1) { char m[96]; snprintf(m, sizeof m, "Cannot read rate for locus %d", g + 1); set_err(err, errlen, m); fclose(f); delete Lc; return GPH_EARG; }
+      if (fscanf(f, "%lf", &Lc->mutRates[g]) != 1) { snprintf(m, sizeof m, "Cannot read rate for locus %d.", g + 1); set_err(err, errlen, m); fclose(f); delete Lc; return GPH_EARG; }
       sum += Lc->mutRates[g];
-      if (Lc->mutRates[g] <= 0.0) { char m[96]; snprintf(m, sizeof m, "Locus %d has non-positive (%g) rate", g + 1, Lc->mutRates[g]); set_err(err, errlen, m); fclose(f); delete Lc; return GPH_EARG; }
+      if (Lc->mutRates[g] <= 0.0) { snprintf(m, sizeof m, "Locus %d has non-positive (%g) rate.", g + 1, Lc->mutRates[g]); set_err(err, errlen, m); fclose(f); delete Lc; return GPH_EARG; }
     }
-    if (fscanf(f, "%lf", &tmp) == 1) { set_err(err, errlen, "Rate file contains more loci than the sequence file"); fclose(f); delete Lc; return GPH_EARG; }
+    if (fscanf(f, "%lf", &tmp) == 1) {
+      snprintf(m, sizeof m, "Rate file contains more than the %d loci specified in the sequence file.", numLoci);
+      set_err(err, errlen, m); fclose(f); delete Lc; return GPH_EARG;
+    }
     fclose(f);
     sum /= numLoci;
     for (int g = 0; g < numLoci; g++) Lc->mutRates[g] = Lc->mutRates[g] / sum;

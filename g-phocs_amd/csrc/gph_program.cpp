@@ -70,7 +70,14 @@ static int run_control_file(const char *ctl, const char *ctl2, int32_t device, i
   if (verbose && lead) printf("\nRandom seed set to %d\n", mc.seed);
 
   auto t0 = std::chrono::steady_clock::now();
-  if ((rc = gph_loci_read(C, nullptr, 0, &LC, err, sizeof err))) return fail(rc, "reading the sequence file");
+  if ((rc = gph_loci_read(C, nullptr, 0, &LC, err, sizeof err))) {
+    /* a rejected rate file (locus-mut-rate FIXED): upstream's two lines (readRateFile, GPhoCS.c:491-579, and its caller :1149-1154) */
+    if (info.mutRateMode == 2 && (strstr(err, "rate") || strstr(err, "Rate")) && lead) {
+      fprintf(stderr, "Error: %s\n", err);
+      if (!strstr(err, "Could not find")) fprintf(stderr, "Error: Unable to reading rate file '%s'. Aborting !!\n", info.rateFile);
+    }
+    return fail(rc, "reading the sequence file");
+  }
   int64_t L = 0;
   int32_t n = 0;
   const int64_t *offs; const uint8_t *leaf; const uint16_t *ph; const int32_t *cnt, *unph; const double *rates;
@@ -123,6 +130,7 @@ static int run_control_file(const char *ctl, const char *ctl2, int32_t device, i
   fprintf(trace, "\tData-ld-ln\tFull-ld-ln\n");
 
   if (lead) printf("Starting MCMC: %d burnin, %d running, sampled every %d iteration(s).\n", info.burnin, info.numSamples, info.sampleSkip);
+  if (lead && info.mutRateMode == 2) printf("Reading locus rates from file %s... ", info.rateFile);   /* readRateFile's progress text (GPhoCS.c:514), printed from initializeMCMC upstream */
   int64_t totalCoals = 0;
   if ((rc = gph_mcmc_initialize(M, &totalCoals))) return fail(rc, "gph_mcmc_initialize");
   std::vector<double> vals(mc.numParameters + 4, 0.0);

@@ -204,6 +204,11 @@ int gph_engine_hbm_bytes(gph_engine *e, double *bytes);
 /* identity of this build of the library: hash of its sources and compiler flags (measurement files under profiles/
  * carry it, and bench.py drops a committed counter measurement that was taken with another build) */
 const char *gph_build_id(void);
+/* the compiler that built this library (its __clang_version__) and the HIP runtime / driver it is running on
+ * ("runtime <hipRuntimeGetVersion>, driver <hipDriverGetVersion>"): both go into the bench line -- a library built by one
+ * ROCm release may well run on another */
+const char *gph_build_compiler(void);
+const char *gph_runtime_version(void);
 
 /* ------------------------------------------------------------------------------------
  * host MCMC driver: the iteration body of performMCMC (GPhoCS.c:1476-1821) above the

@@ -127,6 +127,9 @@ static int cmd_pack(char *ctl, char *out)
   int g, p, leaf, c;
   FILE *f;
   startup(ctl);
+  /* locus-mut-rate FIXED: the rates reach the loci in initializeMCMC (GPhoCS.c:1147-1155); the pack carries them as
+   * readRateFile leaves them (normalised to mean 1) */
+  if (mcmcSetup.mutRateMode == 2 && 0 != readRateFile(ioSetup.rateFileName)) { fprintf(stderr, "harness: readRateFile failed\n"); return 2; }
   f = fopen(out, "w");
   if (!f) { perror(out); return 2; }
   write_model(f);

@@ -86,3 +86,21 @@ for c in "m4 60" "a7 40" "g2 20"; do set -- $c; timeout 300 $REF unit $1.ctl $2 
 # 16 migration bands (library variant `h`: two genealogy nodes per lane would not do, the node sets are 128 bits wide)
 gen y9 9 8 300 16 8 --mig-beta 0.00000004
 timeout 900 $REF main -n 1 y9.ctl >/dev/null 2>&1     # y9.trace: the reference's own trace file
+
+# r5: locus-mut-rate FIXED <rate file> (readRateFile, GPhoCS.c:491-579; MCMCcontrol.c:700-712): 16 rates spread over 0.2 .. 5
+# in a mixed layout, normalised to mean 1 by the reference; pack (carries the normalised rates), records, state, the real
+# binary's trace file and stdout.  r5_{few,many,neg,missing}: the same control file with a rate file of 15 / 17 entries, a
+# negative entry, no file -- the real binary's stderr (r5_*.ctl / r5_*.rates are derived from r5 by the lines below)
+gen r5 3 16 300 60 20 --mig-beta 0.00000004 --fixed-rates
+timeout 900 $REF main -n 1 r5.ctl > r5.stdout 2>/dev/null
+python3 - <<'PY'
+r = open('r5.rates').read().split()
+open('r5_few.rates', 'w').write(' '.join(r[:15]) + '\n')
+open('r5_many.rates', 'w').write(' '.join(r + ['1.5']) + '\n')
+rr = list(r); rr[6] = '-0.25'
+open('r5_neg.rates', 'w').write(' '.join(rr) + '\n')
+c = open('r5.ctl').read()
+for k in ('few', 'many', 'neg', 'missing'):
+    open(f'r5_{k}.ctl', 'w').write(c.replace('r5.rates', f'r5_{k}.rates').replace('r5.trace', f'r5_{k}.trace'))
+PY
+for k in few many neg missing; do timeout 60 $REF main -n 1 r5_$k.ctl > /dev/null 2> r5_$k.stderr || true; rm -f r5_$k.trace; done

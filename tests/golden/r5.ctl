@@ -1,0 +1,82 @@
+GENERAL-INFO-START
+
+	seq-file            r5.seq
+	trace-file          r5.trace
+	locus-mut-rate          FIXED r5.rates
+	num-loci            16
+	random-seed         12345
+	mcmc-iterations	  60
+	iterations-per-log  20
+	logs-per-line       10
+
+	find-finetunes		FALSE
+	finetune-coal-time	0.01		
+	finetune-mig-time	0.3		
+	finetune-theta		0.04
+	finetune-mig-rate	0.02
+	finetune-tau		0.0000008
+	finetune-mixing		0.003
+
+	tau-theta-print		10000.0
+	tau-theta-alpha		1.0
+	tau-theta-beta		10000.0
+
+	mig-rate-print		0.001
+	mig-rate-alpha		0.002
+	mig-rate-beta		0.0000000400
+
+GENERAL-INFO-END
+
+CURRENT-POPS-START	
+
+	POP-START
+		name		A
+		samples		s0 d s1 d
+	POP-END
+
+	POP-START
+		name		B
+		samples		s2 d s3 d
+	POP-END
+
+	POP-START
+		name		C
+		samples		s4 d s5 d
+	POP-END
+
+CURRENT-POPS-END
+
+ANCESTRAL-POPS-START
+
+	POP-START
+		name			AB
+		children		A		B
+		tau-initial	0.000005000
+		tau-beta		20000.0	
+		finetune-tau			0.00000080
+	POP-END
+
+	POP-START
+		name			root
+		children		AB		C
+		tau-initial	0.000025000
+		tau-beta		20000.0	
+		finetune-tau			0.00000286
+	POP-END
+
+ANCESTRAL-POPS-END
+
+MIG-BANDS-START	
+	BAND-START		
+       source  A
+       target  B
+       mig-rate-print 0.1
+	BAND-END
+
+	BAND-START		
+       source  C
+       target  B
+       mig-rate-print 0.1
+	BAND-END
+
+MIG-BANDS-END

@@ -69,3 +69,55 @@ def compare_states(path_a, path_b, tol=STATE_TOL, skip_global=False):
         for u, v in zip(xs, ys):
             assert _tok_close(u, v, tol), f"state differs ({u} vs {v}):\n  {x[:300]}\n  {y[:300]}"
     return True
+
+
+def reinit_after_accepted_mixing(G, lib, pack_path, tmp_path, max_iters=200, more=6):
+    """an accepted mixing proposal leaves its commit for the head of the NEXT sweep kernel (the evaluated
+    state waits in the shadow page).  Re-initialising the genealogies in that window must drop the owed commit: the next
+    sweep would otherwise stage the OLD chain's shadow page over the fresh genealogies.  Engine A runs until a mixing
+    proposal has just been accepted and re-initialises; engine B is fresh, takes A's chain state above the loci, and
+    initialises once: per-locus state and records of both must be identical after `more` iterations."""
+    import ctypes as C
+
+    class Chain(C.Structure):
+        _fields_ = [("theta", C.c_double * 40), ("popAge", C.c_double * 40), ("sampleAge", C.c_double * 40),
+                    ("migRate", C.c_double * 100), ("bandStart", C.c_double * 100), ("bandEnd", C.c_double * 100),
+                    ("rng", C.c_uint32 * 3), ("logLikelihood", C.c_double), ("dataLogLikelihood", C.c_double),
+                    ("rateVar", C.c_double), ("coal_stats", C.c_double * 40), ("num_coals", C.c_double * 40),
+                    ("mig_stats", C.c_double * 100), ("num_migs", C.c_double * 100), ("rubberband_mig_conflicts", C.c_int64)]
+    pk = G.Pack.load(pack_path)
+    a = G.Sampler(pk, lib=lib)
+    a.initialize()
+    it, got = 0, False
+    while it < max_iters:
+        before = a.accept_counts()[6]
+        a.iteration(it)
+        it += 1
+        if a.accept_counts()[6] > before and (it + 1) % int(pk.samplesPerLog) != 0 and it != int(pk.startMig):
+            got = True
+            break
+    assert got, "no accepted mixing proposal within the iteration budget"
+    ch = Chain()
+    assert lib.gph_mcmc_get_chain(a.mcmc, C.byref(ch)) == 0
+    b = G.Sampler(pk, lib=lib)
+    b.initialize()
+    assert lib.gph_mcmc_set_chain(b.mcmc, C.byref(ch)) == 0
+    assert lib.gph_mcmc_set_chain(a.mcmc, C.byref(ch)) == 0
+    ta, tb = str(tmp_path / "a.trace"), str(tmp_path / "b.trace")
+    a.set_record_file(ta)
+    b.set_record_file(tb)
+    assert lib.gph_mcmc_initialize_genealogies(a.mcmc) == 0
+    assert lib.gph_mcmc_initialize_genealogies(b.mcmc) == 0
+    for k in range(more):
+        a.iteration(it + k)
+        b.iteration(it + k)
+    sa, sb = str(tmp_path / "a.state"), str(tmp_path / "b.state")
+    a.dump_state(sa, True)
+    b.dump_state(sb, True)
+    a.set_record_file(None)
+    b.set_record_file(None)
+    a.close()
+    b.close()
+    assert open(sa, "rb").read() == open(sb, "rb").read(), "per-locus state differs after re-initialisation"
+    ra, rb = open(ta).read(), open(tb).read()
+    assert ra == rb and len(ra.splitlines()) > more, "records differ after re-initialisation"

@@ -21,7 +21,7 @@ import pytest
 
 from conftest import GOLDEN, ORACLE_DIR, REPO
 
-CASES = ["g1", "m3", "a7", "f3", "v8", "w2", "x8"]   # (y9 needs the big-tree build of the engine sources: tests/test_host_logic.py, -m gpu)
+CASES = ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "r5"]   # (y9 needs the big-tree build of the engine sources: tests/test_host_logic.py, -m gpu)
 
 
 def _build():
@@ -35,7 +35,7 @@ def _build():
 
 def _run(exe, name, tmp_path):
     for f in os.listdir(GOLDEN):
-        if f.startswith(name) and f.endswith((".ctl", ".seq")):
+        if f.startswith(name + ".") and f.endswith((".ctl", ".seq", ".rates")) or f == name + "b.ctl":
             shutil.copy(os.path.join(GOLDEN, f), tmp_path)
     args = [exe, name + ".ctl"] + ([name + "b.ctl"] if os.path.exists(os.path.join(GOLDEN, name + "b.ctl")) else [])
     r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=900)
@@ -58,7 +58,7 @@ def test_reference_performMCMC_over_the_engine(tmp_path, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "r5"])
 def test_reference_performMCMC_over_the_engine_on_the_gpu(tmp_path, name):
     exe = os.path.join(ORACLE_DIR, "_ref", "gphocs_boundary_hip")
     if not os.path.exists(exe):

@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
 import gphocs_amd as G  # noqa: E402
 import run_hostemu as R  # noqa: E402
 
-CASES = ["g1", "g2", "m3", "m4", "c5", "s3", "a6", "a7", "z0", "stress", "v8", "v9", "y9"]
+CASES = ["g1", "g2", "m3", "m4", "c5", "s3", "a6", "a7", "z0", "stress", "v8", "v9", "y9", "r5"]
 
 
 @pytest.fixture(scope="module")
@@ -78,13 +78,14 @@ def test_thread_count_does_not_change_the_result(lib):
         assert np.array_equal(getattr(a, f), getattr(b, f))
 
 
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "r5"])
 def test_program_writes_the_reference_trace_file(lib, name, tmp_path):
     """same control file + sequence file -> the trace file of the real G-PhoCS binary, byte for byte
     (f3: find-finetunes TRUE -- the step-size search of performMCMC, GPhoCS.c:1896-2180, incl. its acceptance
     bookkeeping quirks, must take the same decisions for the chain to stay on the reference's trajectory)"""
-    for ext in (".ctl", ".seq"):
-        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    for ext in (".ctl", ".seq", ".rates"):
+        if os.path.exists(os.path.join(GOLDEN, name + ext)):
+            shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
     ctl2 = SECONDARY.get(name)
     if ctl2:
         shutil.copy(os.path.join(GOLDEN, ctl2), tmp_path)
@@ -218,7 +219,7 @@ def test_read_trace_partial_tail_and_errors(lib, tmp_path):
     assert rc == 0 and got.split("\n")[1].split() == ["2.000000", "3.500000"]
 
 
-@pytest.mark.parametrize("name", ["g1", "f3", "v8", "a7", "w2"])
+@pytest.mark.parametrize("name", ["g1", "f3", "v8", "a7", "w2", "r5"])
 def test_program_prints_the_reference_log(name, tmp_path):
     """stdout of gph_run_control_file against the real binary's stdout for the same control file (tests/golden/*.stdout):
     from "Reading control settings" on (i.e. everything but the version banner and the thread-count line) -- title, one `\\r`-refreshed line per log period with the acceptance percentages exactly as
@@ -227,8 +228,9 @@ def test_program_prints_the_reference_log(name, tmp_path):
     ever written (GPhoCS.c:1620-1628), that one number is skipped."""
     import re
     import subprocess
-    for ext in (".ctl", ".seq"):
-        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    for ext in (".ctl", ".seq", ".rates"):
+        if os.path.exists(os.path.join(GOLDEN, name + ext)):
+            shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
     ctl2 = SECONDARY.get(name)
     if ctl2:
         shutil.copy(os.path.join(GOLDEN, ctl2), tmp_path)
@@ -307,3 +309,35 @@ def test_reference_sample_control_file_end_to_end(lib, ref_cli, tmp_path):
         if a != b:
             af, bf = [float(x) for x in a.split()], [float(x) for x in b.split()]
             assert all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(af, bf)), (a, b)
+
+
+@pytest.mark.parametrize("kind", ["few", "many", "neg", "missing"])
+def test_rate_file_errors_carry_the_reference_text(lib, kind, tmp_path):
+    """locus-mut-rate FIXED <file> with too few / too many / a non-positive entry / no file: the message bodies of
+    readRateFile (GPhoCS.c:491-579) and of its caller (:1149-1154) -- tests/golden/r5_<kind>.stderr is the stderr of the
+    real binary run on the same control file."""
+    import ctypes as C
+    import subprocess
+    for f in ("r5_%s.ctl" % kind, "r5_%s.rates" % kind, "r5.seq"):
+        if os.path.exists(os.path.join(GOLDEN, f)):
+            shutil.copy(os.path.join(GOLDEN, f), tmp_path)
+    want = [ln for ln in open(os.path.join(GOLDEN, "r5_%s.stderr" % kind)).read().splitlines() if ln.strip()]
+    # through the C ABI: the body of the first line
+    err = C.create_string_buffer(512)
+    ctl, loci = C.c_void_p(), C.c_void_p()
+    with _in_dir(tmp_path):
+        assert lib.gph_control_read(("r5_%s.ctl" % kind).encode(), None, C.byref(ctl)) == 0
+        rc = lib.gph_loci_read(ctl, None, 1, C.byref(loci), err, 512)
+    assert rc != 0 and "Error: " + err.value.decode() == want[0]
+    lib.gph_control_free(ctl)
+    # through the program: the same lines on stderr (next to the program's own status line)
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import gphocs_amd as G, run_hostemu as R\n"
+            "lib = G.load_library(R.build_hostemu())\n"
+            "lib.gph_run_control_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]\n"
+            "sys.exit(1 if lib.gph_run_control_file(%r, None, 0, 0) else 0)\n") % (REPO, os.path.join(REPO, "tests", "hostemu"),
+                                                                                 ("r5_%s.ctl" % kind).encode())
+    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1
+    got = [ln for ln in r.stderr.splitlines() if ln.startswith("Error: ")]
+    assert got == want, (got, want)

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, "a7": 100, "z0": 12, "v8": 60, "v9": 60,
          "w2": 50,   # w2: model from a primary + a secondary control file
+         "r5": 60,   # r5: locus-mut-rate FIXED <rate file> (readRateFile, GPhoCS.c:491-579): per-locus rates 0.2 .. 5 before normalisation
          "x8": 24,   # x8: 32 leaves, 31 populations, 16 bands: the largest lane-per-node build (library variant x)
          "y9": 16}   # y9: 40 leaves, 39 populations (the reference's NSPECIES cap), 16 bands: library variant h
 
@@ -325,7 +326,7 @@ def test_native_library_is_the_path(G):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "y9"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "y9", "r5"])
 def test_program_trace_file(name, tmp_path):
     """G-PhoCS-hip <control-file> on the MI355X: the trace file of the real G-PhoCS binary for the same
     control + sequence files (tests/golden/*.trace), to the printed precision (%8.5f / %.6f)."""
@@ -333,8 +334,9 @@ def test_program_trace_file(name, tmp_path):
     import subprocess
     exe = os.path.join(REPO, "g-phocs_amd", "G-PhoCS-hip")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
-    for ext in (".ctl", ".seq"):
-        shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
+    for ext in (".ctl", ".seq", ".rates"):
+        if os.path.exists(os.path.join(GOLDEN, name + ext)):
+            shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
     extra = []
     if name == "w2":     # primary + secondary control file (GPhoCS.c:35-43, MCMCcontrol.c:178-210)
         shutil.copy(os.path.join(GOLDEN, "w2b.ctl"), tmp_path)

@@ -25,7 +25,7 @@ def hostemu():
     return R, G.load_library(R.build_hostemu())
 
 
-@pytest.mark.parametrize("name,iters", [("g1", 30), ("g2", 30), ("m3", 120), ("m4", 60), ("c5", 30), ("s3", 40), ("a6", 80), ("a7", 100), ("z0", 12), ("v8", 60), ("v9", 60), ("w2", 50), ("x8", 24)])
+@pytest.mark.parametrize("name,iters", [("g1", 30), ("g2", 30), ("m3", 120), ("m4", 60), ("c5", 30), ("s3", 40), ("a6", 80), ("a7", 100), ("z0", 12), ("v8", 60), ("v9", 60), ("w2", 50), ("x8", 24), ("r5", 60)])
 def test_hostemu_matches_reference_goldens(hostemu, name, iters, tmp_path):
     R, lib = hostemu
     tr, st = tmp_path / "t", tmp_path / "s"
@@ -157,3 +157,11 @@ def test_kernel_level_fixtures_hostemu(hostemu, name):
     import unit_fixture
     _, lib = hostemu
     assert unit_fixture.check_unit(G, lib, GOLDEN, name) > 100
+
+
+def test_reinitialise_drops_an_owed_mixing_commit(hostemu, tmp_path):
+    """ADVICE round 3 (gph_engine_init_genealogies left mix_owed / fin_owed / sync_pending set)"""
+    from parity_util import reinit_after_accepted_mixing
+    import gphocs_amd as G
+    R, lib = hostemu
+    reinit_after_accepted_mixing(G, lib, os.path.join(GOLDEN, "m3.gpk"), tmp_path)

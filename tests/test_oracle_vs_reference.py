@@ -14,6 +14,7 @@ from conftest import GOLDEN
 CASES = {  # name: iterations (must match make_goldens.sh)
     "g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, "a7": 100, "z0": 12, "v8": 60, "v9": 60,
     "w2": 50,   # model read from a primary + a secondary control file
+    "r5": 60,   # locus-mut-rate FIXED r5.rates: per-locus rates spread over 0.2 .. 5 (readRateFile, GPhoCS.c:491-579)
     "x8": 24,   # 32 leaves, 31 populations, 16 bands
     "y9": 16,   # 40 leaves, 39 populations (the reference's NSPECIES cap), 16 bands
 }

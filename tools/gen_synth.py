@@ -63,14 +63,15 @@ def build_tree(cfg):
 
 
 def write_ctl(path, cfg, seqfile, tracefile, loci, seed, iters, samples_per_log, no_mixing=False,
-              start_mig=0, mig_beta=0.00001, var_rates=None):
+              start_mig=0, mig_beta=0.00001, var_rates=None, fixed_rates=None):
     cur, anc, taus = build_tree(cfg)
     kc = len(cur)
     out = []
     out.append("GENERAL-INFO-START\n")
     out.append(f"\tseq-file            {seqfile}")
     out.append(f"\ttrace-file          {tracefile}")
-    out.append("\tlocus-mut-rate          " + ("CONST" if var_rates is None else f"VAR {var_rates[0]}"))
+    out.append("\tlocus-mut-rate          " + (f"FIXED {fixed_rates}" if fixed_rates else
+                                            "CONST" if var_rates is None else f"VAR {var_rates[0]}"))
     out.append(f"\tnum-loci            {loci}")
     out.append(f"\trandom-seed         {seed}")
     out.append(f"\tmcmc-iterations\t  {iters}")
@@ -235,6 +236,9 @@ def main():
                     help="scale branch lengths when dropping mutations (more patterns)")
     ap.add_argument("--var-rates", type=float, nargs=2, default=None, metavar=("ALPHA", "FINETUNE"),
                     help="locus-mut-rate VAR <ALPHA> with finetune-locus-rate <FINETUNE> (UpdateLocusRate is live)")
+    ap.add_argument("--fixed-rates", action="store_true",
+                    help="locus-mut-rate FIXED <out>.rates: a rate file with one rate per locus, spread over 0.2 .. 5 "
+                         "(readRateFile, GPhoCS.c:491-579, normalises them to mean 1)")
     ap.add_argument("--out", required=True, help="output prefix: <out>.ctl, <out>.seq")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -245,7 +249,15 @@ def main():
     seqfile = os.path.basename(a.out) + ".seq"
     write_ctl(a.out + ".ctl", cfg, seqfile, os.path.basename(a.out) + ".trace", L, a.mcmc_seed,
               a.iters, a.per_log, no_mixing=a.no_mixing, start_mig=a.start_mig, mig_beta=a.mig_beta,
-              var_rates=a.var_rates)
+              var_rates=a.var_rates, fixed_rates=os.path.basename(a.out) + ".rates" if a.fixed_rates else None)
+    if a.fixed_rates:
+        # log-uniform over 0.2 .. 5, mixed layout (several per line, tabs, an exponent form): the reader is fscanf("%lf")
+        rr = np.exp(np.random.default_rng(77 + a.config).uniform(np.log(0.2), np.log(5.0), L))
+        with open(a.out + ".rates", "w") as f:
+            for g in range(L):
+                f.write(("%.6e" % rr[g]) if g % 5 == 3 else ("%.5f" % rr[g]))
+                f.write("\n" if g % 4 == 3 else "\t" if g % 2 else " ")
+            f.write("\n")
     nd = sum(cfg["pops"])
     with open(a.out + ".seq", "w") as f:
         f.write(f"{L}\n\n")

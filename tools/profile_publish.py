@@ -9,7 +9,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 d = json.load(open(f"gpurun_out/pmc_{tag}.json"))
 k = [x for x in d if "k_sweep" in x][0]
 s = d[k]
@@ -27,6 +27,10 @@ json.dump({"kernel": "k_sweep", "loci": 100000, "hbm_bytes_per_launch": fetch + 
            "valu_per_wave": s["SQ_INSTS_VALU"]["sum"] / n, "salu_per_wave": s["SQ_INSTS_SALU"]["sum"] / n,
            "lds_per_wave": s["SQ_INSTS_LDS"]["sum"] / n, "smem_per_wave": s["SQ_INSTS_SMEM"]["sum"] / n,
            "wave_cycles_per_wave": s["SQ_WAVE_CYCLES"]["sum"] / n,
+           "valu_mix_per_wave": ({kk: s["SQ_INSTS_VALU_" + kk.upper()]["sum"] / n for kk in
+                                  ("add_f64", "mul_f64", "fma_f64", "trans_f64", "int32", "int64", "cvt")}
+                                 if "SQ_INSTS_VALU_ADD_F64" in s and "SQ_INSTS_VALU_INT32" in s else None),
+           "branches_per_wave": s["SQ_INSTS_BRANCH"]["sum"] / n if "SQ_INSTS_BRANCH" in s else None,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_collect.sh): "
                      "FETCH_SIZE(KB)*1024*2 (gfx950 correction) + WRITE_SIZE(KB)*1024 per k_sweep dispatch (one "
                      f"dispatch per sweep), averaged over the {nd} dispatches of a 200-iteration pre-roll + 4 iterations"},
@@ -36,15 +40,11 @@ shutil.copy(f"gpurun_out/kstats_{tag}/k_kernel_stats.csv", f"profiles/{rnd}_benc
 b["roofline"]["traffic"] = fetch + write
 b["roofline"]["traffic_source"] = f"profiles/traffic_k_sweep.json ({rnd} {tag}: rocprofv3 --pmc passes of the same command on the same box)"
 b["roofline"]["hbm_counter_frac"] = (fetch + write) / (b["roofline"]["avg_launch_ms"] * 1e-3) / 8e12
-if not b["roofline"].get("issue"):
-    # the bench ran before this file existed for its build: the same arithmetic as bench.py
-    valu, salu = s["SQ_INSTS_VALU"]["sum"] / n, s["SQ_INSTS_SALU"]["sum"] / n
-    cyc = b["roofline"]["avg_launch_ms"] * 1e-3 * 2.4e9 / (100000 / 256.0)
-    b["roofline"]["issue"] = {"valu_per_wave": valu, "salu_per_wave": salu, "lds_per_wave": s["SQ_INSTS_LDS"]["sum"] / n,
-                              "clock_ghz_assumed": 2.4, "clock_ghz_measured_in_kernel": "2.34-2.41 (round-3 probe build, not this run)",
-                              "cycles_per_locus_per_cu": cyc, "valu_issue_frac": valu / cyc, "salu_issue_frac": salu / cyc,
-                              "floor_ms": max(valu, salu) * (100000 / 256.0) / 2.4e9 * 1e3,
-                              "source": b["roofline"]["traffic_source"]}
+# the bench ran before this file existed for its build: the same arithmetic as bench.py
+sys.path.insert(0, ".")
+import bench as _bench
+b["roofline"]["issue"] = _bench.issue_roofline(json.load(open("profiles/traffic_k_sweep.json")), b["roofline"]["avg_launch_ms"], 100000,
+                                               b["roofline"]["traffic_source"])
 json.dump(b, open(f"profiles/{rnd}_bench_{tag}.json", "w"), indent=1)
 try:
     shutil.copy(f"gpurun_out/bench_{tag}_12500.json", f"profiles/{rnd}_bench_{tag}_12500loci.json")
