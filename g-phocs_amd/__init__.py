@@ -24,12 +24,12 @@ CSRC = os.path.join(_HERE, "csrc")
 # -disable-machine-licm: the machine-level loop-invariant code motion hoists constants (a 64-bit 0.0, 1e-6) and
 # lane-derived masks out of the proposal loops of the sweep kernel into registers it then has to spill to scratch
 # memory -- and reload, hundreds of cycles each, ~10 times per proposal.  Without it the sweep kernel has no vector
-# spills at 80 VGPRs (25 before) and 23 instead of 47 scalar spills: -5.4 % sweep time.
+# spills at 80 VGPRs (25 before) and 23 instead of 47 scalar spills: -5.4 % sweep time (profiles/HISTORY.md, round 1, v16).
 # -structurizecfg-skip-uniform-regions: the backend's CFG structurizer runs on EVERY region by default, also on those
 # whose branches are all wave-uniform (nearly all of this code: the chain logic branches on scalars).  Structurizing
 # rewrites multi-exit loops and unstructured merges with guard flags (lane masks carried through phis) and pays for
 # the extra merges with register copies in the loop bodies; leaving uniform regions as the plain scalar-branch CFG
-# they are: -5 % sweep time, -7..18 % static instructions per kernel.
+# they are: -5 % sweep time, -7..18 % static instructions per kernel (profiles/HISTORY.md, round 2).
 # -amdgpu-sched-strategy=max-ilp: the sweep kernel is issue-bound at a fixed occupancy (launch bounds), so the
 # scheduler has nothing to gain from trading latency hiding for registers: -0.7 % -- for the variants built for 6
 # wavefronts per SIMD (80 VGPRs, no spill).  Variant s is built for 8 (64 VGPRs): there the default scheduler spills 18
@@ -175,7 +175,8 @@ def _build_locked(verbose):
     # control build without the backend switches (parity tests only)
     cl, ck, cb, waves, _ = VARIANTS["m"]
     library(os.path.join(_HERE, PLAIN_LIB), "plain",
-            HIPCC_BASE + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"])
+            HIPCC_BASE + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}",
+                          "-DGPH_LOGSTEPS"])     # + the decision-level transcript (tests/test_logsteps.py)
     # the program: same command line as the reference's G-PhoCS binary (GPhoCS.c:84-238)
     exe, main = os.path.join(_HERE, "G-PhoCS-hip"), os.path.join(CSRC, "gph_main.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(main), os.path.getmtime(deps[-1])):
@@ -255,7 +256,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_comm_unique_id", "gph_comm_create_rccl", "gph_comm_create_shm", "gph_comm_attach_shm", "gph_comm_shm_bytes",
     "gph_comm_destroy", "gph_comm_world", "gph_comm_rank", "gph_comm_on_stream", "gph_comm_kind",
     "gph_comm_allgather_stream", "gph_comm_allreduce_host", "gph_run_control_file_comm", "gph_device_count",
-    "gph_engine_unit", "gph_build_id", "gph_build_compiler", "gph_runtime_version", "gph_comm_local_group", "gph_comm_create_local",
+    "gph_engine_unit", "gph_build_id", "gph_build_compiler", "gph_runtime_version", "gph_engine_steplog_enable", "gph_engine_steplog_fetch", "gph_comm_local_group", "gph_comm_create_local",
     "gph_mcmc_get_chain", "gph_mcmc_set_chain", "gph_mcmc_update_gb", "gph_mcmc_update_locus_rate", "gph_mcmc_update_theta",
     "gph_mcmc_update_mig_rates", "gph_mcmc_update_tau", "gph_mcmc_update_sample_age", "gph_mcmc_mixing",
     "gph_mcmc_synchronize_events", "gph_mcmc_check_all", "gph_mcmc_initialize_genealogies",
@@ -341,6 +342,8 @@ def _load_library(path):
     lib.gph_run_control_file_comm.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.gph_build_id.restype = C.c_char_p
     lib.gph_build_compiler.restype = C.c_char_p
+    lib.gph_engine_steplog_enable.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32]
+    lib.gph_engine_steplog_fetch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32), C.c_int32]
     lib.gph_runtime_version.restype = C.c_char_p
     lib.gph_comm_local_group.argtypes = [C.c_int32, C.c_int32]
     lib.gph_comm_local_group.restype = C.c_void_p

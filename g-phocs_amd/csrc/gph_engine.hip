@@ -362,6 +362,7 @@ struct gph_engine {
   bool sync_pending = false;   // synchronizeEvents of the finished iteration rides at the head of the next sweep kernel
   bool fin_owed = false;       // the commit / revert of the last decided tau / sample-age proposal has not run yet
   bool mix_owed = false;       // the commit of the last decided mixing proposal has not run yet (it rides at the head of the next sweep kernel)
+  int32_t slog_sel = 0;        // loci selected for the decision-level transcript (GPH_LOGSTEPS builds)
   bool mirror_current = true;  // the host mirror G_h holds what the device-side stages last wrote (false between a queued stage and pull_G)
   bool no_fuse = false;        // GPH_NO_FUSE=1 (tests): every finish as a kernel of its own; read once in gph_engine_create
   gph_counters counters = {0, 0, 0.0, 0};
@@ -908,6 +909,7 @@ void gph_engine_destroy(gph_engine *e)
   dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
   dev_free(e->d_lrec); dev_free(e->d_lpre); dev_free(e->d_slot_of); dev_free(e->d_lr_result); dev_free(e->d_lr_gscr); dev_free(e->d_ref_page); dev_free(e->d_ref_seq);
   dev_free(e->d_part); dev_free(e->dev.err);
+  dev_free((void *)e->dev.slog_map); dev_free(e->dev.slog); dev_free(e->dev.slog_n);
   if (e->d_gather != e->d_red) dev_free(e->d_gather);
   dev_free(e->d_red);
 #ifdef GPH_HOSTEMU
@@ -996,7 +998,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
       bk.lds_bytes = GPH_Q_BYTES(pn, n, cnt16);
       /* the per-lane terms of the root reduction through LDS (ordered_sum64_lds: one vector instruction per pattern
        * instead of three) take 8 bytes per pattern behind a locus's block: never at the price of a resident workgroup.
-       * LDS is handed out in 1280-byte granules (160 KB / 128, measured: DESIGN.md section 8.2) and the sweep kernel keeps
+       * LDS is handed out in 1280-byte granules (160 KB / 128, measured: profiles/HISTORY.md, round 1) and the sweep kernel keeps
        * at most GPH_SWEEP_WAVES workgroups per SIMD: the group gets the room of the granules its largest block needs
        * anyway, or -- when even the largest locus's terms do not cost a workgroup -- room for everybody's; a locus takes
        * the LDS form when its terms end inside the allocation (gph_locus.h: lik_compute) */
@@ -1505,6 +1507,57 @@ const char *gph_runtime_version(void)
   snprintf(buf, sizeof buf, "HIP runtime %d, driver %d", rt, dr);
 #endif
   return buf;
+}
+
+// Decision-level transcript (upstream -DLOG_STEPS: GPhoCS.c:2363-2401, 2540-2577, 2654-2718, patch.c:1451-1454):
+// the three genealogy sweeps append one record per printed fragment for the selected loci -- kind 1 node-age proposal
+// {node, t, tnew}, 2 considerEventMove {event, source pop, target pop, old age, new age, new event}, 3 decision {accepted,
+// lnacceptance}, 4 migration-node proposal {migration node, t, tnew}, 5 SPR {node, father, father's population}.  Compiled
+// into the test builds only (GPH_LOGSTEPS: the host build of tests/hostemu and libgphocs_hip_plain.so).
+int gph_engine_steplog_enable(gph_engine *e, const int64_t *loci, int32_t n, int32_t cap)
+{
+#ifndef GPH_LOGSTEPS
+  (void)e; (void)loci; (void)n; (void)cap;
+  return GPH_EARG;      /* not compiled into this build of the library */
+#else
+  if (!e || !e->loaded || n < 0 || cap < 1 || (n > 0 && !loci)) return GPH_EARG;
+  SETDEV(e);
+  { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
+  dev_free((void *)e->dev.slog_map); dev_free(e->dev.slog); dev_free(e->dev.slog_n);
+  e->dev.slog_map = nullptr; e->dev.slog = nullptr; e->dev.slog_n = nullptr; e->dev.slog_cap = 0;
+  e->slog_sel = n;
+  if (n == 0) return 0;
+  std::vector<int32_t> map((size_t)e->L, -1);
+  for (int64_t j = 0; j < e->L; j++)
+    for (int k = 0; k < n; k++)
+      if (e->h_orig[j] + e->cfg.locus_begin == loci[k]) map[j] = k;
+  std::vector<int32_t> zero((size_t)n, 0);
+  if (dev_alloc((void **)&e->dev.slog_map, sizeof(int32_t) * e->L) || dev_alloc((void **)&e->dev.slog, sizeof(double) * 8 * (size_t)n * cap) ||
+      dev_alloc((void **)&e->dev.slog_n, sizeof(int32_t) * n)) return GPH_EHIP;
+  if (h2d(e, (void *)e->dev.slog_map, map.data(), sizeof(int32_t) * e->L) || h2d(e, e->dev.slog_n, zero.data(), sizeof(int32_t) * n)) return GPH_EHIP;
+  e->dev.slog_cap = cap;
+  return 0;
+#endif
+}
+// records of selected locus `idx` so far (out: 8 doubles per record, at most max_records of them; *nrec = records
+// written by the kernels, which may exceed the capacity given to _enable); reset != 0 empties the buffer
+int gph_engine_steplog_fetch(gph_engine *e, int32_t idx, double *out, int32_t max_records, int32_t *nrec, int32_t reset)
+{
+#ifndef GPH_LOGSTEPS
+  (void)e; (void)idx; (void)out; (void)max_records; (void)nrec; (void)reset;
+  return GPH_EARG;
+#else
+  if (!e || !e->dev.slog || idx < 0 || idx >= e->slog_sel || !nrec) return GPH_EARG;
+  SETDEV(e);
+  { int rcs = finish_sync(e); if (rcs) return rcs; }
+  int32_t n = 0;
+  if (d2h(e, &n, e->dev.slog_n + idx, sizeof n)) return GPH_EHIP;
+  *nrec = n;
+  const int32_t m = std::min(std::min(n, e->dev.slog_cap), max_records);
+  if (out && m > 0 && d2h(e, out, e->dev.slog + (size_t)idx * e->dev.slog_cap * 8, sizeof(double) * 8 * (size_t)m)) return GPH_EHIP;
+  if (reset) { const int32_t z = 0; if (h2d(e, e->dev.slog_n + idx, &z, sizeof z)) return GPH_EHIP; }
+  return 0;
+#endif
 }
 
 int gph_engine_hbm_bytes(gph_engine *e, double *bytes)

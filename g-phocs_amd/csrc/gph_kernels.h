@@ -23,6 +23,13 @@ struct GphDev {            // device pointers (passed by value to every kernel)
   int32_t Ltot;            // loci over all devices (dataSetup.numLoci)
   int64_t locus_begin;     // global index of this device's first locus
   int32_t *err;            // sticky error code of the kernels that are not followed by a reduction (commit / revert)
+  // decision-level transcript (GPH_LOGSTEPS builds only -- the host build of the tests and the control build
+  // libgphocs_hip_plain.so; every other build carries the three words and never reads them): per-proposal records
+  // of the selected loci, upstream's -DLOG_STEPS (GPhoCS.c:2363-2401, 2540-2577, 2654-2718; patch.c:1451)
+  const int32_t *slog_map; // per slot: index of its record buffer, -1 = not logged
+  double *slog;            // [selected][slog_cap][8]: kind, six values, spare
+  int32_t *slog_n;         // [selected] records written (may exceed slog_cap: the excess is dropped)
+  int32_t slog_cap, pad_;
 };
 
 #include "gph_locus.h"   // opens struct GphCtx; closed at the end of this file
@@ -230,13 +237,16 @@ template <class RNG> GPH_DEV void sweep_internal(const GphDev &D, int g, double 
     tnew = t + gf64(&GphLds::s_cntf, 7) * l_rnd2normal8(rng);
     tnew = l_reflect(tnew, tb0, tb1);
     if (UNI(fabs(tnew - t) < 1e-15)) { acc++; continue; }
+    GPH_SLOG(1, inode, t, tnew, 0, 0, 0);
     lik_adjust_age(inode, tnew);
     lnLd = -FS(FS_DATALNL);
     { STAMP_BEGIN(1); lnLd += lik_compute(1); STAMP_END(1); }
     { STAMPA_BEGIN(2); dgen = consider_event_move(0, NEV(inode), pop, t, pop, tnew); STAMPA_END(2); }
     lnacc = dgen + lnLd;
     if (gph_failed()) break;
-    if (UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc))) {
+    const bool take_ = UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc));
+    GPH_SLOG(3, take_, lnacc, 0, 0, 0, 0);
+    if (take_) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
       sf64(&GphLds::s_cntf, 2, gf64(&GphLds::s_cntf, 2) + lnLd);
@@ -281,11 +291,14 @@ template <class RNG> GPH_DEV void sweep_mignodes(const GphDev &D, int g, double 
     tnew = t + finetune * l_rnd2normal8(rng);
     tnew = l_reflect(tnew, tb0, tb1);
     if (UNI(fabs(tnew - t) < 1e-15)) { acc++; continue; }
+    GPH_SLOG(4, mignode, t, tnew, 0, 0, 0);
     dgen = consider_event_move(0, ev_s, pop_s, t, pop_s, tnew);
     dgen += consider_event_move(1, ev_t, pop_t, t, pop_t, tnew);
     lnacc = dgen;
     if (gph_failed()) break;
-    if (UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc))) {
+    const bool take_ = UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc));
+    GPH_SLOG(3, take_, lnacc, 0, 0, 0, 0);
+    if (take_) {
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + dgen);
       dLog += dgen / D.Ltot;
@@ -315,13 +328,16 @@ template <class RNG> GPH_DEV void sweep_spr(const GphDev &D, int g, RNG &rng)
     father = FATH(node);
     father_pop_old = NPOP(father);
     sibling = LEFT(father) + RGHT(father) - node;
+    GPH_SLOG(5, node, father, father_pop_old, 0, 0, 0);
     { STAMPA_BEGIN(3); trace_lineage<0>(node, rng); STAMPA_END(3); }
     { STAMPA_BEGIN(4); res = trace_lineage<1>(node, rng); STAMPA_END(4); }
     lnLd = -FS(FS_DATALNL);
     { STAMP_BEGIN(1); lnLd += lik_compute(1); STAMP_END(1); }
     lnacc = lnLd;
     if (gph_failed()) break;
-    if (res >= 0 && (UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc)))) {
+    const bool take_ = res >= 0 && (UNI(lnacc >= 0) || UNI(l_rndu(rng) < gph_exp_u(lnacc)));
+    GPH_SLOG(3, take_, lnacc, 0, 0, 0, 0);
+    if (take_) {
       STAMPC_BEGIN(2);
       acc++;
       setFS(FS_GENLNL, FS(FS_GENLNL) + (SPRLN(1) - SPRLN(0)));
@@ -387,6 +403,7 @@ GPH_DEV void kb_sweep(const GphDev &D, int g, int flags, double ftCoal, double f
   } else {
     stage_in(D, g, D.pages, 1);
   }
+  GPH_SLOG_OPEN(D, g);
   GphRngB rng;       /* uniforms in batches of 64: gph_locus.h */
   rng_load(rng);
   /* flag 8: synchronizeEvents of the previous iteration (patch.c:3548), deferred into this kernel */

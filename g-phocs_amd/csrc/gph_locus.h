@@ -27,6 +27,20 @@ template <bool GPH_GM> struct GphCtxT {
   }
 #endif
   GphPad<IS_COUNT + CN_COUNT + SI_COUNT> r_pad;     /* GPH_PADGET / GPH_PADSET, gph_rt.h */
+#ifdef GPH_LOGSTEPS
+  // decision-level transcript of the selected loci (test builds only; GphDev::slog*): where this locus's records go
+  double *slog_ = nullptr;
+  int32_t *slog_n_ = nullptr;
+  int32_t slog_cap_ = 0;
+  long long slog_gen_ = 0;
+#define GPH_SLOG_OPEN(D, g) do { slog_ = nullptr; if ((D).slog_map && (D).slog_map[g] >= 0) { const int si_ = (D).slog_map[g]; \
+      slog_ = (D).slog + (size_t)si_ * (D).slog_cap * 8; slog_n_ = (D).slog_n + si_; slog_cap_ = (D).slog_cap; } } while (0)
+#define GPH_SLOG(kind, a, b, c, d, e, f) do { if (slog_ && GPH_LANE == 0) { const int k_ = (*slog_n_)++; if (k_ < slog_cap_) { double *r_ = slog_ + (size_t)k_ * 8; \
+      r_[0] = (kind); r_[1] = (double)(a); r_[2] = (double)(b); r_[3] = (double)(c); r_[4] = (double)(d); r_[5] = (double)(e); r_[6] = (double)(f); r_[7] = 0.0; } } } while (0)
+#else
+#define GPH_SLOG_OPEN(D, g) ((void)0)
+#define GPH_SLOG(kind, a, b, c, d, e, f) ((void)0)
+#endif
   // node sets of the saved version (LocusDataLikelihood.c:75-104: recalcConditionals[], changedNodeIds[] /
   // changedCondIds[]) and the double buffer's current halves, bit = genealogy node: wave-uniform 64-bit scalars for
   // as long as a kernel works on the locus, held in lane pairs of the scalar pad (page words IS_DIRTY / IS_CBIT /
@@ -1720,6 +1734,7 @@ GPH_DEVHOT double consider_event_move(int inst, int event_id, int source_pop, do
   inst = RFL(inst); event_id = RFL(event_id); source_pop = RFL(source_pop); target_pop = RFL(target_pop);
   new_event = create_event(target_pop, new_age);
   if (new_event < 0) { gph_fail(13); return 0.0; }
+  GPH_SLOG(2, event_id, source_pop, target_pop, original_age, new_age, new_event);   /* patch.c:1451-1454 */
   setDI(inst, DI_ORIG, event_id);
   setDI(inst, DI_UPD, new_event);
   setDI(inst, DI_SRCPOP, source_pop);

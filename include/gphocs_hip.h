@@ -207,6 +207,14 @@ const char *gph_build_id(void);
 /* the compiler that built this library (its __clang_version__) and the HIP runtime / driver it is running on
  * ("runtime <hipRuntimeGetVersion>, driver <hipDriverGetVersion>"): both go into the bench line -- a library built by one
  * ROCm release may well run on another */
+/* TEST BUILDS ONLY (libgphocs_hip_plain.so and the host build of tests/hostemu; every other build returns GPH_EARG):
+ * decision-level transcript of the three genealogy sweeps for the selected loci (global locus indices), the engine's
+ * counterpart of upstream's -DLOG_STEPS debug file (GPhoCS.c:2363-2401, 2540-2577, 2654-2718; patch.c:1451-1454).
+ * Records are 8 doubles: kind, then  1 node-age proposal: node, t, tnew | 2 considerEventMove: event, source pop, target
+ * pop, old age, new age, new event | 3 decision: accepted, lnacceptance | 4 migration-node proposal: node, t, tnew |
+ * 5 SPR: node, father, father's population.  tests/test_logsteps.py formats them as upstream prints them. */
+int gph_engine_steplog_enable(gph_engine *e, const int64_t *loci, int32_t n, int32_t cap);
+int gph_engine_steplog_fetch(gph_engine *e, int32_t idx, double *out, int32_t max_records, int32_t *nrec, int32_t reset);
 const char *gph_build_compiler(void);
 const char *gph_runtime_version(void);
 

@@ -104,3 +104,6 @@ for k in ('few', 'many', 'neg', 'missing'):
     open(f'r5_{k}.ctl', 'w').write(c.replace('r5.rates', f'r5_{k}.rates').replace('r5.trace', f'r5_{k}.trace'))
 PY
 for k in few many neg missing; do timeout 60 $REF main -n 1 r5_$k.ctl > /dev/null 2> r5_$k.stderr || true; rm -f r5_$k.trace; done
+
+# decision-level fixtures: the reference compiled with -DLOG_STEPS (oracle/_ref/gphocs_ref_log), two loci each of m3 and a7
+python3 make_logsteps.py

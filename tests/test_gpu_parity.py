@@ -587,3 +587,11 @@ def test_sequence_block_forms_agree(G, tmp_path, name):
     assert open(a).read() == open(b).read()
     assert open(a + ".state").read() == open(b + ".state").read()
     compare_records(a, os.path.join(GOLDEN, name + ".rtrace"))
+
+
+def test_reinitialise_drops_an_owed_mixing_commit(G, tmp_path):
+    """gph_engine_init_genealogies with a mixing commit still owed to the next sweep kernel (device-resident
+    iteration: the decision is taken by k_global, the commit rides at the head of k_sweep)"""
+    from parity_util import reinit_after_accepted_mixing
+    pk = G.Pack.load(os.path.join(GOLDEN, "m3.gpk"))
+    reinit_after_accepted_mixing(G, G.load_library(dims=(pk.n, pk.K, pk.B)), os.path.join(GOLDEN, "m3.gpk"), tmp_path)
