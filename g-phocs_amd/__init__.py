@@ -62,6 +62,10 @@ VARIANTS = {  # name: (max leaves, max pops, max bands, waves per SIMD of the sw
     # 64-bit population sets, 16-bit event ids, list-driven pruning order instead of the lane-per-node wave programs
     "g": (48, 16, 8, 6, "libgphocs_hip_g.so"),    # many samples, few populations (e.g. 20 diploids over 5 populations): the big-tree forms with a 9-KB image
     "h": (64, 40, 16, 6, "libgphocs_hip_h.so"),
+    # more than 16 migration bands, up to the reference's MAX_MIG_BANDS 100 (patch.h:17): the live-band list of a chain walk in LDS
+    # instead of 16 nibbles of a scalar, the model read from the chain state in HBM by every kernel (it no longer fits the
+    # kernel-argument segment), 384-column reduced rows; with the 64-leaf / 39-population forms of `h`: the engine's hard caps
+    "b": (64, 40, 100, 6, "libgphocs_hip_b.so"),
 }
 
 
@@ -69,12 +73,12 @@ LIB_SOURCES = ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.c
 
 
 def variant_for(n, K, B):
-    for name in ("s", "l", "m", "x", "g", "h"):
+    for name in ("s", "l", "m", "x", "g", "h", "b"):
         cl, ck, cb, _, _ = VARIANTS[name]
         if n <= cl and K <= ck and B <= cb:
             return name
     raise RuntimeError(f"model (leaves={n}, pops={K}, bands={B}) exceeds the engine's hard caps (64 leaves, 39 populations, "
-                       f"16 bands: 128-bit node sets, 4-bit band ids); the reference's own compile-time caps are "
+                       f"100 bands: 128-bit node sets); the reference's own compile-time caps are "
                        f"200 leaves / 39 populations / 100 bands (upstream src/patch.h:17-22)")
 
 

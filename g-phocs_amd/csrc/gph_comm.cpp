@@ -19,7 +19,7 @@
 #include <rccl/rccl.h>
 #endif
 
-#define GPH_COMM_MAXN 192
+#define GPH_COMM_MAXN 448      /* >= the columns a stage exchanges: counters + 2 * 39 populations + 2 * 100 bands */
 
 struct ShmSeg {                       // one cache line per rank's arrival counter
   std::atomic<uint32_t> magic;

@@ -163,15 +163,18 @@ __device__ __forceinline__ void reduce_run(const double *src, int stride, int co
       if (g + u * step < g1) { s += v[u]; mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
   }
 }
-__device__ void reduce_partial_body(const GphDev &D, int mode, int ncols, double *part, double (*sh)[GPH_RED_SUBS * 4][16])
+// cbase: first column of the window this call folds (at most 128 columns a call; the many-band build's statistics row is
+// folded window by window -- every column's additions are the same whatever the windows)
+__device__ void reduce_partial_body(const GphDev &D, int mode, int ncols, int cbase, int stride_cols, double *part, double (*sh)[GPH_RED_SUBS * 4][16])
 {
   /* a wavefront covers 64 / cw loci at a time (cw = columns rounded up to 16, 32 or 64): every lane has work */
   const int cw = ncols <= 16 ? 16 : ncols <= 32 ? 32 : ncols <= 64 ? 64 : 128;
   const int b = blockIdx.x;
   const int chunk = (D.L + GPH_RED_BLOCKS - 1) / GPH_RED_BLOCKS;
   const int g0 = b * chunk, g1 = g0 + chunk < D.L ? g0 + chunk : D.L;
-  const double *src = mode == 0 ? D.out : D.stats;
-  const int stride = mode == 0 ? GPH_OUT_SLOTS : ncols;
+  const double *src = (mode == 0 ? D.out : D.stats) + cbase;
+  const int stride = mode == 0 ? GPH_OUT_SLOTS : stride_cols;
+  part += cbase;
   if (cw == 128) {
     /* more than 64 columns (the largest capacity variant): two columns per lane, one locus per wavefront step */
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -228,9 +231,10 @@ __device__ void reduce_partial_body(const GphDev &D, int mode, int ncols, double
 // fixed shape, so the result does not depend on scheduling.  Up to 64 columns (every variant but the largest): thread
 // (run, column), one run each; beyond: thread (h, column) folds runs h and h + 4.  A run's 3 x 32 partials are fetched
 // 48 loads at a time: these are reads of other XCDs' writes, a microsecond or two each
-__device__ void reduce_final_body(int ncols, const double *part, double *red, double (*sh)[GPH_RED_SUBS][GPH_RED_COLS])
+__device__ void reduce_final_body(int ncols, int cbase, const double *part, double *red, double (*sh)[GPH_RED_SUBS][128])
 {
-  const int cw = ncols <= 64 ? 64 : GPH_RED_COLS;
+  part += cbase; red += cbase;
+  const int cw = ncols <= 64 ? 64 : 128;
   const int col = threadIdx.x % cw, h = threadIdx.x / cw;
   const int per = GPH_RED_BLOCKS / GPH_RED_SUBS;
   static_assert((GPH_RED_BLOCKS / GPH_RED_SUBS) % 16 == 0, "the final pass folds sixteen block partials per step");
@@ -248,7 +252,7 @@ __device__ void reduce_final_body(int ncols, const double *part, double *red, do
 #pragma unroll
         for (int u = 0; u < 16; u++) { s += vs[u]; mn = vn[u] < mn ? vn[u] : mn; mx = vx[u] > mx ? vx[u] : mx; }
       }
-    if (col < GPH_RED_COLS) { sh[0][sub][col] = s; sh[1][sub][col] = mn; sh[2][sub][col] = mx; }
+    if (col < 128) { sh[0][sub][col] = s; sh[1][sub][col] = mn; sh[2][sub][col] = mx; }
   }
   __syncthreads();
   if (h == 0 && col < ncols) {
@@ -270,10 +274,10 @@ __device__ void reduce_final_body(int ncols, const double *part, double *red, do
 __global__ void __launch_bounds__(GPH_RED_THREADS) k_reduce_stage(GphKargs KA, GphDev D, int nc0, int nc1, double *part, unsigned *ticket, double *red,
                                                                   int do_stage, GphStageList SL, int iteration)
 {
-  __shared__ union { double p[3][GPH_RED_SUBS * 4][16]; double f[3][GPH_RED_SUBS][GPH_RED_COLS]; GphStageShared st; } sh;
+  __shared__ union { double p[3][GPH_RED_SUBS * 4][16]; double f[3][GPH_RED_SUBS][128]; GphStageShared st; } sh;
   __shared__ int s_last;
-  if (nc0 > 0) reduce_partial_body(D, 0, nc0, part, sh.p);
-  if (nc1 > 0) reduce_partial_body(D, 1, nc1, part + 3 * GPH_RED_BLOCKS * GPH_RED_COLS, sh.p);
+  if (nc0 > 0) reduce_partial_body(D, 0, nc0, 0, nc0, part, sh.p);
+  for (int cb = 0; cb < nc1; cb += 128) reduce_partial_body(D, 1, nc1 - cb < 128 ? nc1 - cb : 128, cb, nc1, part + 3 * GPH_RED_BLOCKS * GPH_RED_COLS, sh.p);
   __syncthreads();
   /* ONE release per block (thread 0, after the block barrier: cumulative over the block's stores) -- an agent-scope
    * fence writes the L2 back, and 2048 wavefronts doing it cost more than the reduction itself */
@@ -284,8 +288,8 @@ __global__ void __launch_bounds__(GPH_RED_THREADS) k_reduce_stage(GphKargs KA, G
    * written through other XCDs' L2s): one agent-scope fence per wavefront of ONE block -- the memory model asks for
    * it, the cache-wide invalidate of thread 0's fence only happened to cover the other waves */
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (nc0 > 0) reduce_final_body(nc0, part, red, sh.f);
-  if (nc1 > 0) reduce_final_body(nc1, part + 3 * GPH_RED_BLOCKS * GPH_RED_COLS, red + GPH_RED_STRIDE, sh.f);
+  if (nc0 > 0) reduce_final_body(nc0, 0, part, red, sh.f);
+  for (int cb = 0; cb < nc1; cb += 128) reduce_final_body(nc1 - cb < 128 ? nc1 - cb : 128, cb, part + 3 * GPH_RED_BLOCKS * GPH_RED_COLS, red + GPH_RED_STRIDE, sh.f);
   if (threadIdx.x == 0) { red[3 * GPH_RED_COLS] = (double)*D.err; *ticket = 0; }
   __syncthreads();
   if (do_stage) stages_body(KA, red, 1, SL, iteration, sh.st);
@@ -436,11 +440,8 @@ static void build_model_static(gph_engine *e)
   int cum = 0;
   for (int p = 0; p < c.Kc; p++) { m.samplesPerPop[p] = e->samplesPerPop[p]; cum += e->samplesPerPop[p]; m.cumSamples[p] = cum; }
   for (int b = 0; b < c.B; b++) { m.bandSrc[b] = e->bandSrc[b]; m.bandTgt[b] = e->bandTgt[b]; }
-  for (int p = 0; p < c.K; p++) {
-    uint32_t over = 0;
-    for (int b = 0; b < c.B; b++) if ((m.isAnc[e->bandTgt[b]] >> p) & 1) over |= 1u << b;
-    m.bandsOver[p] = over;
-  }
+  for (int p = 0; p < c.K; p++)
+    for (int b = 0; b < c.B; b++) if ((m.isAnc[e->bandTgt[b]] >> p) & 1) m.bandsOver[p][b >> 5] |= 1u << (b & 31);
   // populationPostOrder(rootPop), patch.c:1936-1951
   std::vector<int> order;
   struct Rec { static void go(gph_engine *e, int pop, std::vector<int> &o) {
@@ -454,6 +455,12 @@ static void build_model_static(gph_engine *e)
 }
 
 // ---------------------------------------------------------------- runtime shim
+// the model in the kernel-argument segment (every build but the many-band one, whose kernels all read G->model)
+#if GPH_BIG_BANDS
+#define GPH_KA_MODEL(ka, e) ((void)0)
+#else
+#define GPH_KA_MODEL(ka, e) ((ka).model = (e)->G_h->model)
+#endif
 #ifdef GPH_HOSTEMU
 static int dev_alloc(void **p, size_t bytes) { *p = calloc(1, bytes ? bytes : 1); return *p ? 0 : GPH_EHIP; }
 static void dev_free(void *p) { free(p); }
@@ -461,7 +468,7 @@ static int h2d(gph_engine *, void *d, const void *h, size_t n) { memcpy(d, h, n)
 static int d2h(gph_engine *, void *h, const void *d, size_t n) { memcpy(h, d, n); return 0; }
 static int stream_sync(gph_engine *e) { e->n_syncs++; return 0; }
 #define LAUNCH_PRE(e) do { g_model = (e)->G_h->model; g_lay = (e)->lay; gph_G_emu = (e)->G_h; \
-    GphKargs &ka_ = (e)->ka; ka_.model = (e)->G_h->model; ka_.lay = (e)->lay; ka_.G = (e)->G_h; } while (0)
+    GphKargs &ka_ = (e)->ka; GPH_KA_MODEL(ka_, e); ka_.lay = (e)->lay; ka_.G = (e)->G_h; } while (0)
 #define LAUNCH(e, which, name, ...) do { LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
     for (auto &bk_ : (e)->buckets) { (e)->lds.assign(bk_.lds_bytes + 8 * (e)->lay.Pmax + 64, 0); /* the host form keeps per-pattern terms for every P */ gph_sm = (e)->lds.data(); \
       for (int b_ = 0; b_ < bk_.count; b_++) name(b_, ka_, (e)->dev, bk_.j0, __VA_ARGS__); } \
@@ -515,7 +522,7 @@ static void tm_end(gph_engine *e, int slot) { if (slot >= 0) (void)hipEventRecor
 // timed launch: HIP events on the engine's own stream bracket the kernel.  One dispatch covers every
 // locus with at most one pattern per lane (slots in decreasing P: longest wavefronts first), a second one
 // the rare loci with more (they also need the per-pattern terms array in LDS).  No host synchronisation here.
-#define LAUNCH_PRE(e) do { GphKargs &ka_ = (e)->ka; ka_.model = (e)->G_h->model; ka_.lay = (e)->lay; ka_.G = (e)->G_d; } while (0)
+#define LAUNCH_PRE(e) do { GphKargs &ka_ = (e)->ka; GPH_KA_MODEL(ka_, e); ka_.lay = (e)->lay; ka_.G = (e)->G_d; } while (0)
 #define LAUNCH(e, which, name, ...) do { { int rcf_ = flush_pending(e); if (rcf_) return rcf_; } LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
     const int tms_ = tm_begin((e), (which)); \
     const bool fork_ = (e)->side_stream && (e)->buckets.size() == 2; \
@@ -667,7 +674,7 @@ static int reduce_stats(gph_engine *e) { return reduce_local(e, 1, 2 * e->cfg.K 
 // which columns of the reduced row a stage consumes (host mode with a caller-supplied all-reduce hook: only these
 // travel): sums / minima / maxima as (section, column) pairs; every stage that follows a locus kernel also takes the
 // counters and the error words
-struct StageCols { int ns = 0, nm = 0, nx = 0; int s[160][2], m[8][2], x[8][2]; };
+struct StageCols { int ns = 0, nm = 0, nx = 0; int s[GPH_RED_COLS + 32][2], m[8][2], x[8][2]; };
 static void stage_columns(const gph_engine *e, int stage, StageCols &c)
 {
   const int C = 2 * e->cfg.K + 2 * e->cfg.B;
@@ -736,7 +743,7 @@ static int run_stage(gph_engine *e, int stage, int arg, int iteration)
     if (e->allreduce || e->comm) {
       StageCols c;
       stage_columns(e, stage, c);
-      double sums[160], mins[16];
+      double sums[GPH_RED_COLS + 32], mins[16];
       for (int k = 0; k < c.ns; k++) sums[k] = *colp(e->h_red, c.s[k], 0);
       for (int k = 0; k < c.nm; k++) mins[k] = *colp(e->h_red, c.m[k], 1);
       for (int k = 0; k < c.nx; k++) mins[c.nm + k] = -*colp(e->h_red, c.x[k], 2);   /* a maximum as the minimum of the negatives */
@@ -845,7 +852,7 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
   if (cfg->n > 200 || cfg->K > 39 || cfg->B > 100)
     fprintf(stderr, "gphocs_hip: n=%d K=%d B=%d exceed even the reference's compile-time caps (NS 200, 2*NSPECIES-1 = 39, MAX_MIG_BANDS 100: upstream src/patch.h:17-22)\n", cfg->n, cfg->K, cfg->B);
   if (cfg->n < 2 || cfg->n > GPH_CAP_LEAVES || cfg->K > GPH_CAP_K || cfg->B > GPH_CAP_B || cfg->K != 2 * cfg->Kc - 1) {
-    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (this library variant: n<=%d leaves, K<=%d populations, B<=%d bands; the engine's hard caps are 64 / 39 / 16 -- 128-bit node sets, 4-bit band ids -- against the reference's 200 / 39 / 100, upstream src/patch.h:17-22; rebuild with -DGPH_CAP_* up to the hard caps)\n",
+    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (this library variant: n<=%d leaves, K<=%d populations, B<=%d bands; the engine's hard caps are 64 / 39 / 100 -- 128-bit node sets -- against the reference's 200 / 39 / 100, upstream src/patch.h:17-22; rebuild with -DGPH_CAP_* up to the hard caps)\n",
             cfg->n, cfg->K, cfg->B, GPH_CAP_LEAVES, GPH_CAP_K, GPH_CAP_B);
     return GPH_EARG;
   }

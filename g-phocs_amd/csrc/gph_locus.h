@@ -22,8 +22,12 @@ template <bool GPH_GM> struct GphCtxT {
 #ifndef GPH_HOSTEMU
   GPH_DEV gph_cmodel &gmodel() const
   {
+#if GPH_BIG_BANDS
+    return *(gph_cmodel *)&(((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->G->model);
+#else
     if constexpr (GPH_GM) return *(gph_cmodel *)&(((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->G->model);
     else return ((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->model;
+#endif
   }
 #endif
   GphPad<IS_COUNT + CN_COUNT + SI_COUNT> r_pad;     /* GPH_PADGET / GPH_PADSET, gph_rt.h */
@@ -129,7 +133,7 @@ template <bool GPH_GM> struct GphCtxT {
 #define CBIT(i) ((int)ns_has(NS_GET(IS_CBIT0), (i)))
 // scratch
 #define DEV(inst, i) RFL((int)gph_lds.s_dev[inst][i])
-#define setDEV(inst, i, v) (gph_lds.s_dev[inst][i] = (uint8_t)(v))
+#define setDEV(inst, i, v) (gph_lds.s_dev[inst][i] = (gph_evid)(v))
 #define DCOAL(inst, i) gf64(&GphLds::s_dcoal, (inst), (i))
 #define setDCOAL(inst, i, v) sf64(&GphLds::s_dcoal, (inst), (i), (v))
 #define DMIG(inst, i) gf64(&GphLds::s_dmig, (inst), (i))
@@ -159,6 +163,19 @@ struct LiveList {
   uint64_t bits;
   int n;
 };
+#if GPH_BIG_BANDS
+// more than 16 bands: the entries are bytes of the LDS image (s_live); `bits` is unused.  ONE list is live at a time (every
+// function that keeps one -- recalc_stats, rubber_band, trace_lineage, check_gtree_structure -- finishes with it before
+// another starts: none of them calls another while its list is in use)
+GPH_DEV int ll_get(const LiveList &l, int i) { (void)l; return gu8(&GphLds::s_live, i); }
+GPH_DEV void ll_set(LiveList &l, int i, int v) { (void)l; su8(&GphLds::s_live, i, v); }
+GPH_DEV void ll_push(LiveList &l, int v) { ll_set(l, l.n, v); l.n++; }
+GPH_DEV int ll_find(const LiveList &l, int v)
+{
+  for (int i = 0; i < l.n; i++) if (ll_get(l, i) == v) return i;
+  return l.n;
+}
+#else
 GPH_DEV int ll_get(const LiveList &l, int i) { return (int)((l.bits >> (4 * i)) & 15); }
 GPH_DEV void ll_set(LiveList &l, int i, int v) { l.bits = (l.bits & ~((uint64_t)15 << (4 * i))) | ((uint64_t)v << (4 * i)); }
 GPH_DEV void ll_push(LiveList &l, int v) { ll_set(l, l.n, v); l.n++; }
@@ -171,6 +188,7 @@ GPH_DEV int ll_find(const LiveList &l, int v)
   if (l.n < 16) t &= (((uint64_t)1 << (4 * l.n)) - 1);
   return t ? (int)(__builtin_ctzll(t) >> 2) : l.n;
 }
+#endif
 GPH_DEV void ll_swap_remove(LiveList &l, int i) { l.n--; ll_set(l, i, ll_get(l, l.n)); }
 
 // every field of one genealogy node with ONE LDS access
@@ -1675,16 +1693,17 @@ GPH_DEV void mig_stats_delta(int inst, double bottom_age, int bottom_pop, double
   double dt, lo, hi;
   /* the bands whose target population is bottom_pop or above it, in band order (the filter of patch.c:1846 as one
    * table word per population) */
-  for (uint32_t over = g_model.bandsOver[bottom_pop]; over != 0; over &= over - 1) {
-    b = __builtin_ctz(over);
-    hi = gmin2(g_model.bandEnd[b], top_age);
-    lo = gmax2(g_model.bandStart[b], bottom_age);
-    dt = hi - lo;
-    if (dt <= 0) continue;
-    setDBANDS(inst, nb, b);
-    setDMIG(inst, nb, dlin * dt);
-    nb++;
-  }
+  for (int w = 0; w < GPH_BANDW; w++)
+    for (uint32_t over = g_model.bandsOver[bottom_pop][w]; over != 0; over &= over - 1) {
+      b = 32 * w + __builtin_ctz(over);
+      hi = gmin2(g_model.bandEnd[b], top_age);
+      lo = gmax2(g_model.bandStart[b], bottom_age);
+      dt = hi - lo;
+      if (dt <= 0) continue;
+      setDBANDS(inst, nb, b);
+      setDMIG(inst, nb, dlin * dt);
+      nb++;
+    }
   setDI(inst, DI_NBANDS, nb);
 }
 // computeCoalStatsDelta, patch.c:1878-1927

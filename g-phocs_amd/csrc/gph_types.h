@@ -41,7 +41,18 @@ typedef uint64_t gph_popmask;
 #define GPH_MAXK 32
 typedef uint32_t gph_popmask;
 #endif
-#define GPH_MAXB 16        // migration bands (reference cap 100, patch.h:17)
+// migration bands: 16 in every build that keeps the live-band list of a chain walk as 16 nibbles of one scalar; the
+// reference's own cap (MAX_MIG_BANDS 100, patch.h:17) in the build whose band capacity exceeds 16 -- there the list sits
+// in LDS (GphLds::s_live), band sets are GPH_BANDW words wide, the model no longer fits the 4-KB kernel-argument segment
+// (every kernel reads it from the chain state in HBM) and the reduced row has 384 columns
+#if GPH_CAP_B > 16
+#define GPH_MAXB 100
+#define GPH_BIG_BANDS 1
+#else
+#define GPH_MAXB 16
+#define GPH_BIG_BANDS 0
+#endif
+#define GPH_BANDW ((GPH_MAXB + 31) / 32)   // 32-bit words of a set of bands
 #ifndef GPH_MAX_MIGS
 #define GPH_MAX_MIGS 10    // migration events per genealogy (patch.h:18); smaller only in LDS-size experiments
 #endif
@@ -71,7 +82,7 @@ struct GphModel {
   double logTwoTheta[GPH_MAXK], logMigRate[GPH_MAXB];
   double migRate[GPH_MAXB], bandStart[GPH_MAXB], bandEnd[GPH_MAXB];
   gph_popmask isAnc[GPH_MAXK];         // bit d of isAnc[a]: a is ancestral to (or is) d
-  uint32_t bandsOver[GPH_MAXK];        // bit b of bandsOver[p]: band b's target population is p or an ancestor of p (computeMigStatsDelta's filter, patch.c:1846)
+  uint32_t bandsOver[GPH_MAXK][GPH_BANDW];   // bit b of bandsOver[p]: band b's target population is p or an ancestor of p (computeMigStatsDelta's filter, patch.c:1846)
   // 32-bit entries: a scalar load cannot fetch 16 bits, and a 16-bit table would be read with vector loads
   // (a VMEM round trip on the chain's critical path for a wave-uniform value)
   int32_t popFather[GPH_MAXK], popSon0[GPH_MAXK], popSon1[GPH_MAXK], samplesPerPop[GPH_MAXK];
@@ -106,7 +117,9 @@ struct GphGlobal;
 // access is one scalar load off the (always live) kernarg pointer -- a __constant__ symbol costs a
 // pc-relative address computation (3 scalar instructions) per access and an upload per change
 struct GphKargs {
-  GphModel model;
+#if !GPH_BIG_BANDS
+  GphModel model;        // (the many-band build: 8 KB, beyond the kernel-argument segment -- read from G->model)
+#endif
   GphLayout lay;
   // exp() / log() / rndu() constants (gph_math.h, gph_libm_tables.h): [0..7] exp, [8..25] log, [26..31] 1/m and m of
   // the three Wichmann-Hill streams; and the device addresses of the two 128-entry libm tables
@@ -227,6 +240,9 @@ struct alignas(16) GphLds {
   int16_t s_ord[GPH_CAP_N + 1], s_stack[GPH_CAP_N + 1];   // the list-driven pruning (the lane-per-node builds have no lists)
 #endif
   gph_evid s_dev[2][GPH_CAP_E];  // event lists of the two pending deltas
+#if GPH_BIG_BANDS
+  uint8_t s_live[(GPH_CAP_B + 15) & ~15];   // the live-band list of the chain walk in progress (one walk at a time: LiveList, gph_locus.h)
+#endif
 #if GPH_BIG_TREE
   double s_pe[GPH_CAP_N];        // edge transition probabilities of an evaluation, by child node (the smaller builds keep them in the lane of the node)
 #endif
@@ -235,7 +251,7 @@ struct alignas(16) GphLds {
 #endif
 };
 
-static_assert(GPH_CAP_LEAVES <= 64 && GPH_CAP_K <= GPH_MAXK && GPH_CAP_B <= GPH_MAXB, "capacities beyond the engine's hard caps (64 leaves, 39 populations, 16 bands)");
+static_assert(GPH_CAP_LEAVES <= 64 && GPH_CAP_K <= GPH_MAXK && GPH_CAP_B <= GPH_MAXB, "capacities beyond the engine's hard caps (64 leaves, 39 populations, 100 bands)");
 
 // arguments of the tau-evaluate kernel (host part of UpdateTau, GPhoCS.c:3224-3461)
 struct GphTauArgs {
@@ -269,7 +285,11 @@ struct GphTauFin {
 // reduced vectors of one launch: section 0 = per-locus outputs (GPH_OUT_SLOTS columns), section 1 = the compact
 // statistics (2K+2B columns); per section sum / min / max per column + the sticky error word.  With several
 // ranks every rank's row is all-gathered (RCCL, on the engine's stream) and combined in rank order.
+#if GPH_BIG_BANDS
+#define GPH_RED_COLS 384      /* 2 * 39 populations + 2 * 100 bands = 278 statistics columns */
+#else
 #define GPH_RED_COLS 128
+#endif
 #define GPH_RED_STRIDE (3 * GPH_RED_COLS + 8)
 #define GPH_RED_ROW (2 * GPH_RED_STRIDE)
 // stages of an iteration that run above the loci (gph_global.h: gg_stage)

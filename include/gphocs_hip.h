@@ -111,9 +111,9 @@ typedef struct {
 typedef struct {
   int32_t ap, son0, son1, isRoot, num_aff, mode;
   double tauold, taunew, taub0, taub1, taufactor0, taufactor1;
-  int32_t aff_bands[32];
-  int32_t start_or_end[32];
-  double new_band_ages[32];
+  int32_t aff_bands[200];     /* 2 * MAX_MIG_BANDS (patch.h:17): a band can enter with its start and its end */
+  int32_t start_or_end[200];
+  double new_band_ages[200];
 } gph_tau_args;
 
 typedef struct {

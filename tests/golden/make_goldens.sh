@@ -105,5 +105,9 @@ for k in ('few', 'many', 'neg', 'missing'):
 PY
 for k in few many neg missing; do timeout 60 $REF main -n 1 r5_$k.ctl > /dev/null 2> r5_$k.stderr || true; rm -f r5_$k.trace; done
 
+# b2: more than 16 migration bands (20; the reference allows MAX_MIG_BANDS 100, patch.h:17): library variant `b`
+gen b2 12 10 300 24 8 --mig-beta 0.00000004
+timeout 900 $REF main -n 1 b2.ctl >/dev/null 2>&1     # b2.trace: the reference's own trace file
+
 # decision-level fixtures: the reference compiled with -DLOG_STEPS (oracle/_ref/gphocs_ref_log), two loci each of m3 and a7
 python3 make_logsteps.py

@@ -37,6 +37,9 @@ CONFIGS = {
     8: dict(pops=[1] * 16, bands=[(i, i + 1) for i in range(8)] + [(i + 1, i) for i in range(8)], loci=1000, tau_factor=1.3),
     # the reference's own population cap (NSPECIES 20, patch.h:19): 20 current populations (39 in all), 40 leaves, 16 bands
     9: dict(pops=[1] * 20, bands=[(i, i + 1) for i in range(8)] + [(i + 1, i) for i in range(8)], loci=1000, tau_factor=1.25),
+    # more than 16 migration bands (the reference allows MAX_MIG_BANDS 100, patch.h:17): 6 current populations, 12 leaves, 20 bands
+    12: dict(pops=[1] * 6, bands=[(i, i + 1) for i in range(5)] + [(i + 1, i) for i in range(5)] + [(i, i + 2) for i in range(4)] +
+             [(i + 2, i) for i in range(4)] + [(0, 3), (3, 0)], loci=1000, tau_factor=1.6),
 }
 
 
