@@ -1529,7 +1529,9 @@ int gph_engine_steplog_enable(gph_engine *e, const int64_t *loci, int32_t n, int
 #else
   if (!e || !e->loaded || n < 0 || cap < 1 || (n > 0 && !loci)) return GPH_EARG;
   SETDEV(e);
-  { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
+  /* (before the first initialisation nothing is in flight, and the host mirror of the chain state -- not yet pushed -- must
+   * not be overwritten by a read-back) */
+  if (e->initialized) { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
   dev_free((void *)e->dev.slog_map); dev_free(e->dev.slog); dev_free(e->dev.slog_n);
   e->dev.slog_map = nullptr; e->dev.slog = nullptr; e->dev.slog_n = nullptr; e->dev.slog_cap = 0;
   e->slog_sel = n;
