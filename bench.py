@@ -558,7 +558,7 @@ def main():
         # committed under profiles/ -- not measured here.  They are the measurement of ONE build: used only when the
         # file's build id is the loaded library's and the shard has the file's size.
         build_id = lib.gph_build_id().decode()
-        traffic, traffic_src, issue = None, None, None
+        traffic, traffic_src, issue, secondary = None, None, None, None
         tf = os.path.join(REPO, "profiles", "traffic_k_sweep.json")
         if os.path.exists(tf):
             try:
@@ -568,6 +568,17 @@ def main():
                     traffic_src = "profiles/traffic_k_sweep.json (%s)" % tj.get("build", "committed rocprofv3 --pmc passes, not this run")
                     if tj.get("valu_per_wave") and sweep_ms > 0:
                         issue = issue_roofline(tj, sweep_ms, L_local, traffic_src)
+                    # the second kernel class: the evaluate kernels of the global proposals are the ones that DO sit on the
+                    # memory system (counter bytes per launch / this run's HIP-event time / 8 TB/s)
+                    secondary = {}
+                    for kk, v in (tj.get("secondary") or {}).items():
+                        ms = (kern_pre.get(kk[2:]) or {}).get("avg_ms")
+                        if ms:
+                            byts = v["fetch_bytes"] + v["write_bytes"]
+                            secondary[kk] = {"bound": "hbm", "traffic": byts, "fetch_bytes": v["fetch_bytes"], "write_bytes": v["write_bytes"],
+                                             "avg_launch_ms": ms, "achieved": byts / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                             "frac": byts / (ms * 1e-3) / 8e12, "source": traffic_src}
+                    secondary = secondary or None
                 elif tj.get("loci") == L_local:
                     traffic_src = (f"none: profiles/traffic_k_sweep.json was measured with build {tj.get('build_id')}, "
                                    f"the loaded library is {build_id}")
@@ -620,6 +631,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "hbm_counter_frac": (traffic / (sweep_ms * 1e-3) / 8e12) if traffic and sweep_ms > 0 else None,
                          "issue": issue,
+                         "secondary": secondary,
                          "per_sweep": {"bytes": per_sweep_bytes, "bound_ms_at_peak": per_sweep_bytes / 8e12 * 1e3,
                                        "frac": per_sweep_bytes / 8e12 * 1e3 / sweep_ms if sweep_ms > 0 else None,
                                        "accounting": "load-once/store-once: 2 (32 N P + 32 E + 20 N) bytes per locus per sweep"},

@@ -31,6 +31,12 @@ json.dump({"kernel": "k_sweep", "loci": 100000, "hbm_bytes_per_launch": fetch + 
                                   ("add_f64", "mul_f64", "fma_f64", "trans_f64", "int32", "int64", "cvt")}
                                  if "SQ_INSTS_VALU_ADD_F64" in s and "SQ_INSTS_VALU_INT32" in s else None),
            "branches_per_wave": s["SQ_INSTS_BRANCH"]["sum"] / n if "SQ_INSTS_BRANCH" in s else None,
+           # the second kernel class (evaluate kernels of the global proposals): counter bytes per launch, same corrections
+           "secondary": {kk: {"fetch_bytes": d[kn]["FETCH_SIZE"]["sum"] * 1024 * 2 / d[kn]["FETCH_SIZE"]["dispatches"],
+                              "write_bytes": d[kn]["WRITE_SIZE"]["sum"] * 1024 / d[kn]["WRITE_SIZE"]["dispatches"],
+                              "launches_measured": d[kn]["FETCH_SIZE"]["dispatches"]}
+                         for kk, kn in (("k_tau_eval", next((x for x in d if "k_tau_eval" in x), None)),
+                                        ("k_mix_eval", next((x for x in d if "k_mix_eval" in x), None))) if kn},
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_collect.sh): "
                      "FETCH_SIZE(KB)*1024*2 (gfx950 correction) + WRITE_SIZE(KB)*1024 per k_sweep dispatch (one "
                      f"dispatch per sweep), averaged over the {nd} dispatches of a 200-iteration pre-roll + 4 iterations"},
