@@ -285,6 +285,20 @@ def issue_roofline(tj, sweep_ms, loci, source):
             "source": source}
 
 
+def secondary_roofline(tj, kernels, source):
+    """the evaluate kernels of the global proposals against the HBM peak: counter bytes per launch (committed passes,
+    profiles/traffic_k_sweep.json: secondary) / this run's HIP-event time per launch / 8 TB/s"""
+    out = {}
+    for kk, v in (tj.get("secondary") or {}).items():
+        ms = (kernels.get(kk[2:]) or {}).get("avg_ms")
+        if ms:
+            byts = v["fetch_bytes"] + v["write_bytes"]
+            out[kk] = {"bound": "hbm", "traffic": byts, "fetch_bytes": v["fetch_bytes"], "write_bytes": v["write_bytes"],
+                       "avg_launch_ms": ms, "achieved": byts / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                       "frac": byts / (ms * 1e-3) / 8e12, "source": source}
+    return out or None
+
+
 def launch_ranks(a):
     """`bench.py --gpus N` with no launcher around it: this process starts the N ranks (one process per GPU, RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment -- what torch.distributed.run would set), waits for them and
@@ -570,15 +584,7 @@ def main():
                         issue = issue_roofline(tj, sweep_ms, L_local, traffic_src)
                     # the second kernel class: the evaluate kernels of the global proposals are the ones that DO sit on the
                     # memory system (counter bytes per launch / this run's HIP-event time / 8 TB/s)
-                    secondary = {}
-                    for kk, v in (tj.get("secondary") or {}).items():
-                        ms = (kern_pre.get(kk[2:]) or {}).get("avg_ms")
-                        if ms:
-                            byts = v["fetch_bytes"] + v["write_bytes"]
-                            secondary[kk] = {"bound": "hbm", "traffic": byts, "fetch_bytes": v["fetch_bytes"], "write_bytes": v["write_bytes"],
-                                             "avg_launch_ms": ms, "achieved": byts / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                             "frac": byts / (ms * 1e-3) / 8e12, "source": traffic_src}
-                    secondary = secondary or None
+                    secondary = secondary_roofline(tj, kern_pre, traffic_src)
                 elif tj.get("loci") == L_local:
                     traffic_src = (f"none: profiles/traffic_k_sweep.json was measured with build {tj.get('build_id')}, "
                                    f"the loaded library is {build_id}")

@@ -66,6 +66,9 @@ VARIANTS = {  # name: (max leaves, max pops, max bands, waves per SIMD of the sw
     # instead of 16 nibbles of a scalar, the model read from the chain state in HBM by every kernel (it no longer fits the
     # kernel-argument segment), 384-column reduced rows; with the 64-leaf / 39-population forms of `h`: the engine's hard caps
     "b": (64, 40, 100, 6, "libgphocs_hip_b.so"),
+    # the reference's own compile-time caps (NS 200, 39 populations, MAX_MIG_BANDS 100: patch.h:17-22): node sets of seven 64-bit
+    # words, the scalar pad in two registers, a 44-KB LDS image (3 loci resident per CU) -- a capability build
+    "n": (200, 40, 100, 2, "libgphocs_hip_n.so"),
 }
 
 
@@ -73,12 +76,12 @@ LIB_SOURCES = ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.c
 
 
 def variant_for(n, K, B):
-    for name in ("s", "l", "m", "x", "g", "h", "b"):
+    for name in ("s", "l", "m", "x", "g", "h", "b", "n"):
         cl, ck, cb, _, _ = VARIANTS[name]
         if n <= cl and K <= ck and B <= cb:
             return name
-    raise RuntimeError(f"model (leaves={n}, pops={K}, bands={B}) exceeds the engine's hard caps (64 leaves, 39 populations, "
-                       f"100 bands: 128-bit node sets); the reference's own compile-time caps are "
+    raise RuntimeError(f"model (leaves={n}, pops={K}, bands={B}) exceeds the engine's caps (200 leaves, 39 populations, "
+                       f"100 bands); the reference's own compile-time caps are "
                        f"200 leaves / 39 populations / 100 bands (upstream src/patch.h:17-22)")
 
 

@@ -852,7 +852,7 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
   if (cfg->n > 200 || cfg->K > 39 || cfg->B > 100)
     fprintf(stderr, "gphocs_hip: n=%d K=%d B=%d exceed even the reference's compile-time caps (NS 200, 2*NSPECIES-1 = 39, MAX_MIG_BANDS 100: upstream src/patch.h:17-22)\n", cfg->n, cfg->K, cfg->B);
   if (cfg->n < 2 || cfg->n > GPH_CAP_LEAVES || cfg->K > GPH_CAP_K || cfg->B > GPH_CAP_B || cfg->K != 2 * cfg->Kc - 1) {
-    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (this library variant: n<=%d leaves, K<=%d populations, B<=%d bands; the engine's hard caps are 64 / 39 / 100 -- 128-bit node sets -- against the reference's 200 / 39 / 100, upstream src/patch.h:17-22; rebuild with -DGPH_CAP_* up to the hard caps)\n",
+    fprintf(stderr, "gphocs_hip: unsupported dimensions n=%d K=%d B=%d (this library variant: n<=%d leaves, K<=%d populations, B<=%d bands; the largest variant covers the reference's own caps 200 / 39 / 100, upstream src/patch.h:17-22)\n",
             cfg->n, cfg->K, cfg->B, GPH_CAP_LEAVES, GPH_CAP_K, GPH_CAP_B);
     return GPH_EARG;
   }

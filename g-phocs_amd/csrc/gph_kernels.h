@@ -365,7 +365,7 @@ template <class RNG> GPH_DEV void sweep_spr(const GphDev &D, int g, RNG &rng)
       replace_mig_nodes(node);
       /* one lane per list entry / band / population (entries are distinct) */
       (void)ev; (void)b; (void)pop;
-      GPH_EACH(k, DI(1, DI_NEV)) { const int q = gph_lds.s_dev[1][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + 1); }
+      GPH_EACH(k, DI(1, DI_NEV)) { const int q = gph_lds.s_dev[1][k]; gph_lds.ev[q].nlin = (uint8_t)(gph_lds.ev[q].nlin + 1); }
       GPH_EACH1(k, g_lay.B) gph_lds.migst[k] = gph_lds.migst[k] + (gph_lds.s_dmig[1][k] - gph_lds.s_dmig[0][k]);
       GPH_EACH1(k, g_lay.K) gph_lds.coal[k] = gph_lds.coal[k] + (gph_lds.s_dcoal[1][k] - gph_lds.s_dcoal[0][k]);
       lik_reset_saved();
@@ -378,7 +378,7 @@ template <class RNG> GPH_DEV void sweep_spr(const GphDev &D, int g, RNG &rng)
         remove_event(SPRA(SA_NEWIN, i), g_model.bandTgt[b]);
         remove_event(SPRA(SA_NEWOUT, i), g_model.bandSrc[b]);
       }
-      GPH_EACH(k, DI(0, DI_NEV)) { const int q = gph_lds.s_dev[0][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + 1); }
+      GPH_EACH(k, DI(0, DI_NEV)) { const int q = gph_lds.s_dev[0][k]; gph_lds.ev[q].nlin = (uint8_t)(gph_lds.ev[q].nlin + 1); }
       lik_revert();
       STAMPC_END(3);
     }

@@ -55,15 +55,20 @@ template <bool GPH_GM> struct GphCtxT {
 #define m_cbit_get() pad64(IS_CBIT0)
   // gph_nset: a set of genealogy nodes -- one 64-bit scalar up to 32 leaves, a pair beyond (GPH_BIG_TREE)
 #if GPH_BIG_TREE
-  struct gph_nset { uint64_t lo, hi; };
-  GPH_DEV static gph_nset ns_none() { gph_nset r = {0, 0}; return r; }
-  GPH_DEV static bool ns_has(const gph_nset &s, int i) { return (((i < 64 ? s.lo : s.hi) >> (i & 63)) & 1) != 0; }
-  GPH_DEV static gph_nset ns_with(gph_nset s, int i) { if (i < 64) s.lo |= (uint64_t)1 << i; else s.hi |= (uint64_t)1 << (i - 64); return s; }
-  GPH_DEV static gph_nset ns_flip(gph_nset s, int i) { if (i < 64) s.lo ^= (uint64_t)1 << i; else s.hi ^= (uint64_t)1 << (i - 64); return s; }
-  GPH_DEV static gph_nset ns_xor(gph_nset a, const gph_nset &b) { a.lo ^= b.lo; a.hi ^= b.hi; return a; }
-  GPH_DEV static bool ns_any(const gph_nset &s) { return (s.lo | s.hi) != 0; }
-#define NS_GET(k) ns_get_((k))
-#define NS_PUT(k, v) do { const gph_nset nsv_ = (v); setpad64((k), nsv_.lo); setpad64((k) + 2, nsv_.hi); } while (0)
+  struct gph_nset { uint64_t w[GPH_NSQ]; };
+  GPH_DEV static gph_nset ns_none() { gph_nset r; for (int q = 0; q < GPH_NSQ; q++) r.w[q] = 0; return r; }
+  GPH_DEV static bool ns_has(const gph_nset &s, int i)
+  {
+    uint64_t x = s.w[0];
+    for (int q = 1; q < GPH_NSQ; q++) if ((i >> 6) == q) x = s.w[q];     /* (selects, not an indexed private array) */
+    return ((x >> (i & 63)) & 1) != 0;
+  }
+  GPH_DEV static gph_nset ns_with(gph_nset s, int i) { for (int q = 0; q < GPH_NSQ; q++) if ((i >> 6) == q) s.w[q] |= (uint64_t)1 << (i & 63); return s; }
+  GPH_DEV static gph_nset ns_flip(gph_nset s, int i) { for (int q = 0; q < GPH_NSQ; q++) if ((i >> 6) == q) s.w[q] ^= (uint64_t)1 << (i & 63); return s; }
+  GPH_DEV static gph_nset ns_xor(gph_nset a, const gph_nset &b) { for (int q = 0; q < GPH_NSQ; q++) a.w[q] ^= b.w[q]; return a; }
+  GPH_DEV static bool ns_any(const gph_nset &s) { uint64_t x = 0; for (int q = 0; q < GPH_NSQ; q++) x |= s.w[q]; return x != 0; }
+#define NS_GET(k) ns_get_<(k)>()
+#define NS_PUT(k, v) ns_put_<(k)>((v))
 #else
   typedef uint64_t gph_nset;
   GPH_DEV static gph_nset ns_none() { return 0; }
@@ -113,7 +118,7 @@ template <bool GPH_GM> struct GphCtxT {
 #define ENODE(e) RFL((int)gph_lds.ev[e].node)
 #define setENODE(e, v) (gph_lds.ev[e].node = (int16_t)(v))
 #define ENLIN(e) RFL((int)gph_lds.ev[e].nlin)
-#define setENLIN(e, v) (gph_lds.ev[e].nlin = (int8_t)(v))
+#define setENLIN(e, v) (gph_lds.ev[e].nlin = (uint8_t)(v))
 #define ETYPE(e) RFL((int)gph_lds.ev[e].type)
 #define setETYPE(e, v) (gph_lds.ev[e].type = (uint8_t)(v))
 #define FIRSTEV(p) gi16(&GphLds::first, (p))
@@ -220,7 +225,7 @@ GPH_DEVHOT GphEvS ld_ev(int ev)
   r.next = (int)(int16_t)w2;
   r.prev = w2 >> 16;
   r.node = (int)(int16_t)w3;
-  r.nlin = (int)(int8_t)(w3 >> 16);
+  r.nlin = (int)(uint8_t)(w3 >> 16);
   r.type = (int)((uint32_t)w3 >> 24);
   return r;
 }
@@ -268,7 +273,11 @@ GPH_DEV int gph_errcode() { return CNT(CN_ERROR); }
 #define pad64(k) ((uint64_t)(uint32_t)ISC(k) | ((uint64_t)(uint32_t)ISC((k) + 1) << 32))
 #define setpad64(k, v) do { const uint64_t pv64_ = (v); setISC((k), (int)(uint32_t)pv64_); setISC((k) + 1, (int)(uint32_t)(pv64_ >> 32)); } while (0)
 #if GPH_BIG_TREE
-GPH_DEV gph_nset ns_get_(int k) { gph_nset r; r.lo = pad64(k); r.hi = pad64(k + 2); return r; }
+/* word q of the set that starts at scalar K: pad scalars K + 2q, K + 2q + 1 (compile-time lanes) */
+template <int K, int Q> GPH_DEV void ns_get_words_(gph_nset &r) { if constexpr (Q < GPH_NSQ) { r.w[Q] = pad64(K + 2 * Q); ns_get_words_<K, Q + 1>(r); } }
+template <int K> GPH_DEV gph_nset ns_get_() { gph_nset r; ns_get_words_<K, 0>(r); return r; }
+template <int K, int Q> GPH_DEV void ns_put_words_(const gph_nset &v) { if constexpr (Q < GPH_NSQ) { setpad64(K + 2 * Q, v.w[Q]); ns_put_words_<K, Q + 1>(v); } }
+template <int K> GPH_DEV void ns_put_(const gph_nset &v) { ns_put_words_<K, 0>(v); }
 #endif
 GPH_DEV void load_scalars() { r_pad.load(gph_lds.iscal, IS_COUNT); }
 GPH_DEV void flush_scalars() { r_pad.store(gph_lds.iscal, IS_COUNT); }
@@ -1801,7 +1810,7 @@ GPH_DEV void accept_event_chain_changes(int inst)
   oe = DI(inst, DI_ORIG);
   i = DI(inst, DI_NEV) - 1;
   if (i >= 0 && DEV(inst, i) == oe) i--;
-  GPH_EACH(k, i + 1) { const int q = gph_lds.s_dev[inst][k]; gph_lds.ev[q].nlin = (int8_t)(gph_lds.ev[q].nlin + dlin); }
+  GPH_EACH(k, i + 1) { const int q = gph_lds.s_dev[inst][k]; gph_lds.ev[q].nlin = (uint8_t)(gph_lds.ev[q].nlin + dlin); }
   ue = DI(inst, DI_UPD);
   if (ue >= 0) {
     setENODE(ue, ENODE(oe));

@@ -206,14 +206,28 @@ template <int NN> struct GphPad {
 #define GPH_PADGET(i) (r_pad.get(i))
 #define GPH_PADSET(i, x) (r_pad.set((i), (x)))
 #else
+// (up to 64 scalars: one register; the 200-leaf build's node sets need more: scalars 64.. sit in a second register, which a
+// build that never indexes beyond 63 never materialises)
 template <int NN> struct GphPad {
-  static_assert(NN <= 64, "one scalar per lane");
-  int32_t v = 0;
-  __device__ inline void load(const int32_t *src, int n) { const int lane = GPH_LANE; v = lane < n ? ((const GPH_LDS int32_t *)src)[lane] : 0; }
-  __device__ inline void store(int32_t *dst, int n) const { const int lane = GPH_LANE; if (lane < n) ((GPH_LDS int32_t *)dst)[lane] = v; }
+  static_assert(NN <= 128, "one scalar per lane of two registers");
+  int32_t v = 0, v2 = 0;
+  __device__ inline void load(const int32_t *src, int n)
+  {
+    const int lane = GPH_LANE;
+    v = lane < n ? ((const GPH_LDS int32_t *)src)[lane] : 0;
+    if constexpr (NN > 64) v2 = lane + 64 < n ? ((const GPH_LDS int32_t *)src)[lane + 64] : 0;
+  }
+  __device__ inline void store(int32_t *dst, int n) const
+  {
+    const int lane = GPH_LANE;
+    if (lane < n) ((GPH_LDS int32_t *)dst)[lane] = v;
+    if constexpr (NN > 64) { if (lane + 64 < n) ((GPH_LDS int32_t *)dst)[lane + 64] = v2; }
+  }
 };
-#define GPH_PADGET(i) __builtin_amdgcn_readlane(r_pad.v, (i))
-#define GPH_PADSET(i, x) do { const int pv_ = RFL(x); asm("v_writelane_b32 %0, %1, %2" : "+v"(r_pad.v) : "s"(pv_), "i"(i)); } while (0)
+#define GPH_PADGET(i) ((i) < 64 ? __builtin_amdgcn_readlane(r_pad.v, (i) & 63) : __builtin_amdgcn_readlane(r_pad.v2, (i) & 63))
+#define GPH_PADSET(i, x) do { const int pv_ = RFL(x); \
+    if ((i) < 64) asm("v_writelane_b32 %0, %1, %2" : "+v"(r_pad.v) : "s"(pv_), "i"((i) & 63)); \
+    else asm("v_writelane_b32 %0, %1, %2" : "+v"(r_pad.v2) : "s"(pv_), "i"((i) & 63)); } while (0)
 #endif
 // a / b given y = RN(1/b).  Device: q0 = a*y, r = fma(-q0, b, a) (exact), q = fma(r, y, q0) is the correctly rounded
 // quotient (Markstein) without the ~12-instruction divide expansion; tools/verify_fma_div*.c compare it with the

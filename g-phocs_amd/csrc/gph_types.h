@@ -57,12 +57,13 @@ typedef uint32_t gph_popmask;
 #define GPH_MAX_MIGS 10    // migration events per genealogy (patch.h:18); smaller only in LDS-size experiments
 #endif
 #if GPH_CAP_LEAVES > 32
-#define GPH_BIG_TREE 1     // 2n - 1 > 64 genealogy nodes: no lane-per-node programs, node sets of 128 bits
-#define GPH_NSW 4          // 32-bit page words per node set
+#define GPH_BIG_TREE 1     // 2n - 1 > 64 genealogy nodes: no lane-per-node programs, node sets of GPH_NSQ 64-bit words
+#define GPH_NSQ ((2 * GPH_CAP_LEAVES - 1 + 63) / 64)     // 2 up to 64 leaves, 7 at the reference's NS 200 (patch.h:22)
 #else
 #define GPH_BIG_TREE 0
-#define GPH_NSW 2
+#define GPH_NSQ 1
 #endif
+#define GPH_NSW (2 * GPH_NSQ)   // 32-bit page words per node set
 #define GPH_OLDAGE 999.0   // patch.h:21
 #define GPH_WAVE 64
 #define FS_COUNT_ 5
@@ -192,7 +193,7 @@ struct alignas(16) GphEv {
   double time;            // elapsed_time
   int16_t next, prev;     // chain links
   int16_t node;           // node_id (genealogy node, migration node or band)
-  int8_t nlin;            // num_lineages
+  uint8_t nlin;           // num_lineages (0 .. number of leaves <= 200: never negative)
   uint8_t type;           // EventType
 };
 
@@ -251,7 +252,7 @@ struct alignas(16) GphLds {
 #endif
 };
 
-static_assert(GPH_CAP_LEAVES <= 64 && GPH_CAP_K <= GPH_MAXK && GPH_CAP_B <= GPH_MAXB, "capacities beyond the engine's hard caps (64 leaves, 39 populations, 100 bands)");
+static_assert(GPH_CAP_LEAVES <= 200 && GPH_CAP_K <= GPH_MAXK && GPH_CAP_B <= GPH_MAXB, "capacities beyond the reference's own caps (200 leaves, 39 populations, 100 bands: patch.h:17-22)");
 
 // arguments of the tau-evaluate kernel (host part of UpdateTau, GPhoCS.c:3224-3461)
 struct GphTauArgs {

@@ -109,5 +109,9 @@ for k in few many neg missing; do timeout 60 $REF main -n 1 r5_$k.ctl > /dev/nul
 gen b2 12 10 300 24 8 --mig-beta 0.00000004
 timeout 900 $REF main -n 1 b2.ctl >/dev/null 2>&1     # b2.trace: the reference's own trace file
 
+# n7: more than 64 leaves (36 diploids over 6 populations = 72; the reference allows NS 200, patch.h:22): library variant `n`
+gen n7 13 6 200 12 6 --mig-beta 0.0000001
+timeout 900 $REF main -n 1 n7.ctl >/dev/null 2>&1     # n7.trace: the reference's own trace file
+
 # decision-level fixtures: the reference compiled with -DLOG_STEPS (oracle/_ref/gphocs_ref_log), two loci each of m3 and a7
 python3 make_logsteps.py

@@ -54,7 +54,7 @@ def build_hostemu(sanitize=False, big=False):
 
 def _build(out, srcs, sanitize, big):
     # the engine's hard caps (library variant `x`): every golden fits, the image size does not matter on the host
-    caps = ["-DGPH_CAP_LEAVES=64", "-DGPH_CAP_K=40", "-DGPH_CAP_B=100"] if big else ["-DGPH_CAP_LEAVES=32", "-DGPH_CAP_K=32", "-DGPH_CAP_B=16"]
+    caps = ["-DGPH_CAP_LEAVES=200", "-DGPH_CAP_K=40", "-DGPH_CAP_B=100"] if big else ["-DGPH_CAP_LEAVES=32", "-DGPH_CAP_K=32", "-DGPH_CAP_B=16"]
     tmp = f"{out}.tmp.{os.getpid()}"
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU", "-DGPH_LOGSTEPS"] + caps + [
            "-ffp-contract=off", "-fPIC", "-shared", "-pthread",

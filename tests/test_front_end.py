@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
 import gphocs_amd as G  # noqa: E402
 import run_hostemu as R  # noqa: E402
 
-CASES = ["g1", "g2", "m3", "m4", "c5", "s3", "a6", "a7", "z0", "stress", "v8", "v9", "y9", "r5", "b2"]
+CASES = ["g1", "g2", "m3", "m4", "c5", "s3", "a6", "a7", "z0", "stress", "v8", "v9", "y9", "r5", "b2", "n7"]
 
 
 @pytest.fixture(scope="module")

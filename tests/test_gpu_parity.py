@@ -21,6 +21,7 @@ CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, 
          "r5": 60,   # r5: locus-mut-rate FIXED <rate file> (readRateFile, GPhoCS.c:491-579): per-locus rates 0.2 .. 5 before normalisation
          "x8": 24,   # x8: 32 leaves, 31 populations, 16 bands: the largest lane-per-node build (library variant x)
          "y9": 16,   # y9: 40 leaves, 39 populations (the reference's NSPECIES cap), 16 bands: library variant h
+         "n7": 12,   # n7: 72 leaves: library variant n (200 leaves / 39 populations / 100 bands, the reference's own caps)
          "b2": 24}   # b2: 20 migration bands: library variant b (live-band list in LDS, model read from HBM, 384-column reduced rows)
 
 
@@ -327,7 +328,7 @@ def test_native_library_is_the_path(G):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "y9", "r5", "b2"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "y9", "r5", "b2", "n7"])
 def test_program_trace_file(name, tmp_path):
     """G-PhoCS-hip <control-file> on the MI355X: the trace file of the real G-PhoCS binary for the same
     control + sequence files (tests/golden/*.trace), to the printed precision (%8.5f / %.6f)."""

@@ -48,7 +48,7 @@ def test_sequence_block_with_32bit_counts(hostemu, name, iters, tmp_path, monkey
     assert worst < 1e-12
 
 
-@pytest.mark.parametrize("name,iters", [("y9", 16), ("x8", 24), ("m3", 120), ("a7", 100), ("v8", 60), ("b2", 24)])
+@pytest.mark.parametrize("name,iters", [("y9", 16), ("x8", 24), ("m3", 120), ("a7", 100), ("v8", 60), ("b2", 24), ("n7", 12)])
 def test_big_tree_build_matches_reference_goldens(name, iters, tmp_path):
     """the 64-leaf / 39-population capacities (library variant `h`: 128-bit node sets, 64-bit population sets, 16-bit
     event ids, list-driven forms instead of the lane-per-node programs): golden y9 -- 40 leaves, 20 current populations

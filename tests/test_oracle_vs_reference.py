@@ -17,6 +17,7 @@ CASES = {  # name: iterations (must match make_goldens.sh)
     "r5": 60,   # locus-mut-rate FIXED r5.rates: per-locus rates spread over 0.2 .. 5 (readRateFile, GPhoCS.c:491-579)
     "x8": 24,   # 32 leaves, 31 populations, 16 bands
     "y9": 16,   # 40 leaves, 39 populations (the reference's NSPECIES cap), 16 bands
+    "n7": 12,   # 72 leaves (beyond the 64 of 128-bit node sets; the reference allows 200)
     "b2": 24,   # 20 migration bands (beyond the 16 of the nibble list; the reference allows 100)
 }
 

@@ -40,6 +40,8 @@ CONFIGS = {
     # more than 16 migration bands (the reference allows MAX_MIG_BANDS 100, patch.h:17): 6 current populations, 12 leaves, 20 bands
     12: dict(pops=[1] * 6, bands=[(i, i + 1) for i in range(5)] + [(i + 1, i) for i in range(5)] + [(i, i + 2) for i in range(4)] +
              [(i + 2, i) for i in range(4)] + [(0, 3), (3, 0)], loci=1000, tau_factor=1.6),
+    # more than 64 leaves (the reference allows NS 200, patch.h:22): 36 diploids over 6 populations = 72 leaves, 4 bands
+    13: dict(pops=[6] * 6, bands=[(0, 1), (1, 0), (3, 2), (4, 3)], loci=1000, tau_factor=1.6),
 }
 
 

@@ -51,6 +51,7 @@ sys.path.insert(0, ".")
 import bench as _bench
 b["roofline"]["issue"] = _bench.issue_roofline(json.load(open("profiles/traffic_k_sweep.json")), b["roofline"]["avg_launch_ms"], 100000,
                                                b["roofline"]["traffic_source"])
+b["roofline"]["secondary"] = _bench.secondary_roofline(json.load(open("profiles/traffic_k_sweep.json")), b["kernels"], b["roofline"]["traffic_source"])
 json.dump(b, open(f"profiles/{rnd}_bench_{tag}.json", "w"), indent=1)
 try:
     shutil.copy(f"gpurun_out/bench_{tag}_12500.json", f"profiles/{rnd}_bench_{tag}_12500loci.json")
