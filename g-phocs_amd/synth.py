@@ -26,6 +26,12 @@ CONFIGS = {  # diploid samples per current pop, migration bands (src, tgt), anci
     # variant h (128-bit node sets); and many populations: 12 current (23 in all), 24 leaves
     10: dict(pops=[4, 4, 4, 4, 4], bands=[(0, 1), (1, 0), (3, 2), (4, 3)]),
     11: dict(pops=[1] * 12, bands=[(0, 1), (1, 0), (3, 2), (4, 3), (6, 5), (8, 7)]),
+    # beyond the nibble list / 128-bit node sets (tools/gen_synth.py configs 12, 13): 20 migration bands (variant b); 72 leaves
+    # (variant n); and 136 leaves with 132 of them in ONE population: event records with more than 127 lineages
+    12: dict(pops=[1] * 6, bands=[(i, i + 1) for i in range(5)] + [(i + 1, i) for i in range(5)] + [(i, i + 2) for i in range(4)] +
+             [(i + 2, i) for i in range(4)] + [(0, 3), (3, 0)]),
+    13: dict(pops=[6] * 6, bands=[(0, 1), (1, 0), (3, 2), (4, 3)]),
+    14: dict(pops=[66, 2], bands=[(0, 1)]),
 }
 
 

@@ -86,7 +86,10 @@ def test_many_patterns_against_live_oracle(G, oracle_cli, tmp_path):
                                                              (7, 1500, 24, 2.0, 4e-8), (4, 1500, 16, 3.0, 4e-8),
                                                              (4, 600, 400, 3.0, 4e-8),    # long trajectory
                                                              (10, 500, 12, 3.0, 4e-8),    # 40 leaves: library variant h
-                                                             (11, 800, 16, 3.0, 4e-8)])   # 23 populations, 6 bands: variant x
+                                                             (11, 800, 16, 3.0, 4e-8),    # 23 populations, 6 bands: variant x
+                                                             (12, 400, 16, 3.0, 4e-8),    # 20 migration bands: variant b
+                                                             (13, 100, 10, 2.0, 1e-5),    # 72 leaves: variant n
+                                                             (14, 30, 8, 0.5, 1e-5)])     # 136 leaves, 132 lineages in one population: variant n, lineage counts > 127
 def test_scale_parity_against_live_oracle(G, oracle_cli, tmp_path, config, loci, iters, mut, mig_beta):
     """thousands of loci of the benchmark's synthetic shape (configs[3] and [4], the 3-population one, the two
     estimated-sample-age ones and a high-migration prior: mig-rate-beta 4e-8 puts thousands of migration events

@@ -165,3 +165,26 @@ def test_reinitialise_drops_an_owed_mixing_commit(hostemu, tmp_path):
     import gphocs_amd as G
     R, lib = hostemu
     reinit_after_accepted_mixing(G, lib, os.path.join(GOLDEN, "m3.gpk"), tmp_path)
+
+
+@pytest.mark.parametrize("config,loci,iters,mut", [(12, 40, 12, 3.0), (13, 12, 8, 2.0), (14, 6, 6, 0.5)])
+def test_big_build_against_live_oracle(oracle_cli, tmp_path, config, loci, iters, mut):
+    """the reference's own capacities on the host build of the engine sources (200 leaves / 39 populations / 100 bands) against
+    the oracle run live: 20 migration bands (live-band list in LDS), 72 leaves (node sets of several words), 136 leaves with
+    132 lineages in one population (lineage counts beyond a signed byte)"""
+    import run_hostemu as R
+    import gphocs_amd as G
+    from gphocs_amd_pkg import synth
+    lib = G.load_library(R.build_hostemu(big=True))
+    pk = synth.make_synthetic_pack(G.Pack, config, loci, seqlen=300, mut_scale=mut, data_seed=31 + config, mcmc_seed=99, samples_per_log=4,
+                                   mig_beta=4e-8)
+    pth = str(tmp_path / "big.gpk")
+    synth.write_pack(pk, pth)
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(pth, iters, str(tr), str(st), iters - 1, with_cond=False, lib=lib)
+    ot, os_ = tmp_path / "ot", tmp_path / "os"
+    subprocess.run([oracle_cli, "run", pth, str(iters), str(ot), str(os_), str(iters - 1), "0"], check=True, timeout=1200)
+    assert compare_records(tr, ot) < 1e-10
+    compare_states(st, os_)
+    if config == 14:
+        assert max(int(x.split(":")[3]) for ln in open(st) if ln.startswith("EV") or " " in ln for x in ln.split() if x.count(":") == 4) > 127
