@@ -186,5 +186,6 @@ def test_big_build_against_live_oracle(oracle_cli, tmp_path, config, loci, iters
     subprocess.run([oracle_cli, "run", pth, str(iters), str(ot), str(os_), str(iters - 1), "0"], check=True, timeout=1200)
     assert compare_records(tr, ot) < 1e-10
     compare_states(st, os_)
-    if config == 14:
-        assert max(int(x.split(":")[3]) for ln in open(st) if ln.startswith("EV") or " " in ln for x in ln.split() if x.count(":") == 4) > 127
+    if config == 14:   # event records "id:type:node:lineages:time" of the state dump
+        import re
+        assert max(int(m.group(1)) for ln in open(st) for m in re.finditer(r" \d+:\d+:-?\d+:(-?\d+):0x", ln)) > 127
