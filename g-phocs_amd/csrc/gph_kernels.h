@@ -326,8 +326,9 @@ template <class RNG> GPH_DEV void sweep_spr(const GphDev &D, int g, RNG &rng)
   for (node = 0; node < g_lay.N; node++) {
     if (node == ISC(IS_ROOT)) continue;
     father = FATH(node);
-    father_pop_old = NPOP(father);
-    sibling = LEFT(father) + RGHT(father) - node;
+    { const GphNodeS F_ = ld_node(father);     /* one LDS round trip for the father's record */
+      father_pop_old = F_.npop;
+      sibling = F_.left + F_.right - node; }
     GPH_SLOG(5, node, father, father_pop_old, 0, 0, 0);
     { STAMPA_BEGIN(3); trace_lineage<0>(node, rng); STAMPA_END(3); }
     { STAMPA_BEGIN(4); res = trace_lineage<1>(node, rng); STAMPA_END(4); }
@@ -528,11 +529,13 @@ GPH_DEV void kb_tau_eval(const GphDev &D, int g, gph_ctau &A, int fuse)
       int guard = 0;
       band = A.aff_bands[i];
       tgtP = g_model.bandTgt[band];
-      for (ev = FIRSTEV(tgtP); ev >= 0; ev = ENEXT(ev)) {
-        if (ENODE(ev) == band &&
-            ((ETYPE(ev) == GPH_MIG_BAND_START && A.start_or_end[i]) || ETYPE(ev) == GPH_MIG_BAND_END))
+      for (ev = FIRSTEV(tgtP); ev >= 0;) {
+        const GphEvS R = ld_ev(ev);
+        if (R.node == band &&
+            ((R.type == GPH_MIG_BAND_START && A.start_or_end[i]) || R.type == GPH_MIG_BAND_END))
           break;
         if (++guard > g_lay.E) { ev = -1; break; }
+        ev = R.next;
       }
       if (ev < 0) { gph_fail(74); break; }
       k = ISC(IS_RB_NUM);
@@ -603,7 +606,7 @@ GPH_DEV void tau_commit_body(gph_cfin &F)
     int guard = 0;
     ev = FIRSTEV(g_lay.rootPop);
     age = F.taunew;
-    while (ENEXT(ev) >= 0) { age += EVT(ev); ev = ENEXT(ev); if (++guard > g_lay.E) { gph_fail(97); break; } }
+    for (GphEvS R = ld_ev(ev); R.next >= 0; R = ld_ev(ev)) { age += R.time; ev = R.next; if (++guard > g_lay.E) { gph_fail(97); break; } }
     setEVT(ev, GPH_OLDAGE - age);
   }
 }
@@ -686,7 +689,7 @@ GPH_DEV void mix_commit_body(double c, double lnc)
     int guard = 0;
     ev = FIRSTEV(g_lay.rootPop);
     age = g_model.popAge[g_lay.rootPop];
-    while (ENEXT(ev) >= 0) { age += EVT(ev); ev = ENEXT(ev); if (++guard > g_lay.E) { gph_fail(97); break; } }
+    for (GphEvS R = ld_ev(ev); R.next >= 0; R = ld_ev(ev)) { age += R.time; ev = R.next; if (++guard > g_lay.E) { gph_fail(97); break; } }
     setEVT(ev, GPH_OLDAGE - age);
   }
 }

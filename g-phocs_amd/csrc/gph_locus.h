@@ -1334,8 +1334,9 @@ GPH_DEV int lik_spr(int subtreeRoot, int target, double age)
 {
   int targetFather = FATH(target);
   int father = FATH(subtreeRoot);
-  int grandpa = FATH(father);
-  int sibling = LEFT(father) + RGHT(father) - subtreeRoot;
+  const GphNodeS F_ = ld_node(father);
+  int grandpa = F_.father;
+  int sibling = F_.left + F_.right - subtreeRoot;
   lik_adjust_age(father, age);
   if (target == sibling || target == father) return 0;
   lik_save_node(sibling, 0);
@@ -1854,23 +1855,24 @@ GPH_DEVHOT double rubber_band(int pop, double age0, double static_point, double 
   while (UNI(age < end_time)) {
     if (ev == -1) { gph_fail(11); break; }
     if (++guard > g_lay.E) { gph_fail(95); break; }
-    dt = gmin2(EVT(ev), end_time - age);
+    const GphEvS R = ld_ev(ev);      /* every field of the interval with ONE LDS round trip (they were five) */
+    dt = gmin2(R.time, end_time - age);
     age += dt;
     if (!flag && UNI(age > start_time)) { flag = 1; dt = age - start_time; }
     if (flag) {
       dt *= fm1;
-      num_lins = ENLIN(ev);
+      num_lins = R.nlin;
       mig_delta = dt * num_lins;
       coal_delta += mig_delta * (num_lins - 1);
       lnLd -= mig_delta * mig_rate;
       if (post) {
-        setEVT(ev, EVT(ev) + dt);
+        setEVT(ev, R.time + dt);
         for (b = 0; b < live.n; b++) setMIGST(ll_get(live, b), MIGST(ll_get(live, b)) + mig_delta);
       }
     }
-    ty = ETYPE(ev);
+    ty = R.type;
     if (UNI(age >= end_time) && ty != GPH_SAMPLES_START) break;
-    node_id = ENODE(ev);
+    node_id = R.node;
     switch (ty) {
     case GPH_COAL:
       if (flag) {
@@ -1908,7 +1910,7 @@ GPH_DEVHOT double rubber_band(int pop, double age0, double static_point, double 
     case GPH_END_CHAIN: age = end_time; break;
     default: break;
     }
-    ev = ENEXT(ev);
+    ev = R.next;
   }
   if (post) setCOALS(pop, COALS(pop) + coal_delta);
   lnLd -= coal_delta / (g_model.theta[pop]);
@@ -1963,9 +1965,10 @@ GPH_DEVHOT int trace_lineage(int node, RNG &rng)
   pop = NPOP(node);
   if (node < g_lay.n) {
     ev = FIRSTEV(pop);
-    while (ETYPE(ev) != GPH_SAMPLES_START && ETYPE(ev) != GPH_END_CHAIN) ev = ENEXT(ev);
-    if (ETYPE(ev) == GPH_END_CHAIN) { gph_fail(101); setDI(inst, DI_NEV, 0); setSPRLN(RECONNECT, 0.0); return RECONNECT ? -1 : 0; }
-    ev = ENEXT(ev);
+    GphEvS S0 = ld_ev(ev);
+    while (S0.type != GPH_SAMPLES_START && S0.type != GPH_END_CHAIN) { ev = S0.next; S0 = ld_ev(ev); }
+    if (S0.type == GPH_END_CHAIN) { gph_fail(101); setDI(inst, DI_NEV, 0); setSPRLN(RECONNECT, 0.0); return RECONNECT ? -1 : 0; }
+    ev = S0.next;
   } else {
     ev = ENEXT(NEV(node));
   }
@@ -2271,11 +2274,14 @@ GPH_DEV int synchronize_events()
     int guard = 0;
     ev = FIRSTEV(pop);
     age = g_model.popAge[pop];
-    for (; ev >= 0; ev = ENEXT(ev)) {
+    int nxt_;
+    for (; ev >= 0; ev = nxt_) {
       if (++guard > g_lay.E) { gph_fail(97); return 0; }
-      id = ENODE(ev);
-      age += EVT(ev);
-      switch (ETYPE(ev)) {
+      const GphEvS R = ld_ev(ev);    /* one LDS round trip per event (this pass walks every chain of every locus once per iteration) */
+      nxt_ = R.next;
+      id = R.node;
+      age += R.time;
+      switch (R.type) {
       case GPH_SAMPLES_START: realAge = g_model.sampleAge[pop]; break;
       case GPH_COAL: realAge = AGE(id); break;
       case GPH_IN_MIG:
@@ -2289,7 +2295,7 @@ GPH_DEV int synchronize_events()
       default: realAge = age; break;
       }
       if (fabs(realAge - age) > PREC) res = 0;
-      et = EVT(ev) + (realAge - age);
+      et = R.time + (realAge - age);
       if (et < -PREC) res = 0;
       else if (et < 0.0) et = 0.0;
       setEVT(ev, et);
