@@ -1508,9 +1508,9 @@ GPH_DEV void remove_event(int ev, int pop)
   setENODE(ev, -1);
 }
 // createEventBefore, patch.c:1707-1742
-GPH_DEV int create_event_before(int pop, int ev, double elapsed)
+// R = the record of `ev` (the caller has just read it)
+GPH_DEVHOT int create_event_before(int pop, int ev, double elapsed, const GphEvS &R)
 {
-  const GphEvS R = ld_ev(ev);
   int pv = R.prev, nw = ISC(IS_FREE);
   const int fnext = ENEXT(nw);
   setISC(IS_FREE, fnext);
@@ -1526,6 +1526,7 @@ GPH_DEV int create_event_before(int pop, int ev, double elapsed)
   else setENEXT(pv, nw);
   return nw;
 }
+GPH_DEV int create_event_before(int pop, int ev, double elapsed) { return create_event_before(pop, ev, elapsed, ld_ev(ev)); }
 // createEvent, patch.c:1753-1802
 GPH_DEVHOT int create_event(int pop, double age)
 {
@@ -1547,7 +1548,7 @@ GPH_DEVHOT int create_event(int pop, double age)
     if (UNI(R.time < dt - 0.000001)) { gph_fail(18); return -1; }
     dt = R.time;
   }
-  return create_event_before(pop, ev, dt);
+  return create_event_before(pop, ev, dt, R);
 }
 
 // recalcStats, patch.c:2387-2513.  The reference also patches the global totals
@@ -1761,6 +1762,7 @@ GPH_DEVHOT double consider_event_move(int inst, int event_id, int source_pop, do
   int new_event, bottom_event, top_event, bottom_pop, dlin;
   double top_age, bottom_age, r;
   inst = RFL(inst); event_id = RFL(event_id); source_pop = RFL(source_pop); target_pop = RFL(target_pop);
+  const int ev_type = ETYPE(event_id);     /* (read once: creating the new event does not change the old one's type) */
   new_event = create_event(target_pop, new_age);
   if (new_event < 0) { gph_fail(13); return 0.0; }
   GPH_SLOG(2, event_id, source_pop, target_pop, original_age, new_age, new_event);   /* patch.c:1451-1454 */
@@ -1769,14 +1771,14 @@ GPH_DEVHOT double consider_event_move(int inst, int event_id, int source_pop, do
   setDI(inst, DI_SRCPOP, source_pop);
   setDI(inst, DI_TGTPOP, target_pop);
   if (new_age > original_age) {
-    dlin = (ETYPE(event_id) == GPH_OUT_MIG) ? (-1) : (1);
+    dlin = (ev_type == GPH_OUT_MIG) ? (-1) : (1);
     bottom_event = ENEXT(event_id);
     top_event = new_event;
     bottom_pop = source_pop;
     top_age = new_age;
     bottom_age = original_age;
   } else {
-    dlin = (ETYPE(event_id) == GPH_OUT_MIG) ? (1) : (-1);
+    dlin = (ev_type == GPH_OUT_MIG) ? (1) : (-1);
     bottom_event = ENEXT(new_event);
     top_event = event_id;
     bottom_pop = target_pop;
@@ -1787,7 +1789,7 @@ GPH_DEVHOT double consider_event_move(int inst, int event_id, int source_pop, do
   coal_stats_delta(inst, bottom_event, bottom_pop, top_event, dlin);
   mig_stats_delta(inst, bottom_age, bottom_pop, top_age, dlin);
   r = delta_lnld(inst);
-  if (ETYPE(event_id) == GPH_COAL && source_pop != target_pop)
+  if (ev_type == GPH_COAL && source_pop != target_pop)
     r += gph_log_u(g_model.theta[source_pop] / g_model.theta[target_pop]);
   return r;
 }
@@ -1814,12 +1816,13 @@ GPH_DEV void accept_event_chain_changes(int inst)
   GPH_EACH(k, i + 1) { const int q = gph_lds.s_dev[inst][k]; gph_lds.ev[q].nlin = (uint8_t)(gph_lds.ev[q].nlin + dlin); }
   ue = DI(inst, DI_UPD);
   if (ue >= 0) {
-    setENODE(ue, ENODE(oe));
-    setETYPE(ue, ETYPE(oe));
-    switch (ETYPE(ue)) {
-    case GPH_COAL: setNEV(ENODE(ue), ue); break;
-    case GPH_OUT_MIG: setMG(ENODE(ue), MG_SEV, ue); break;
-    case GPH_IN_MIG: setMG(ENODE(ue), MG_TEV, ue); break;
+    const GphEvS O_ = ld_ev(oe);       /* node and type of the original event: one LDS round trip */
+    setENODE(ue, O_.node);
+    setETYPE(ue, O_.type);
+    switch (O_.type) {
+    case GPH_COAL: setNEV(O_.node, ue); break;
+    case GPH_OUT_MIG: setMG(O_.node, MG_SEV, ue); break;
+    case GPH_IN_MIG: setMG(O_.node, MG_TEV, ue); break;
     default: gph_fail(14); break;
     }
     remove_event(oe, DI(inst, DI_SRCPOP));
