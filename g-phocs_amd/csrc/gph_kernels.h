@@ -96,13 +96,33 @@ GPH_DEV void stage_out(const GphDev &D, int g, char *pages, int unused)
     }
   }
 }
+// algorithmic bytes of the launch's useOld evaluations: 96 R P + 20 N + 8 U + 8 per evaluation that recomputed
+// anything -- derived ONCE here from the counters (recomputed nodes, evaluations, the empty ones) instead of being summed in
+// LDS by every evaluation: the same integers, a dozen instructions less per evaluation
+GPH_DEV double eval_bytes()
+{
+  const int P = CNT(CN_P), full = CNT(CN_EVALS) - CNT(CN_EMPTY);
+  if (P <= 0 || full <= 0) return 0.0;
+  const int q_phases = GPH_Q_PHASES(P, g_lay.n);
+  int U = 0;
+#ifdef GPH_HOSTEMU
+  for (int p = 0; p < P; p++) U += gu16v(q_phases, p) > 0;
+#else
+  for (int p0 = 0; p0 < P; p0 += GPH_WAVE) {
+    const int p = p0 + GPH_LANE;
+    U += __builtin_popcountll(__ballot(p < P && gu16v(q_phases, p < P ? p : 0) > 0));
+  }
+#endif
+  return (double)(96ll * (CNT(CN_NODES) - CNT(CN_NODES0)) * P + (long long)(20 * g_lay.N + 8 * U + 8) * full);
+}
 GPH_DEV void out_common(const GphDev &D, int g)
 {
+  const double bytes_ = eval_bytes();
   if (GPH_LANE == 0) {
     double *o = D.out + (size_t)g * GPH_OUT_SLOTS;
     o[8] = CNT(CN_EVALS);
     o[9] = CNT(CN_NODES);
-    o[10] = gf64(&GphLds::s_cntf, 0);
+    o[10] = bytes_;
     o[11] = gph_errcode();
     o[13] = CNT(CN_NOTENOUGH);
     if (gph_errcode() != 0) {
@@ -534,7 +554,7 @@ GPH_DEV void kb_tau_eval(const GphDev &D, int g, gph_ctau &A, int fuse)
         if (R.node == band &&
             ((R.type == GPH_MIG_BAND_START && A.start_or_end[i]) || R.type == GPH_MIG_BAND_END))
           break;
-        if (++guard > g_lay.E) { ev = -1; break; }
+        if (++guard > GPH_CAP_E) { ev = -1; break; }
         ev = R.next;
       }
       if (ev < 0) { gph_fail(74); break; }
@@ -606,7 +626,7 @@ GPH_DEV void tau_commit_body(gph_cfin &F)
     int guard = 0;
     ev = FIRSTEV(g_lay.rootPop);
     age = F.taunew;
-    for (GphEvS R = ld_ev(ev); R.next >= 0; R = ld_ev(ev)) { age += R.time; ev = R.next; if (++guard > g_lay.E) { gph_fail(97); break; } }
+    for (GphEvS R = ld_ev(ev); R.next >= 0; R = ld_ev(ev)) { age += R.time; ev = R.next; if (++guard > GPH_CAP_E) { gph_fail(97); break; } }
     setEVT(ev, GPH_OLDAGE - age);
   }
 }
@@ -689,7 +709,7 @@ GPH_DEV void mix_commit_body(double c, double lnc)
     int guard = 0;
     ev = FIRSTEV(g_lay.rootPop);
     age = g_model.popAge[g_lay.rootPop];
-    for (GphEvS R = ld_ev(ev); R.next >= 0; R = ld_ev(ev)) { age += R.time; ev = R.next; if (++guard > g_lay.E) { gph_fail(97); break; } }
+    for (GphEvS R = ld_ev(ev); R.next >= 0; R = ld_ev(ev)) { age += R.time; ev = R.next; if (++guard > GPH_CAP_E) { gph_fail(97); break; } }
     setEVT(ev, GPH_OLDAGE - age);
   }
 }

@@ -848,7 +848,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     setCNT(CN_EVALS, CNT(CN_EVALS) + 1);
   }
   const int root = ISC(IS_ROOT);
-  if (!((need >> root) & 1)) return FS(FS_DATALNL);
+  if (!((need >> root) & 1)) { if (useOld) setCNT(CN_EMPTY, CNT(CN_EMPTY) + 1); return FS(FS_DATALNL); }
   todo = need & internal;
   const int nord = __builtin_popcountll(todo);
   gdbl *cb = cond_base();
@@ -951,7 +951,6 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   /* root reduction, LocusDataLikelihood.c:466-479: per unphased pattern
    * log(sum over phases and bases / (4*phases)) * count, summed in pattern order */
   double lnl = 0.0;
-  int U;
   const gdbl *rc = cb + (((int)((cbit >> root) & 1) * (n - 1) + (root - n)) * P) * 4;
   if (!wide) {
     /* the root was computed last: its conditionals for pattern `lane` are q0..q3; only the further
@@ -982,7 +981,6 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       else avg = prob / nc;
       term = gph_log(avg) * GPH_PATCOUNT(q_count, lane);
     }
-    U = __builtin_popcountll(__ballot(ph > 0));
     if (g_lay.lds_sum && q_terms + 8 * ((P + 7) & ~7) <= g_lay.dyn_bytes) lnl = ordered_sum64_lds(term, P, q_terms);
     else lnl = ordered_sum64(term, P);
   } else {
@@ -997,12 +995,11 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       }
     }
     GPH_SYNC();
-    U = 0;
     for (int p = 0; p < P; p++)
-      if (gu16(q_phases, p) > 0) { lnl += gf64(q_terms, p); U++; }
+      if (gu16(q_phases, p) > 0) lnl += gf64(q_terms, p);
   }
   setFS(FS_DATALNL, lnl);
-  if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (double)(96 * nord * P + 20 * N + 8 * U + 8));
+  if (!useOld) setCNT(CN_NODES0, CNT(CN_NODES0) + nord);     /* (the algorithmic-byte count covers useOld evaluations: out_common) */
   STAMPB_END(4);
   return lnl;
 }
@@ -1016,7 +1013,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   const int n = g_lay.n, N = g_lay.N;
   (void)warm;
   useOld = RFL(useOld);
-  int P = CNT(CN_P), i, node, k, sp, nord, U;
+  int P = CNT(CN_P), i, node, k, sp, nord;
   gph_nset need = ns_none();
   double lnl;
   if (P == 0) return 0.0;
@@ -1040,7 +1037,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   }
   if (useOld) setCNT(CN_EVALS, CNT(CN_EVALS) + 1);
   node = ISC(IS_ROOT);
-  if (!ns_has(need, node)) return FS(FS_DATALNL);
+  if (!ns_has(need, node)) { if (useOld) setCNT(CN_EMPTY, CNT(CN_EMPTY) + 1); return FS(FS_DATALNL); }
   /* pre-order list of needed internal nodes */
   nord = 0;
   sp = 0;
@@ -1113,10 +1110,9 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       else avg = prob / nc;
       term = gph_log(avg) * GPH_PATCOUNT(q_count, lane);
     }
-    U = __builtin_popcountll(__ballot(ph > 0));
     lnl = ordered_sum64(term, P);
     setFS(FS_DATALNL, lnl);
-    if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (double)(96 * nord * P + 20 * N + 8 * U + 8));
+    if (!useOld) setCNT(CN_NODES0, CNT(CN_NODES0) + nord);
     return lnl;
   }
 #endif
@@ -1142,13 +1138,12 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     }
     GPH_SYNC();
     lnl = 0.0;
-    U = 0;
     for (p = 0; p < P; p++) {
-      if (gu16(q_phases, p) > 0) { lnl += gf64(q_terms, p); U++; }
+      if (gu16(q_phases, p) > 0) lnl += gf64(q_terms, p);
     }
   }
   setFS(FS_DATALNL, lnl);
-  if (useOld) sf64(&GphLds::s_cntf, 0, gf64(&GphLds::s_cntf, 0) + (double)(96 * nord * P + 20 * N + 8 * U + 8));
+  if (!useOld) setCNT(CN_NODES0, CNT(CN_NODES0) + nord);
   return lnl;
 }
 
@@ -1492,7 +1487,7 @@ GPH_DEV void remove_event(int ev, int pop)
   if (pv < 0) {
 #ifdef GPH_HOSTEMU
     int guard = 0;
-    for (pv = nx; ETYPE(pv) != GPH_END_CHAIN; pv = ENEXT(pv)) { if (++guard > g_lay.E || ENEXT(pv) < 0) { gph_fail(91); return; } }
+    for (pv = nx; ETYPE(pv) != GPH_END_CHAIN; pv = ENEXT(pv)) { if (++guard > GPH_CAP_E || ENEXT(pv) < 0) { gph_fail(91); return; } }
     if (ENODE(pv) != pop) { gph_fail(91); return; }
 #endif
     setFIRSTEV(pop, nx);
@@ -1540,7 +1535,7 @@ GPH_DEVHOT int create_event(int pop, double age)
   GphEvS R = ld_ev(ev);
   while (R.type != GPH_END_CHAIN && UNI(R.time < dt)) {
     dt -= R.time;
-    if (++guard > g_lay.E || R.next < 0) { gph_fail(92); return -1; }
+    if (++guard > GPH_CAP_E || R.next < 0) { gph_fail(92); return -1; }
     ev = R.next;
     R = ld_ev(ev);
   }
@@ -1564,7 +1559,7 @@ GPH_DEVHOT double recalc_stats(int pop)
   n = ENLIN(ev);
   int nxt;
   for (; ev >= 0; ev = nxt) {
-    if (++guard > g_lay.E) { gph_fail(93); return 0.0; }
+    if (++guard > GPH_CAP_E) { gph_fail(93); return 0.0; }
     const GphEvS R = ld_ev(ev);
     nxt = R.next;
     setENLIN(ev, n);
@@ -1725,7 +1720,7 @@ GPH_DEV void coal_stats_delta(int inst, int bottom_event, int bottom_pop, int to
   int guard = 0;
   setDPOPS(inst, 0, pop);
   while (ev >= 0) {
-    if (++guard > 2 * g_lay.E) { gph_fail(94); break; }
+    if (++guard > 2 * GPH_CAP_E) { gph_fail(94); break; }
     const GphEvS R = ld_ev(ev);
     acc += dlin * (dlin - 1 + 2 * R.nlin) * R.time;
     setDEV(inst, ne, ev);
@@ -1857,7 +1852,7 @@ GPH_DEVHOT double rubber_band(int pop, double age0, double static_point, double 
   int guard = 0;
   while (UNI(age < end_time)) {
     if (ev == -1) { gph_fail(11); break; }
-    if (++guard > g_lay.E) { gph_fail(95); break; }
+    if (++guard > GPH_CAP_E) { gph_fail(95); break; }
     const GphEvS R = ld_ev(ev);      /* every field of the interval with ONE LDS round trip (they were five) */
     dt = gmin2(R.time, end_time - age);
     age += dt;
@@ -2279,7 +2274,7 @@ GPH_DEV int synchronize_events()
     age = g_model.popAge[pop];
     int nxt_;
     for (; ev >= 0; ev = nxt_) {
-      if (++guard > g_lay.E) { gph_fail(97); return 0; }
+      if (++guard > GPH_CAP_E) { gph_fail(97); return 0; }
       const GphEvS R = ld_ev(ev);    /* one LDS round trip per event (this pass walks every chain of every locus once per iteration) */
       nxt_ = R.next;
       id = R.node;
@@ -2326,7 +2321,7 @@ GPH_DEV int check_gtree_structure()
     live.n = 0;
     int guard = 0;
     for (ev = FIRSTEV(pop); ev >= 0; ev = ENEXT(ev)) {
-      if (++guard > g_lay.E) { gph_fail(98); return 0; }
+      if (++guard > GPH_CAP_E) { gph_fail(98); return 0; }
       if (ENLIN(ev) != n) res = 0;
       if (ENEXT(ev) >= 0 && ev != EPREV(ENEXT(ev))) res = 0;
       id = ENODE(ev);

@@ -155,7 +155,8 @@ enum { DI_ORIG = 0, DI_UPD, DI_DLIN, DI_NEV, DI_NPOPS, DI_NBANDS, DI_SRCPOP, DI_
 enum { SI_FEV_OLD = 0, SI_FEV_NEW, SI_FPOP_NEW, SI_TARGET, SI_NOLD, SI_NNEW, SI_COUNT };
 enum { SA_OLD = 0, SA_NEWIN, SA_NEWOUT, SA_NEWBAND };
 // counters (s_cnt i32): evals, evalNodes, error, P, U ; (s_cntf f64): evalBytes
-enum { CN_EVALS = 0, CN_NODES, CN_ERROR, CN_P, CN_NOTENOUGH, CN_RX, CN_RY, CN_RZ, CN_COUNT };   // CN_RX..: the batched generator's state after its current batch
+enum { CN_EVALS = 0, CN_NODES, CN_ERROR, CN_P, CN_NOTENOUGH, CN_RX, CN_RY, CN_RZ, CN_EMPTY, CN_NODES0, CN_COUNT };   // CN_EMPTY: useOld evaluations that found nothing to recompute; CN_NODES0: nodes recomputed by useOld = 0 evaluations (both off the hot path: out_common derives the algorithmic bytes from them)
+//   // CN_RX..: the batched generator's state after its current batch
 
 // f64 scalars in the page (index into o_fscal)
 enum { FS_DATALNL = 0, FS_SV_DATALNL, FS_GENLNL, FS_GENDELTA, FS_MUTRATE, FS_COUNT };
