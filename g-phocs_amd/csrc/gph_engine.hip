@@ -454,6 +454,10 @@ static void build_model_static(gph_engine *e)
   G.tau_limit = (long long)1 << 62;
 }
 
+#ifdef GPH_WALKSTAT
+long long gph_ws[4];
+struct GphWsPrint { ~GphWsPrint() { fprintf(stderr, "WALKSTAT proposals %lld: prune steps %.2f, regraft steps %.2f, common prefix %.2f per proposal\n", gph_ws[3], (double)gph_ws[0] / gph_ws[3], (double)gph_ws[1] / gph_ws[3], (double)gph_ws[2] / gph_ws[3]); } } gph_ws_print;
+#endif
 // ---------------------------------------------------------------- runtime shim
 // the model in the kernel-argument segment (every build but the many-band one, whose kernels all read G->model)
 #if GPH_BIG_BANDS

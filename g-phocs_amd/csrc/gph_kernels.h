@@ -352,6 +352,11 @@ template <class RNG> GPH_DEV void sweep_spr(const GphDev &D, int g, RNG &rng)
     GPH_SLOG(5, node, father, father_pop_old, 0, 0, 0);
     { STAMPA_BEGIN(3); trace_lineage<0>(node, rng); STAMPA_END(3); }
     { STAMPA_BEGIN(4); res = trace_lineage<1>(node, rng); STAMPA_END(4); }
+#ifdef GPH_WALKSTAT
+    { extern long long gph_ws[4]; int n0 = DI(0, DI_NEV), n1 = DI(1, DI_NEV), c = 0;
+      while (c < n0 && c < n1 && gph_lds.s_dev[0][c] == gph_lds.s_dev[1][c]) c++;
+      gph_ws[0] += n0; gph_ws[1] += n1; gph_ws[2] += c; gph_ws[3] += 1; }
+#endif
     lnLd = -FS(FS_DATALNL);
     { STAMP_BEGIN(1); lnLd += lik_compute(1); STAMP_END(1); }
     lnacc = lnLd;
