@@ -350,8 +350,12 @@ template <class RNG> GPH_DEV void sweep_spr(const GphDev &D, int g, RNG &rng)
       father_pop_old = F_.npop;
       sibling = F_.left + F_.right - node; }
     GPH_SLOG(5, node, father, father_pop_old, 0, 0, 0);
+#if GPH_BIG_BANDS || defined(GPH_TWO_WALKS)
     { STAMPA_BEGIN(3); trace_lineage<0>(node, rng); STAMPA_END(3); }
     { STAMPA_BEGIN(4); res = trace_lineage<1>(node, rng); STAMPA_END(4); }
+#else
+    { STAMPA_BEGIN(3); res = trace_pair(node, rng); STAMPA_END(3); }      /* both walks, their common prefix once (gph_locus.h) */
+#endif
 #ifdef GPH_WALKSTAT
     { extern long long gph_ws[4]; int n0 = DI(0, DI_NEV), n1 = DI(1, DI_NEV), c = 0;
       while (c < n0 && c < n1 && gph_lds.s_dev[0][c] == gph_lds.s_dev[1][c]) c++;
