@@ -1325,6 +1325,9 @@ GPH_DEV double lik_scale_ages(double factor)
 }
 
 // executeGenSPR, LocusDataLikelihood.c:931-1012
+// The node sets of the saved version (recomputed / current half / saved record) are read from the scalar pad ONCE, updated in
+// scalar registers for the up to five nodes an SPR saves, and written back once (every copyNodeToSaved /
+// copyNodeConditionals used to be its own read-modify-write of the pad: a dozen lane reads / writes per node)
 GPH_DEV int lik_spr(int subtreeRoot, int target, double age)
 {
   int targetFather = FATH(target);
@@ -1332,35 +1335,48 @@ GPH_DEV int lik_spr(int subtreeRoot, int target, double age)
   const GphNodeS F_ = ld_node(father);
   int grandpa = F_.father;
   int sibling = F_.left + F_.right - subtreeRoot;
-  lik_adjust_age(father, age);
-  if (target == sibling || target == father) return 0;
-  lik_save_node(sibling, 0);
-  setFATH(sibling, grandpa);
-  if (grandpa >= 0) {
-    lik_save_node(grandpa, 1);
-    if (LEFT(grandpa) == father) setLEFT(grandpa, sibling);
-    else setRGHT(grandpa, sibling);
+  gph_nset dirty = NS_GET(IS_DIRTY0), cbit = NS_GET(IS_CBIT0), saved = NS_GET(IS_SAVED0);
+  const bool hasP = CNT(CN_P) > 0;
+  int ret = 0;
+#define SPR_MARK(node) do { if (hasP && !ns_has(dirty, (node))) { dirty = ns_with(dirty, (node)); cbit = ns_flip(cbit, (node)); } } while (0)
+#define SPR_SAVE(node, recalc) do { if (recalc) SPR_MARK(node); saved = ns_with(saved, (node)); gph_lds.sv[node] = gph_lds.nd[node]; } while (0)
+  SPR_SAVE(father, 1);              /* adjustGenNodeAge(father, age) */
+  setAGE(father, age);
+  if (!(target == sibling || target == father)) {
+    SPR_SAVE(sibling, 0);
+    setFATH(sibling, grandpa);
+    if (grandpa >= 0) {
+      SPR_SAVE(grandpa, 1);
+      if (LEFT(grandpa) == father) setLEFT(grandpa, sibling);
+      else setRGHT(grandpa, sibling);
+    }
+    setFATH(father, targetFather);
+    setLEFT(father, subtreeRoot);
+    setRGHT(father, target);
+    if (target != grandpa) SPR_SAVE(target, 0);
+    setFATH(target, father);
+    if (targetFather < 0) {
+      setISC(IS_SV_ROOT, target);
+      setISC(IS_ROOT, father);
+      ret = 1;
+    } else {
+      if (targetFather == sibling) SPR_MARK(targetFather);
+      else if (targetFather != grandpa) SPR_SAVE(targetFather, 1);
+      if (LEFT(targetFather) == target) setLEFT(targetFather, father);
+      else setRGHT(targetFather, father);
+      if (grandpa < 0) {
+        setISC(IS_SV_ROOT, father);
+        setISC(IS_ROOT, sibling);
+        ret = 2;
+      }
+    }
   }
-  setFATH(father, targetFather);
-  setLEFT(father, subtreeRoot);
-  setRGHT(father, target);
-  if (target != grandpa) lik_save_node(target, 0);
-  setFATH(target, father);
-  if (targetFather < 0) {
-    setISC(IS_SV_ROOT, target);
-    setISC(IS_ROOT, father);
-    return 1;
-  }
-  if (targetFather == sibling) lik_mark_cond(targetFather);
-  else if (targetFather != grandpa) lik_save_node(targetFather, 1);
-  if (LEFT(targetFather) == target) setLEFT(targetFather, father);
-  else setRGHT(targetFather, father);
-  if (grandpa < 0) {
-    setISC(IS_SV_ROOT, father);
-    setISC(IS_ROOT, sibling);
-    return 2;
-  }
-  return 0;
+#undef SPR_MARK
+#undef SPR_SAVE
+  NS_PUT(IS_DIRTY0, dirty);
+  NS_PUT(IS_CBIT0, cbit);
+  NS_PUT(IS_SAVED0, saved);
+  return ret;
 }
 
 // ---------------------------------------------------------------- migration-node lookups
