@@ -992,16 +992,7 @@ GPH_DEVHOT double lr_ref_eval(const GphLrArgs &A, const GphRefProg &R, int P, do
   prob += q1;
   prob += q2;
   prob += q3;
-  for (int k = 1; __ballot(ph > k) != 0; k++) {
-    const int src = ((lane + k) & (GPH_WAVE - 1)) << 2;
-    const double r0 = bperm64(src, q0), r1 = bperm64(src, q1), r2 = bperm64(src, q2), r3 = bperm64(src, q3);
-    if (ph > k) {
-      prob += r0;
-      prob += r1;
-      prob += r2;
-      prob += r3;
-    }
-  }
+  prob = add_phases(prob, ph, q0, q1, q2, q3);
   if (ph > 0) {
     const int nc = 4 * ph;
     double avg;

@@ -613,13 +613,33 @@ GPH_DEV void prune_node(int node)
 #define GPH_LANE_NODES 0
 #endif
 #ifndef GPH_HOSTEMU
-GPH_DEV double bperm64(int byteaddr, double v)
+// the next lane's value (lane i <- lane i + 1, the last lane gets 0): two v_mov_b32_dpp wave_shl:1 -- VALU register moves,
+// against two ds_bpermute_b32 (an LDS-pipe instruction and a crossbar round trip each; tools/probe/dpp_probe.cpp has the
+// direction check on gfx950)
+GPH_DEV double dpp_next64(double v)
 {
   union { double d; int32_t i[2]; } u;
   u.d = v;
-  u.i[0] = __builtin_amdgcn_ds_bpermute(byteaddr, u.i[0]);
-  u.i[1] = __builtin_amdgcn_ds_bpermute(byteaddr, u.i[1]);
+  u.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x130, 0xf, 0xf, true);
+  u.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x130, 0xf, 0xf, true);
   return u.d;
+}
+// the further phases of an unphased pattern (LocusDataLikelihood.c:466-479): the rows after pattern `lane` of the root's
+// conditionals sit in the NEXT lanes' registers q0..q3 (rows of one pattern are adjacent, all below P <= 64); every round
+// moves the four values one lane down and the lanes that still have a phase add them in the reference's order (phase
+// by phase, base by base)
+GPH_DEVHOT double add_phases(double prob, int ph, double q0, double q1, double q2, double q3)
+{
+  for (int k = 1; __ballot(ph > k) != 0; k++) {
+    q0 = dpp_next64(q0); q1 = dpp_next64(q1); q2 = dpp_next64(q2); q3 = dpp_next64(q3);
+    if (ph > k) {
+      prob += q0;
+      prob += q1;
+      prob += q2;
+      prob += q3;
+    }
+  }
+  return prob;
 }
 // sum of term[0..P-1] in lane order, P <= 64 (lanes >= P and lanes without a term hold +0.0: x + 0.0 == x bit for
 // bit, and the running sum is never -0.0): two lane reads with a constant lane + one add per pattern, no mask
@@ -961,18 +981,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     prob += q1;
     prob += q2;
     prob += q3;
-    /* further phases: the next lanes' registers, fetched lane-to-lane (no store->load round trip),
-     * added in the reference's order (phase by phase, base by base) */
-    for (int k = 1; __ballot(ph > k) != 0; k++) {
-      const int src = ((lane + k) & (GPH_WAVE - 1)) << 2;
-      const double r0 = bperm64(src, q0), r1 = bperm64(src, q1), r2 = bperm64(src, q2), r3 = bperm64(src, q3);
-      if (ph > k) {
-        prob += r0;
-        prob += r1;
-        prob += r2;
-        prob += r3;
-      }
-    }
+    prob = add_phases(prob, ph, q0, q1, q2, q3);
     if (ph > 0) {
       const int nc = 4 * ph;
       /* phase counts are powers of two upstream (2^hets): the division is an exact exponent shift */
@@ -1093,16 +1102,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     prob += q1;
     prob += q2;
     prob += q3;
-    for (int k2 = 1; __ballot(ph > k2) != 0; k2++) {
-      const int src = ((lane + k2) & (GPH_WAVE - 1)) << 2;
-      const double r0 = bperm64(src, q0), r1 = bperm64(src, q1), r2 = bperm64(src, q2), r3 = bperm64(src, q3);
-      if (ph > k2) {
-        prob += r0;
-        prob += r1;
-        prob += r2;
-        prob += r3;
-      }
-    }
+    prob = add_phases(prob, ph, q0, q1, q2, q3);
     if (ph > 0) {
       const int nc = 4 * ph;
       double avg;
@@ -1229,16 +1229,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
     prob += q1;
     prob += q2;
     prob += q3;
-    for (int k = 1; __ballot(ph > k) != 0; k++) {
-      const int src = ((lane + k) & (GPH_WAVE - 1)) << 2;
-      const double r0 = bperm64(src, q0), r1 = bperm64(src, q1), r2 = bperm64(src, q2), r3 = bperm64(src, q3);
-      if (ph > k) {
-        prob += r0;
-        prob += r1;
-        prob += r2;
-        prob += r3;
-      }
-    }
+    prob = add_phases(prob, ph, q0, q1, q2, q3);
     if (ph > 0) {
       const int nc = 4 * ph;
       double avg;

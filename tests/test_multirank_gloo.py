@@ -12,6 +12,14 @@ import pytest
 from conftest import GOLDEN, REPO
 from parity_util import compare_records
 
+
+def _free_port():
+    """a port nobody listens on right now (tests of this file may run side by side under pytest -n)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, %(repo)r); sys.path.insert(0, os.path.join(%(repo)r, "tests", "hostemu"))
@@ -60,7 +68,7 @@ def test_two_ranks_equal_one_rank(name, iters, presharded, world, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % dict(repo=REPO, pack=os.path.join(GOLDEN, name + ".gpk"), out=out, iters=iters,
                                       presharded=presharded))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
@@ -87,7 +95,7 @@ def test_program_over_two_ranks(tmp_path, name):
     lib = R.build_hostemu()
     for ext in (".ctl", ".seq"):
         shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="2")
     cmd = [sys.executable, os.path.join(REPO, "tools", "run_multi_gpu.py"), name + ".ctl", "--backend", "gloo", "--lib", lib]
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=tmp_path) for r in range(2)]
     for p in procs:

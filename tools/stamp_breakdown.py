@@ -12,8 +12,8 @@ os.makedirs(os.path.dirname(lib_path), exist_ok=True)
 srcs = [os.path.join(G.CSRC, f) for f in G.LIB_SOURCES]
 deps = [os.path.join(G.CSRC, f) for f in os.listdir(G.CSRC)]
 if not os.path.exists(lib_path) or any(os.path.getmtime(d) > os.path.getmtime(lib_path) for d in deps):
-    subprocess.run(["hipcc"] + G.HIPCC_FLAGS + [f"-DGPH_STAMPS={MODE}", "-DGPH_CAP_LEAVES=16", "-DGPH_CAP_K=9", "-DGPH_CAP_B=4",
-                                                "-DGPH_SWEEP_WAVES=6"] + srcs + ["-o", lib_path], check=True)
+    subprocess.run(["hipcc"] + G.HIPCC_BASE + G.HIPCC_TUNING_SPILLING + [f"-DGPH_STAMPS={MODE}", "-DGPH_CAP_LEAVES=16", "-DGPH_CAP_K=9", "-DGPH_CAP_B=4",
+                                                "-DGPH_SWEEP_WAVES=8"] + srcs + ["-o", lib_path], check=True)
 if "--build-only" in sys.argv:
     sys.exit(0)
 lib = G.load_library(lib_path)
@@ -21,12 +21,13 @@ L = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100000
 pack = bench.build_workload(G, 4, L, 6.5, 20261006, os.path.join(REPO, "bench_cache"))
 s = G.Sampler(pack, lib=lib)
 s.initialize()
-for it in range(2):
+PRE = int(os.environ.get('PRE', '100'))      # leave the prior-sampled start of the chain (as bench.py's pre-roll does)
+for it in range(PRE):
     s.iteration(it)
 r = G.GphSweepResult()
 lib.gph_engine_genealogy_sweep(s.engine, 7, pack.ftCoalTime, pack.ftMigTime, C.byref(r))
 # in the stamps build the sweep result fields carry cycle sums (see kb_sweep)
-names = ["kernel body", "lik_compute", "consider_event_move", "trace_lineage<0>", "trace_lineage<1>",
+names = ["kernel body", "lik_compute", "consider_event_move", "trace_pair (both lineage walks)", "(unused)",
          "internal sweep", "spr sweep", "prune_node (inside lik_compute)"]
 if MODE == 3:
     names[2:5] = ["SPR accept path", "SPR reject path", "migration-node sweep"]
