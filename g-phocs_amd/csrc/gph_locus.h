@@ -1398,14 +1398,22 @@ GPH_DEV int find_first_mig(int node, double age)
 GPH_DEV void mig_bounds(int inode, int left, int right, int &first_up, int &last_l, int &last_r)
 {
   int i, mig, br, nm = ISC(IS_NUM_MIGS);
-  first_up = last_l = last_r = -1;
+  /* three scalars updated by selects: with one conditional store per result the compiler sinks the three stores into ONE
+   * through a selected address, which turns the results into a stack array -- scratch memory in the bounds of every node */
+  int fu = -1, ll = -1, lr = -1;
   for (i = 0; i < nm; i++) {
     mig = LIVING(i);
     br = MG(mig, MG_BRANCH);
-    if (br == inode) { if (MAGE(mig) > -1 && (first_up < 0 || MAGE(mig) < MAGE(first_up))) first_up = mig; }
-    else if (br == left) { if (last_l < 0 || MAGE(mig) > MAGE(last_l)) last_l = mig; }
-    else if (br == right) { if (last_r < 0 || MAGE(mig) > MAGE(last_r)) last_r = mig; }
+    const bool up = br == inode, lf = !up && br == left, rt = !up && !lf && br == right;
+    if (!(up || lf || rt)) continue;
+    const int cur = up ? fu : lf ? ll : lr;
+    const double a = MAGE(mig);
+    bool take = cur < 0;
+    if (!take) take = up ? a < MAGE(cur) : a > MAGE(cur);
+    if (up && !(a > -1)) take = false;
+    if (take) { fu = up ? mig : fu; ll = lf ? mig : ll; lr = rt ? mig : lr; }
   }
+  first_up = fu; last_l = ll; last_r = lr;
 }
 // getEdgesForTimePop, patch.c:526-571 (targets written to s_targets, increasing node id).
 // Device form: one lane per genealogy node evaluates the membership test, a ballot yields the
