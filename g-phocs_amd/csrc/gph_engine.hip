@@ -439,7 +439,7 @@ static void build_model_static(gph_engine *e)
   }
   int cum = 0;
   for (int p = 0; p < c.Kc; p++) { m.samplesPerPop[p] = e->samplesPerPop[p]; cum += e->samplesPerPop[p]; m.cumSamples[p] = cum; }
-  for (int b = 0; b < c.B; b++) { m.bandSrc[b] = e->bandSrc[b]; m.bandTgt[b] = e->bandTgt[b]; }
+  for (int b = 0; b < c.B; b++) { m.bandSrc[b] = e->bandSrc[b]; m.bandTgt[b] = e->bandTgt[b]; m.bandsInto[e->bandTgt[b]][b >> 5] |= 1u << (b & 31); }
   for (int p = 0; p < c.K; p++)
     for (int b = 0; b < c.B; b++) if ((m.isAnc[e->bandTgt[b]] >> p) & 1) m.bandsOver[p][b >> 5] |= 1u << (b & 31);
   // populationPostOrder(rootPop), patch.c:1936-1951
@@ -1527,7 +1527,7 @@ const char *gph_runtime_version(void)
 // into the test builds only (GPH_LOGSTEPS: the host build of tests/hostemu and libgphocs_hip_plain.so).
 int gph_engine_steplog_enable(gph_engine *e, const int64_t *loci, int32_t n, int32_t cap)
 {
-#ifndef GPH_LOGSTEPS
+#if !defined(GPH_LOGSTEPS) && !defined(GPH_BBCOUNT)    /* (GPH_BBCOUNT: tools/bbcount.sh borrows the record buffer for basic-block counters) */
   (void)e; (void)loci; (void)n; (void)cap;
   return GPH_EARG;      /* not compiled into this build of the library */
 #else
@@ -1556,7 +1556,7 @@ int gph_engine_steplog_enable(gph_engine *e, const int64_t *loci, int32_t n, int
 // written by the kernels, which may exceed the capacity given to _enable); reset != 0 empties the buffer
 int gph_engine_steplog_fetch(gph_engine *e, int32_t idx, double *out, int32_t max_records, int32_t *nrec, int32_t reset)
 {
-#ifndef GPH_LOGSTEPS
+#if !defined(GPH_LOGSTEPS) && !defined(GPH_BBCOUNT)
   (void)e; (void)idx; (void)out; (void)max_records; (void)nrec; (void)reset;
   return GPH_EARG;
 #else
@@ -1566,6 +1566,9 @@ int gph_engine_steplog_fetch(gph_engine *e, int32_t idx, double *out, int32_t ma
   int32_t n = 0;
   if (d2h(e, &n, e->dev.slog_n + idx, sizeof n)) return GPH_EHIP;
   *nrec = n;
+#ifdef GPH_BBCOUNT
+  n = e->dev.slog_cap;       /* the whole buffer: it holds counters, not records */
+#endif
   const int32_t m = std::min(std::min(n, e->dev.slog_cap), max_records);
   if (out && m > 0 && d2h(e, out, e->dev.slog + (size_t)idx * e->dev.slog_cap * 8, sizeof(double) * 8 * (size_t)m)) return GPH_EHIP;
   if (reset) { const int32_t z = 0; if (h2d(e, e->dev.slog_n + idx, &z, sizeof z)) return GPH_EHIP; }

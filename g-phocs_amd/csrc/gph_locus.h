@@ -842,7 +842,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   useOld = RFL(useOld);
   const int P = CNT(CN_P);
   if (P == 0) return 0.0;
-  const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n, g_lay.cnt16);
+  const int q_phases = CNT(CN_QPH), q_count = CNT(CN_QCNT), q_terms = CNT(CN_QTERMS);
   (void)q_terms;
   STAMPB_BEGIN(2);
   const bool isnode = lane < N;
@@ -914,12 +914,12 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   STAMPB_END(2);
   /* the two mappings are separate loops (the choice is per locus): the per-pattern one keeps the conditionals of the
    * node just computed in registers from step to step, and its loop must stay simple enough for that */
-  bool failed = false;
+  bool bad = false;
   if (wide) {
     for (int guard = 0; todo != 0; guard++) {
       bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
       uint64_t rmask = __ballot(rdy);
-      if (rmask == 0 || guard > N) { failed = true; break; }
+      if (rmask == 0 || guard > N) { gph_fail(100); return FS(FS_DATALNL); }
       while (rmask) {
         const int node = __builtin_ctzll(rmask);
         const uint64_t bit = (uint64_t)1 << node;
@@ -936,7 +936,10 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     /* one node per step.  Usual case: a dirty path is a chain, the next node is the father of the one just
      * computed (whose conditionals are still in registers) -- three lane reads and a bit test.  Otherwise
      * (start, or the father waits for its other subtree) any node whose recomputed children are done. */
-    int guard = 0;
+    /* ONE exit: every step takes a node off `todo`, so the loop ends whatever the tree looks like; a step that finds no
+     * ready node (a corrupted tree) takes the lowest one and the failure is reported behind the loop.  (As a `break` or a
+     * `return` the check was a second exit, and the structurizer -- this loop contains the lane-masked store -- paid for
+     * it with an exit flag set, inverted and tested in EVERY step.) */
     while (todo != 0) {
       int node = -1, l = 0, r = 0;
       if (prev >= 0) {
@@ -950,8 +953,8 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       }
       if (node < 0) {
         bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
-        const uint64_t rmask = __ballot(rdy);
-        if (rmask == 0 || ++guard > N) { failed = true; break; }
+        uint64_t rmask = __ballot(rdy);
+        if (rmask == 0) { bad = true; rmask = todo; }
         node = __builtin_ctzll(rmask);
         l = __builtin_amdgcn_readlane(le, node);
         r = __builtin_amdgcn_readlane(ri, node);
@@ -965,7 +968,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       prev = node;
     }
   }
-  if (failed) { gph_fail(100); return FS(FS_DATALNL); }
+  if (bad) { gph_fail(100); return FS(FS_DATALNL); }
   setCNT(CN_NODES, CNT(CN_NODES) + nord);
   STAMPB_BEGIN(4);
   /* root reduction, LocusDataLikelihood.c:466-479: per unphased pattern
@@ -1026,7 +1029,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   gph_nset need = ns_none();
   double lnl;
   if (P == 0) return 0.0;
-  const int q_phases = GPH_Q_PHASES(P, n), q_count = GPH_Q_COUNT(P, n), q_terms = GPH_Q_TERMS(P, n, g_lay.cnt16);
+  const int q_phases = CNT(CN_QPH), q_count = CNT(CN_QCNT), q_terms = CNT(CN_QTERMS);
   if (!useOld)
     for (node = n; node < N; node++) lik_mark_cond(node);
   setFS(FS_SV_DATALNL, FS(FS_DATALNL));
@@ -1962,6 +1965,24 @@ GPH_DEV double rubber_band_ripple(int do_or_redo)
   return delta;
 }
 
+// the migration bands a lineage in population `pop` at time `age` is exposed to (patch.c:934-944, 1285-1294: a scan of all
+// bands for target == pop and start < age < end, strict at the start of a walk, start <= age after a migration event),
+// in increasing band order: only the bands whose target IS `pop` are looked at (GphModel.bandsInto) -- most populations
+// have none, and the scan of every band cost a scalar load and a dozen instructions per band at the start of every walk
+GPH_DEV void live_bands_into(int pop, double age, bool strict, LiveList &live, double &mig_rate)
+{
+  for (int w = 0; w < GPH_BANDW; w++) {
+    for (uint32_t m = g_model.bandsInto[pop][w]; m != 0; m &= m - 1) {
+      const int b = 32 * w + __builtin_ctz(m);
+      const double st = g_model.bandStart[b];
+      if ((strict ? st < age : st <= age) && g_model.bandEnd[b] > age) {
+        mig_rate += g_model.migRate[b];
+        ll_push(live, b);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- traceLineage
 // traceLineage, patch.c:886-1331.  RECONNECT == 0: walk the existing edge above
 // `node`, removing one lineage; RECONNECT == 1: re-sample its path from the prior
@@ -2014,12 +2035,7 @@ GPH_DEVHOT int trace_lineage(int node, RNG &rng, const GphWalkResume *rs = nullp
   GPH_EACH1(k, g_lay.K) { gph_lds.s_dpops[inst][k] = (int16_t)k; gph_lds.s_dcoal[inst][k] = 0.0; }
   GPH_EACH1(k, g_lay.B) { gph_lds.s_dbands[inst][k] = (int16_t)k; gph_lds.s_dmig[inst][k] = 0.0; }
   mig_rate = 0.0;
-  for (b = 0; b < g_lay.B; b++) {
-    if (g_model.bandTgt[b] == pop && g_model.bandStart[b] < age && g_model.bandEnd[b] > age) {
-      mig_rate += g_model.migRate[b];
-      ll_push(live, b);
-    }
-  }
+  live_bands_into(pop, age, true, live, mig_rate);
   mig_source = -1;
   proceed = 1;
   /* per step every field of the current interval is read ONCE into registers (the LDS image is only
@@ -2144,12 +2160,7 @@ GPH_DEVHOT int trace_lineage(int node, RNG &rng, const GphWalkResume *rs = nullp
         thinv = g_model.thetaInv[pop];
         mig_rate = 0.0;
         live.n = 0;
-        for (b = 0; b < g_lay.B; b++) {
-          if (g_model.bandTgt[b] == pop && g_model.bandStart[b] <= age && g_model.bandEnd[b] > age) {
-            mig_rate += g_model.migRate[b];
-            ll_push(live, b);
-          }
-        }
+        live_bands_into(pop, age, false, live, mig_rate);
         ev = ENEXT(mig_source);
         mig_source = -1;
       } else {
@@ -2223,12 +2234,7 @@ GPH_DEVHOT int trace_lineage(int node, RNG &rng, const GphWalkResume *rs = nullp
       thinv = g_model.thetaInv[pop];
       mig_rate = 0.0;
       live.n = 0;
-      for (b = 0; b < g_lay.B; b++) {
-        if (g_model.bandTgt[b] == pop && g_model.bandStart[b] <= age && g_model.bandEnd[b] > age) {
-          mig_rate += g_model.migRate[b];
-          ll_push(live, b);
-        }
-      }
+      live_bands_into(pop, age, false, live, mig_rate);
       ev = ENEXT(mig_source);
       mig_source = -1;
     } else {
@@ -2312,20 +2318,20 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
   GPH_EACH1(k, g_lay.K) { gph_lds.s_dpops[0][k] = (int16_t)k; gph_lds.s_dcoal[0][k] = 0.0; gph_lds.s_dpops[1][k] = (int16_t)k; gph_lds.s_dcoal[1][k] = 0.0; }
   GPH_EACH1(k, g_lay.B) { gph_lds.s_dbands[0][k] = (int16_t)k; gph_lds.s_dmig[0][k] = 0.0; gph_lds.s_dbands[1][k] = (int16_t)k; gph_lds.s_dmig[1][k] = 0.0; }
   mig_rate = 0.0;
-  for (b = 0; b < g_lay.B; b++) {
-    if (g_model.bandTgt[b] == pop && g_model.bandStart[b] < age && g_model.bandEnd[b] > age) {
-      mig_rate += g_model.migRate[b];
-      ll_push(live, b);
-    }
-  }
+  live_bands_into(pop, age, true, live, mig_rate);
   const int fev_old = SPRI(SI_FEV_OLD);
   dcoal = DCOAL(0, pop);
   int both = 1;                 /* the prior-sampling walk is still on this walk's interval */
   GphWalkResume rs;
+  /* a failed consistency check leaves the function from inside the loop (the sticky error aborts the run): as `break`s the
+   * three checks were three more exits whose live-out values met the normal exit's behind the loop, and the register
+   * allocator paid for that with two dozen copies at the head of EVERY interval (tools/bbcount.sh, round 4).  (Raising a
+   * flag that the loop condition tests instead -- one exit, no exit flag in the latch -- measured the same: not kept.) */
+#define GPH_WALK_ABORT() do { setDI(0, DI_NEV, 0); setSPRLN(0, 0.0); setDI(1, DI_NEV, 0); setSPRLN(1, 0.0); return -1; } while (0)
   while (proceed) {
-    if (nev >= GPH_CAP_E) { gph_fail(96); break; }
+    if (nev >= GPH_CAP_E) { gph_fail(96); GPH_WALK_ABORT(); }
     if (ev < 0) {
-      if (g_model.popFather[pop] < 0) { gph_fail(6); break; }
+      if (g_model.popFather[pop] < 0) { gph_fail(6); GPH_WALK_ABORT(); }
       setDCOAL(0, pop, dcoal);
       if (both) setDCOAL(1, pop, dcoal);
       pop = g_model.popFather[pop];
@@ -2334,7 +2340,7 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
       thinv = g_model.thetaInv[pop];
       ev = FIRSTEV(pop);
       mig_rate = 0.0;
-      if (fabs(age / g_model.popAge[pop] - 1) > 0.01) { gph_fail(8); break; }
+      if (fabs(age / g_model.popAge[pop] - 1) > 0.01) { gph_fail(8); GPH_WALK_ABORT(); }
       age = g_model.popAge[pop];
     }
     const GphEvS R = ld_ev(ev);
@@ -2394,12 +2400,7 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
       thinv = g_model.thetaInv[pop];
       mig_rate = 0.0;
       live.n = 0;
-      for (b = 0; b < g_lay.B; b++) {
-        if (g_model.bandTgt[b] == pop && g_model.bandStart[b] <= age && g_model.bandEnd[b] > age) {
-          mig_rate += g_model.migRate[b];
-          ll_push(live, b);
-        }
-      }
+      live_bands_into(pop, age, false, live, mig_rate);
       ev = ENEXT(mig_source);
       mig_source = -1;
     } else {
@@ -2426,6 +2427,7 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
     walk_unpark(rs);
   }
   return trace_lineage<1, RNG, true>(node, rng, &rs);
+#undef GPH_WALK_ABORT
 }
 #endif
 

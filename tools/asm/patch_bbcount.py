@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Assembly-level instrumentation of k_sweep: a counter per basic block (tools/bbcount.sh).
+   patch_bbcount.py in.s out.s
+Every basic block of the kernel (labels .LBB1_N and the label-less fall-through blocks `; %bb.N:`) gets
+   save exec; exec = lane 0; global_atomic_add counters[N], 1; s_waitcnt vmcnt(0); restore exec
+on registers the kernel does not use (v64, v65, s[82:85]; the kernel descriptor is widened to 72 VGPRs / 88 SGPRs -- occupancy
+does not matter for counting).  The counters live in the decision-transcript buffer of the engine (GphDev.slog, kernel
+argument offset 0xd80 of k_sweep; allocated by gph_engine_steplog_enable in a -DGPH_BBCOUNT build).  The wait after the
+atomic keeps the kernel's own vmcnt bookkeeping exact (nothing of the instrumentation is outstanding when its code goes on)."""
+import re
+import sys
+
+KERNEL = "_Z7k_sweep8GphKargs6GphDeviidddd"
+SLOG_KERNARG_OFFSET = 0xd80      # kernarg offset of GphDev (3344) + offsetof(GphDev, slog) (112)
+
+
+def snippet(n):
+    return ["\ts_mov_b64 s[84:85], exec", "\ts_mov_b64 exec, 1", f"\tv_mov_b32_e32 v64, {4 * n}",
+            "\tglobal_atomic_add v64, v65, s[82:83]", "\ts_waitcnt vmcnt(0)", "\ts_mov_b64 exec, s[84:85]"]
+
+
+def main():
+    src = open(sys.argv[1]).read().split("\n")
+    out, inside, nblocks, desc = [], False, 0, None
+    for ln in src:
+        if ln.startswith(KERNEL + ":"):
+            inside = True
+        if inside and ln.startswith(".Lfunc_end"):
+            inside = False
+        out.append(ln)
+        t = ln.strip()
+        if t.startswith(".amdhsa_kernel "):
+            desc = t.split()[1]
+        if desc == KERNEL:
+            if t == ".amdhsa_next_free_vgpr 64":
+                out[-1] = "\t\t.amdhsa_next_free_vgpr 72"
+            elif t == ".amdhsa_accum_offset 64":
+                out[-1] = "\t\t.amdhsa_accum_offset 72"
+            elif t.startswith(".amdhsa_next_free_sgpr"):
+                out[-1] = "\t\t.amdhsa_next_free_sgpr 88"
+        if t == ".end_amdhsa_kernel":
+            desc = None
+        if not inside:
+            continue
+        m = re.match(r"^\.LBB1_(\d+):", ln) or re.match(r"^; %bb\.(\d+):", ln)
+        if m:
+            n = int(m.group(1))
+            if n == 0:
+                out += [f"\ts_load_dwordx2 s[82:83], s[0:1], {hex(SLOG_KERNARG_OFFSET)}", "\tv_mov_b32_e32 v65, 1", "\ts_waitcnt lgkmcnt(0)"]
+            out += snippet(n)
+            nblocks += 1
+    open(sys.argv[2], "w").write("\n".join(out))
+    print(f"patch_bbcount: {nblocks} basic blocks of {KERNEL} instrumented", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
