@@ -5,13 +5,22 @@ Every basic block of the kernel (labels .LBB1_N and the label-less fall-through 
    save exec; exec = lane 0; global_atomic_add counters[N], 1; s_waitcnt vmcnt(0); restore exec
 on registers the kernel does not use (v64, v65, s[82:85]; the kernel descriptor is widened to 72 VGPRs / 88 SGPRs -- occupancy
 does not matter for counting).  The counters live in the decision-transcript buffer of the engine (GphDev.slog, kernel
-argument offset 0xd80 of k_sweep; allocated by gph_engine_steplog_enable in a -DGPH_BBCOUNT build).  The wait after the
+argument offset of k_sweep's GphDev + 112, read from the metadata; allocated by gph_engine_steplog_enable in a -DGPH_BBCOUNT build).  The wait after the
 atomic keeps the kernel's own vmcnt bookkeeping exact (nothing of the instrumentation is outstanding when its code goes on)."""
 import re
 import sys
 
 KERNEL = "_Z7k_sweep8GphKargs6GphDeviidddd"
-SLOG_KERNARG_OFFSET = 0xd80      # kernarg offset of GphDev (3344) + offsetof(GphDev, slog) (112)
+SLOG_IN_GPHDEV = 112             # offsetof(GphDev, slog) (gph_kernels.h: ten pointers, L, Ltot, locus_begin, err, slog_map)
+
+
+def slog_kernarg_offset(text):
+    """kernarg offset of k_sweep's second argument (GphDev, by value), from the code-object metadata in the assembly"""
+    j = text.index(".name:           " + KERNEL)
+    k = text.rfind("- .agpr_count", 0, j)
+    offs = re.findall(r"\.offset:\s+(\d+)\n\s+\.size:\s+(\d+)", text[k:j])
+    assert len(offs) >= 2 and int(offs[1][1]) == 136, offs       # sizeof(GphDev)
+    return int(offs[1][0]) + SLOG_IN_GPHDEV
 
 
 def snippet(n):
@@ -20,7 +29,9 @@ def snippet(n):
 
 
 def main():
-    src = open(sys.argv[1]).read().split("\n")
+    text = open(sys.argv[1]).read()
+    slog_off = slog_kernarg_offset(text)
+    src = text.split("\n")
     out, inside, nblocks, desc = [], False, 0, None
     for ln in src:
         if ln.startswith(KERNEL + ":"):
@@ -46,7 +57,7 @@ def main():
         if m:
             n = int(m.group(1))
             if n == 0:
-                out += [f"\ts_load_dwordx2 s[82:83], s[0:1], {hex(SLOG_KERNARG_OFFSET)}", "\tv_mov_b32_e32 v65, 1", "\ts_waitcnt lgkmcnt(0)"]
+                out += [f"\ts_load_dwordx2 s[82:83], s[0:1], {hex(slog_off)}", "\tv_mov_b32_e32 v65, 1", "\ts_waitcnt lgkmcnt(0)"]
             out += snippet(n)
             nblocks += 1
     open(sys.argv[2], "w").write("\n".join(out))

@@ -106,7 +106,9 @@ def main():
     per = lambda v: v / loci
     allv = sum(tot.values())
     print(f"# k_sweep, dynamic instructions per locus and sweep by basic-block counters (tools/bbcount.sh): {loci} loci of the bench data set,")
-    print(f"# one sweep after {cj['preroll']} iterations; library {cj['build_id']} + -gline-tables-only; {len(blocks)} blocks, {sum(1 for b in blocks if counts.get(b))} executed")
+    import subprocess
+    head = subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    print(f"# one sweep after {cj['preroll']} iterations; variant-s sources at {head} + -gline-tables-only; {len(blocks)} blocks, {sum(1 for b in blocks if counts.get(b))} executed")
     print(f"\n## by class (per locus and sweep)\ntotal {per(allv):10.0f}")
     for c in CLASSES:
         print(f"  {c:14s} {per(tot[c]):10.0f}  {100.0 * tot[c] / allv:5.1f} %")
