@@ -2346,9 +2346,11 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
     const GphEvS R = ld_ev(ev);
     node_id = R.node;
     const int nlin = R.nlin - 1;
+    /* m + 2 (n - 1) / theta of this interval: the sampling walk's event rate and the factor of this walk's own likelihood
+     * term below (one evaluation for both: the compiler does not merge the two across the branch) */
+    const double rate = mig_rate + gph_div_by(2 * nlin, theta, thinv);
     if (both) {
       /* the sampling walk's step for this interval (trace_lineage<1>'s inner loop), on the lineage count it would read */
-      const double rate = mig_rate + gph_div_by(2 * nlin, theta, thinv);
       if (!UNI(rate <= 0)) {
         const double u = l_rndu(rng);
         const double y = 1.0 - u;
@@ -2384,7 +2386,7 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
     setDEV(0, nev, ev);
     if (both) setDEV(1, nev, ev);
     nev++;
-    lnld -= (mig_rate + gph_div_by(2 * nlin, theta, thinv)) * t;
+    lnld -= rate * t;
     if (mig_source >= 0) {
       if (both) {
         /* the old edge leaves through a migration event: the sampling walk passes it and stays in this population */
