@@ -51,6 +51,7 @@ GPH_DEV void scratch_init(const GphDev &D, int g, int P, uint64_t cond_off)
   for (k = 0; k < CN_COUNT; k++) setCNT(k, 0);
   setCNT(CN_P, P);
   setCNT(CN_QPH, GPH_Q_PHASES(P, g_lay.n)); setCNT(CN_QCNT, GPH_Q_COUNT(P, g_lay.n)); setCNT(CN_QTERMS, GPH_Q_TERMS(P, g_lay.n, g_lay.cnt16));
+  setCNT(CN_SUMLDS, g_lay.lds_sum && GPH_Q_TERMS(P, g_lay.n, g_lay.cnt16) + 8 * ((P + 7) & ~7) <= g_lay.dyn_bytes);
   sf64(&GphLds::s_cntf, 0, 0.0);
 #if defined(GPH_STAMPS) || defined(GPH_HOSTEMU)
   for (k = 0; k < 8; k++) gph_lds.s_stamp[k] = 0.0;

@@ -859,9 +859,11 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     need = internal;
   } else {
     need = dirty;
+    /* le / ri of a lane that is not an internal node are -1 or a leaf's: whatever their shifts give is masked by `internal`,
+     * a scalar AND of the ballot instead of two more per-lane conditions in it */
+    const int le6 = le & 63, ri6 = ri & 63;
     for (int it = 0; it <= N; it++) {
-      bool up = isnode && lane >= n && ((((need >> le) | (need >> ri)) & 1) != 0);
-      uint64_t nn = need | __ballot(up);
+      const uint64_t nn = need | (__ballot((((need >> le6) | (need >> ri6)) & 1) != 0) & internal);
       if (nn == need) break;
       need = nn;
     }
@@ -993,7 +995,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
       else avg = prob / nc;
       term = gph_log(avg) * GPH_PATCOUNT(q_count, lane);
     }
-    if (g_lay.lds_sum && q_terms + 8 * ((P + 7) & ~7) <= g_lay.dyn_bytes) lnl = ordered_sum64_lds(term, P, q_terms);
+    if (CNT(CN_SUMLDS)) lnl = ordered_sum64_lds(term, P, q_terms);
     else lnl = ordered_sum64(term, P);
   } else {
     GPH_WAVE_FENCE();
@@ -1965,6 +1967,11 @@ GPH_DEV double rubber_band_ripple(int do_or_redo)
   return delta;
 }
 
+// traceLineage's consistency check when a walk enters the parent population (patch.c:1053: fabs(age / popAge - 1) >
+// 0.01 is fatal): |age - popAge| > 0.01 popAge -- the same test without the fp64 division (14 instructions, once per
+// population a walk crosses); a valid chain is off by rounding errors, nowhere near the threshold where the two forms differ
+GPH_DEV bool pop_age_off(double age, double pop_age) { return UNI(fabs(age - pop_age) > 0.01 * pop_age); }
+
 // the migration bands a lineage in population `pop` at time `age` is exposed to (patch.c:934-944, 1285-1294: a scan of all
 // bands for target == pop and start < age < end, strict at the start of a walk, start <= age after a migration event),
 // in increasing band order: only the bands whose target IS `pop` are looked at (GphModel.bandsInto) -- most populations
@@ -2076,7 +2083,7 @@ GPH_DEVHOT int trace_lineage(int node, RNG &rng, const GphWalkResume *rs = nullp
             thinv = g_model.thetaInv[pop];
             ev = FIRSTEV(pop);
             mig_rate = 0.0;
-            if (fabs(age / g_model.popAge[pop] - 1) > 0.01) { gph_fail(8); status = 3; }
+            if (pop_age_off(age, g_model.popAge[pop])) { gph_fail(8); status = 3; }
             else age = g_model.popAge[pop];
           }
         }
@@ -2201,7 +2208,7 @@ GPH_DEVHOT int trace_lineage(int node, RNG &rng, const GphWalkResume *rs = nullp
       thinv = g_model.thetaInv[pop];
       ev = FIRSTEV(pop);
       mig_rate = 0.0;
-      if (fabs(age / g_model.popAge[pop] - 1) > 0.01) { gph_fail(8); break; }
+      if (pop_age_off(age, g_model.popAge[pop])) { gph_fail(8); break; }
       age = g_model.popAge[pop];
     }
     const GphEvS R = ld_ev(ev);
@@ -2323,15 +2330,18 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
   dcoal = DCOAL(0, pop);
   int both = 1;                 /* the prior-sampling walk is still on this walk's interval */
   GphWalkResume rs;
-  /* a failed consistency check leaves the function from inside the loop (the sticky error aborts the run): as `break`s the
-   * three checks were three more exits whose live-out values met the normal exit's behind the loop, and the register
-   * allocator paid for that with two dozen copies at the head of EVERY interval (tools/bbcount.sh, round 4).  (Raising a
-   * flag that the loop condition tests instead -- one exit, no exit flag in the latch -- measured the same: not kept.) */
+  /* ONE exit.  The three consistency checks of a step (a chain that ends in the root population, a population entered at
+   * the wrong age, no slot left in the event list for the next step) raise `bad`, which the loop condition tests together
+   * with `proceed`; the step that raised it finishes on what it has (LDS reads and writes only -- an out-of-range LDS
+   * access is dropped by the hardware) and the failure is reported behind the loop.  As `break`s the checks were three more
+   * exits whose live-out values met the normal exit's behind the loop: two dozen register copies at the head of EVERY
+   * interval; as `return`s from inside the loop they still cost exit flags cleared and tested in every interval
+   * (tools/bbcount.sh, round 4). */
+  int bad = 0;                  /* the code of the failed check */
 #define GPH_WALK_ABORT() do { setDI(0, DI_NEV, 0); setSPRLN(0, 0.0); setDI(1, DI_NEV, 0); setSPRLN(1, 0.0); return -1; } while (0)
-  while (proceed) {
-    if (nev >= GPH_CAP_E) { gph_fail(96); GPH_WALK_ABORT(); }
-    if (ev < 0) {
-      if (g_model.popFather[pop] < 0) { gph_fail(6); GPH_WALK_ABORT(); }
+  while (proceed && !bad) {
+    if (ev < 0 && g_model.popFather[pop] < 0) bad = 6;
+    else if (ev < 0) {
       setDCOAL(0, pop, dcoal);
       if (both) setDCOAL(1, pop, dcoal);
       pop = g_model.popFather[pop];
@@ -2340,7 +2350,7 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
       thinv = g_model.thetaInv[pop];
       ev = FIRSTEV(pop);
       mig_rate = 0.0;
-      if (fabs(age / g_model.popAge[pop] - 1) > 0.01) { gph_fail(8); GPH_WALK_ABORT(); }
+      if (pop_age_off(age, g_model.popAge[pop])) bad = 8;
       age = g_model.popAge[pop];
     }
     const GphEvS R = ld_ev(ev);
@@ -2386,6 +2396,7 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
     setDEV(0, nev, ev);
     if (both) setDEV(1, nev, ev);
     nev++;
+    if (nev >= GPH_CAP_E && proceed) bad = 96;     /* the next step would not have a slot in the event list */
     lnld -= rate * t;
     if (mig_source >= 0) {
       if (both) {
@@ -2418,6 +2429,7 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
       ev = R.next;
     }
   }
+  if (bad) { gph_fail(bad); GPH_WALK_ABORT(); }
   setDCOAL(0, pop, dcoal);
   setDI(0, DI_NEV, nev);
   setSPRLN(0, lnld + g_model.logTwoTheta[pop]);

@@ -156,7 +156,7 @@ enum { DI_ORIG = 0, DI_UPD, DI_DLIN, DI_NEV, DI_NPOPS, DI_NBANDS, DI_SRCPOP, DI_
 enum { SI_FEV_OLD = 0, SI_FEV_NEW, SI_FPOP_NEW, SI_TARGET, SI_NOLD, SI_NNEW, SI_COUNT };
 enum { SA_OLD = 0, SA_NEWIN, SA_NEWOUT, SA_NEWBAND };
 // counters (s_cnt i32): evals, evalNodes, error, P, U ; (s_cntf f64): evalBytes
-enum { CN_EVALS = 0, CN_NODES, CN_ERROR, CN_P, CN_NOTENOUGH, CN_RX, CN_RY, CN_RZ, CN_EMPTY, CN_NODES0, CN_QPH, CN_QCNT, CN_QTERMS, CN_COUNT };   // CN_QPH / CN_QCNT / CN_QTERMS: byte offsets of the phases, the counts and the terms inside the locus's sequence block (GPH_Q_*: functions of P alone, derived once per kernel instead of in every evaluation); CN_EMPTY: useOld evaluations that found nothing to recompute; CN_NODES0: nodes recomputed by useOld = 0 evaluations (both off the hot path: out_common derives the algorithmic bytes from them)
+enum { CN_EVALS = 0, CN_NODES, CN_ERROR, CN_P, CN_NOTENOUGH, CN_RX, CN_RY, CN_RZ, CN_EMPTY, CN_NODES0, CN_QPH, CN_QCNT, CN_QTERMS, CN_SUMLDS, CN_COUNT };   // CN_QPH / CN_QCNT / CN_QTERMS: byte offsets of the phases, the counts and the terms inside the locus's sequence block (GPH_Q_*: functions of P alone, derived once per kernel instead of in every evaluation); CN_SUMLDS: 1 when the locus's per-pattern terms fit behind its block in this launch's dynamic LDS (ordered_sum64_lds); CN_EMPTY: useOld evaluations that found nothing to recompute; CN_NODES0: nodes recomputed by useOld = 0 evaluations (both off the hot path: out_common derives the algorithmic bytes from them)
 //   // CN_RX..: the batched generator's state after its current batch
 
 // f64 scalars in the page (index into o_fscal)
