@@ -9,6 +9,7 @@
 set -e
 if [ "$1" = build ]; then
   rm -rf /tmp/gph_bb
+  # [BB_KERNEL=<mangled name of another kernel whose second argument is GphDev>, with BB_WHAT=iteration BB_LAUNCHES=<launches per iteration> for steps 2 and 3]
   WORK=/tmp/gph_bb bash tools/asm/build_from_asm.sh bench_cache/bbcount.so tools/asm/patch_bbcount.py -DGPH_BBCOUNT -gline-tables-only
   gzip -c /tmp/gph_bb/dev.s > bench_cache/bbcount_dev.s.gz
   ls -la bench_cache/bbcount.so bench_cache/bbcount_dev.s.gz

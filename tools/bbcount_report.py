@@ -11,7 +11,7 @@ import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_Z7k_sweep8GphKargs6GphDeviidddd"
+KERNEL = os.environ.get("BB_KERNEL", "_Z7k_sweep8GphKargs6GphDeviidddd")
 CSRC = os.path.join(REPO, "g-phocs_amd", "csrc")
 
 
@@ -47,7 +47,7 @@ def functions_of(path):
 
 def main():
     cj = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "bbcount.json")))
-    loci = cj["loci"]
+    loci = cj["loci"] * int(os.environ.get("BB_LAUNCHES", "1"))      # per locus and launch
     counts = {int(k): v for k, v in cj["counts"].items()}
     src = gzip.open(os.path.join(REPO, "bench_cache", "bbcount_dev.s.gz"), "rt").read().split("\n")
     fmap = {}
@@ -69,7 +69,7 @@ def main():
             break
         if not inside:
             continue
-        m = re.match(r"^\.LBB1_(\d+):", ln) or re.match(r"^; %bb\.(\d+):", ln)
+        m = re.match(r"^\.LBB\d+_(\d+):", ln) or re.match(r"^; %bb\.(\d+):", ln)
         if m:
             blk = int(m.group(1))
             blocks.setdefault(blk, [])
@@ -105,7 +105,7 @@ def main():
         hot.append((n * len(ins), b, n, len(ins)))
     per = lambda v: v / loci
     allv = sum(tot.values())
-    print(f"# k_sweep, dynamic instructions per locus and sweep by basic-block counters (tools/bbcount.sh): {loci} loci of the bench data set,")
+    print(f"# {KERNEL}, dynamic instructions per locus and launch by basic-block counters (tools/bbcount.sh): {loci} loci of the bench data set,")
     import subprocess
     head = subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     print(f"# one sweep after {cj['preroll']} iterations; variant-s sources at {head} + -gline-tables-only; {len(blocks)} blocks, {sum(1 for b in blocks if counts.get(b))} executed")

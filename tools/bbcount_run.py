@@ -38,8 +38,11 @@ def main():
     for it in range(pre):
         s.iteration(it)
     a = fetch(lib, s)
-    r = G.GphSweepResult()
-    lib.gph_engine_genealogy_sweep(s.engine, 7, pack.ftCoalTime, pack.ftMigTime, C.byref(r))
+    if os.environ.get("BB_WHAT", "sweep") == "sweep":       # one launch of k_sweep
+        r = G.GphSweepResult()
+        lib.gph_engine_genealogy_sweep(s.engine, 7, pack.ftCoalTime, pack.ftMigTime, C.byref(r))
+    else:                                                    # one whole iteration (the evaluate kernels: BB_KERNEL names the instrumented one)
+        s.iteration(pre)
     b = fetch(lib, s)
     d = (b - a).astype(np.uint32)           # modulo 2^32
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
