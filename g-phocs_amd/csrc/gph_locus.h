@@ -752,15 +752,18 @@ GPH_DEVHOT void child_factor4(int child, CP cnd, bool fwd, double q0, double q1,
   S += s1;
   S += s2;
   S += s3;
-  const bool miss = S >= 4;
-  /* the skip of LocusDataLikelihood.c:1660-1663 as two selects instead of four: 1.0 + s*0.0 == 1.0 exactly
-   * (conditionals are finite and non-negative) */
-  const double Sp = miss ? 1.0 : S * pe;
-  const double qm = miss ? 0.0 : qe;
-  f0 = Sp + s0 * qm;
-  f1 = Sp + s1 * qm;
-  f2 = Sp + s2 * qm;
-  f3 = Sp + s3 * qm;
+  /* The skip of LocusDataLikelihood.c:1660-1663 (a son whose four conditionals add up to 4 -- a subtree of N only -- leaves
+   * the parent's product alone: factor 1.0) needs NO select here.  Such a son's conditionals are four exact 1.0 (leaves
+   * carry 1.0 for N, products of 1.0 are 1.0), so S = 4 exactly, S * pe = 4 pe exactly, s * qe = qe, and
+   * fl(4 pe + qe) with qe = fl(1 - 4 pe) is 1.0: 1 - 4 pe = qe + d with |d| <= ulp(qe) / 2 <= 2^-54, and 1 - d rounds to
+   * 1.0 for every such d (below 1 the spacing is 2^-53 and a tie goes to the even 1.0; above it 2^-52).  The general
+   * formula therefore gives the reference's factor bit for bit; the two compares and eight selects per node step that
+   * spelt the skip out were 5 % of the kernel's vector instructions (tools/bbcount.sh).  [pe in [0, 1/4]; -ffp-contract=off] */
+  const double Sp = S * pe;
+  f0 = Sp + s0 * qe;
+  f1 = Sp + s1 * qe;
+  f2 = Sp + s2 * qe;
+  f3 = Sp + s3 * qe;
 }
 
 // factors of a child that is NOT in the registers: a leaf (base code) or an internal node's array at cb + off
@@ -777,13 +780,11 @@ GPH_DEVHOT void child_inplace4(double &s0, double &s1, double &s2, double &s3, d
   S += s1;
   S += s2;
   S += s3;
-  const bool miss = S >= 4;
-  const double Sp = miss ? 1.0 : S * pe;
-  const double qm = miss ? 0.0 : qe;
-  s0 = Sp + s0 * qm;
-  s1 = Sp + s1 * qm;
-  s2 = Sp + s2 * qm;
-  s3 = Sp + s3 * qm;
+  const double Sp = S * pe;          /* (no select for a son of N only: see child_factor4) */
+  s0 = Sp + s0 * qe;
+  s1 = Sp + s1 * qe;
+  s2 = Sp + s2 * qe;
+  s3 = Sp + s3 * qe;
 }
 
 // recompute node `node`; on entry q* hold node `prev`'s conditionals (prev < 0: nothing), on exit
@@ -2393,8 +2394,10 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
       setDMIG(0, ll_get(live, i), v);
       if (both) setDMIG(1, ll_get(live, i), v);
     }
+    /* the event goes on both walks' lists: unconditionally -- once the walks have parted, the sampling walk (which resumes
+     * only after this loop) lists its own events from rs.nev on, over whatever this walk left there */
     setDEV(0, nev, ev);
-    if (both) setDEV(1, nev, ev);
+    setDEV(1, nev, ev);
     nev++;
     if (nev >= GPH_CAP_E && proceed) bad = 96;     /* the next step would not have a slot in the event list */
     lnld -= rate * t;

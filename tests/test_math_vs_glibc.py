@@ -77,3 +77,23 @@ def test_device_math_bit_identical():
         assert np.array_equal(sq.view(np.uint64), np.sqrt(np.abs(x)).view(np.uint64)), "device sqrt not IEEE"
         assert np.array_equal(dv.view(np.uint64), (x / y).view(np.uint64)), "device divide not IEEE"
         assert np.array_equal(fl, np.floor(x))
+
+
+def test_all_missing_son_needs_no_select():
+    """gph_locus.h: child_factor4 / child_inplace4 drop the reference's `probSum >= CODE_SIZE -> skip`
+    (LocusDataLikelihood.c:1660-1663): for a son of N only (four exact 1.0) the general factor
+    fl(fl(4 * pe) + fl(1.0 * fl(1 - 4 * pe))) is exactly 1.0 for every edge probability pe in [0, 1/4]"""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    for scale in (0.25, 1e-3, 1e-8, 1e-16, 1e-300):
+        pe = rng.random(2_000_000) * scale
+        assert np.all(4.0 * pe + 1.0 * (1.0 - 4.0 * pe) == 1.0), scale
+    for e in range(-70, -1):            # every binade, random significands
+        m = rng.integers(0, 2 ** 52, 100_000, dtype=np.uint64)
+        pe = np.ldexp(1.0 + m / 2.0 ** 52, e)
+        pe = pe[pe <= 0.25]
+        assert np.all(4.0 * pe + (1.0 - 4.0 * pe) == 1.0), e
+    pe = np.nextafter(0.25, 0) - np.arange(0, 4096) * 2.0 ** -55      # the last values below 1/4
+    assert np.all(4.0 * pe + (1.0 - 4.0 * pe) == 1.0)
+    for pe in (0.0, 0.25, 2.0 ** -1074, 2.0 ** -1022, 0.125, 0.1875):
+        assert 4.0 * pe + (1.0 - 4.0 * pe) == 1.0
