@@ -329,7 +329,7 @@ GPH_DEV double l_rndu(GphRng &g)
   r = (r - (int)r);
   return r;
 }
-// ---- the sweep kernel's generator: the SAME stream, 64 draws at a time.  The integer recurrences stay serial (scalar
+// ---- the sweep kernel's generator: the SAME stream, a batch of draws (GPH_RNG_BATCH) at a time.  The integer recurrences stay serial (scalar
 // unit, one lane of three registers written per step); the expensive part of a draw -- three exact quotients, two sums and
 // the fractional part, 15 fp64 vector instructions that used to run for ONE useful lane -- runs once per batch with a draw in
 // every lane.  Handing a draw out is two lane reads.  The state written back to the page is the one after the last draw
@@ -337,17 +337,23 @@ GPH_DEV double l_rndu(GphRng &g)
 #ifdef GPH_HOSTEMU
 typedef GphRng GphRngB;
 #else
+// draws per batch: a batch is generated in full and the draws a kernel has not handed out when it ends are thrown away
+// (and the state replayed to where it stopped): 64 per batch wasted 32 draws + 32 replay steps per kernel on average;
+// measured 64 / 32 / 16 / 8: 16 and 32 are the fastest (-0.6 % sweep against 64), 8 pays more in refills than it saves
+#ifndef GPH_RNG_BATCH
+#define GPH_RNG_BATCH 16
+#endif
 struct GphRngB {
-  int pos;               // draws of the batch handed out; GPH_WAVE = none left
+  int pos;               // draws of the batch handed out; GPH_RNG_BATCH = none left
   double u;              // per lane: draw `lane` of the batch
 };
-// The generator's integer state is touched twice per 64 draws, so it lives in lanes of the scalar pad, not in scalar
+// The generator's integer state is touched twice per batch of draws, so it lives in lanes of the scalar pad, not in scalar
 // registers that stay allocated (and get spilled) across the whole sweep: page scalars IS_RX / IS_RY / IS_RZ = the state
-// the current batch STARTED from, CN_RX / CN_RY / CN_RZ = the state after its 64th draw (where the next batch starts).
+// the current batch STARTED from, CN_RX / CN_RY / CN_RZ = the state after its last draw (where the next batch starts).
 GPH_DEV void rng_load(GphRngB &g)
 {
   setCNT(CN_RX, ISC(IS_RX)); setCNT(CN_RY, ISC(IS_RY)); setCNT(CN_RZ, ISC(IS_RZ));
-  g.pos = GPH_WAVE; g.u = 0.0;
+  g.pos = GPH_RNG_BATCH; g.u = 0.0;
 }
 // The state to leave behind is the one after the last draw handed out: the recurrences replayed from the batch's start
 // for `pos` steps, once per kernel (scalar unit).  Keeping the per-lane states of the batch for this instead cost three
@@ -355,7 +361,7 @@ GPH_DEV void rng_load(GphRngB &g)
 GPH_DEV void rng_store(const GphRngB &g)
 {
   uint32_t x = (uint32_t)CNT(CN_RX), y = (uint32_t)CNT(CN_RY), z = (uint32_t)CNT(CN_RZ);
-  if (g.pos < GPH_WAVE) {
+  if (g.pos < GPH_RNG_BATCH) {
     x = (uint32_t)ISC(IS_RX); y = (uint32_t)ISC(IS_RY); z = (uint32_t)ISC(IS_RZ);
     for (int k = 0; k < g.pos; k++) {
       x = 171u * x - 30269u * (x / 177u);
@@ -371,7 +377,7 @@ GPH_DEV void rng_refill(GphRngB &g)
   int vx = 0, vy = 0, vz = 0;
   setISC(IS_RX, (int)x); setISC(IS_RY, (int)y); setISC(IS_RZ, (int)z);
 #pragma unroll 4
-  for (int k = 0; k < GPH_WAVE; k++) {
+  for (int k = 0; k < GPH_RNG_BATCH; k++) {
     x = 171u * x - 30269u * (x / 177u);
     y = 172u * y - 30307u * (y / 176u);
     z = 170u * z - 30323u * (z / 178u);
@@ -396,7 +402,7 @@ GPH_DEV void rng_refill(GphRngB &g)
 }
 GPH_DEV double l_rndu(GphRngB &g)
 {
-  if (g.pos >= GPH_WAVE) rng_refill(g);
+  if (g.pos >= GPH_RNG_BATCH) rng_refill(g);
   const double u = gph_readlane64(g.u, g.pos);
   g.pos++;
   return u;
