@@ -957,11 +957,12 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
           l = __builtin_amdgcn_readlane(le, f);
           r = __builtin_amdgcn_readlane(ri, f);
           const int sib = l == prev ? r : l;
-          if (sib < n || !((todo >> sib) & 1)) node = f;
+          if (!((todo >> sib) & 1)) node = f;        /* (a leaf is never in `todo`: no separate test for sib < n) */
         }
       }
       if (node < 0) {
-        bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
+        /* lanes in `todo` are internal nodes: their le / ri are node ids, and a leaf's bit of `todo` is 0 */
+        bool rdy = ((todo >> lane) & 1) && !((todo >> (le & 63)) & 1) && !((todo >> (ri & 63)) & 1);
         uint64_t rmask = __ballot(rdy);
         if (rmask == 0) { bad = true; rmask = todo; }
         node = __builtin_ctzll(rmask);
@@ -2345,6 +2346,7 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
    * interval; as `return`s from inside the loop they still cost exit flags cleared and tested in every interval
    * (tools/bbcount.sh, round 4). */
   int bad = 0;                  /* the code of the failed check */
+  int at_end = 0;               /* the step just done was the old edge's last */
 #define GPH_WALK_ABORT() do { setDI(0, DI_NEV, 0); setSPRLN(0, 0.0); setDI(1, DI_NEV, 0); setSPRLN(1, 0.0); return -1; } while (0)
   while (proceed && !bad) {
     if (ev < 0 && g_model.popFather[pop] < 0) bad = 6;
@@ -2384,7 +2386,8 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
     setENLIN(ev, nlin);
     t = R.time;
     age += t;
-    proceed = (ev != fev_old);
+    at_end = (ev == fev_old);
+    proceed = !at_end;
     if (R.type == GPH_IN_MIG) {
       if (MG(node_id, MG_BRANCH) == node) {
         int k = SPRI(SI_NOLD);
@@ -2405,7 +2408,7 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
     setDEV(0, nev, ev);
     setDEV(1, nev, ev);
     nev++;
-    if (nev >= GPH_CAP_E && proceed) bad = 96;     /* the next step would not have a slot in the event list */
+    if (nev >= GPH_CAP_E) proceed = 0;             /* the next step would not have a slot in the event list: see behind the loop */
     lnld -= rate * t;
     if (mig_source >= 0) {
       if (both) {
@@ -2438,6 +2441,7 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
       ev = R.next;
     }
   }
+  if (!bad && !at_end) bad = 96;        /* stopped by the capacity of the event list, not by the end of the old edge */
   if (bad) { gph_fail(bad); GPH_WALK_ABORT(); }
   setDCOAL(0, pop, dcoal);
   setDI(0, DI_NEV, nev);
