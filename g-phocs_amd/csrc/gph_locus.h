@@ -371,6 +371,7 @@ GPH_DEV void rng_store(const GphRngB &g)
   }
   setISC(IS_RX, (int)x); setISC(IS_RY, (int)y); setISC(IS_RZ, (int)z);
 }
+#ifdef GPH_RNG_SCALAR_REFILL      /* the refill of rounds 2-4, kept for A/B measurements: the three recurrences on the scalar unit */
 GPH_DEV void rng_refill(GphRngB &g)
 {
   uint32_t x = (uint32_t)CNT(CN_RX), y = (uint32_t)CNT(CN_RY), z = (uint32_t)CNT(CN_RZ);
@@ -400,6 +401,66 @@ GPH_DEV void rng_refill(GphRngB &g)
 #endif
   g.pos = 0;
 }
+#else
+// Round 5: the recurrences run on the VECTOR unit, one component per row of 16 lanes (row 0 = x, 1 = y, 2 = z; row 3 runs z
+// again and is ignored), every lane of a row redundantly.  A step is
+//   q = x / d      by the 33-bit multiply-shift of Granlund & Montgomery: t = mulhi(x, M'), q = (t + ((x - t) >> 1)) >> 7
+//                  with M' = floor(2^32 (256 - d) / d) + 1 -- equal to x / d for ALL 2^32 x and d = 177, 176, 178
+//                  (exhaustively: tools/verify_rng_magic.c),
+//   x = a x - m q  modulo 2^32 (= a (x % d) - c (x / d), utils.c:503-505, as in the scalar form above),
+// and one v_cndmask_b32_dpp that shifts the row's history register one lane down (row_shl:1: lane i <- lane i + 1) and puts
+// the new state into the row's last lane: after 16 steps lane j of a row holds the state after step j + 1, i.e. the integers of
+// draw j.  9 vector instructions per draw where the scalar form had 18 scalar ones + s_mov m0 + s_nop + 3 v_writelane; the
+// three quotients x / 30269.0 ... then run ONCE over the 48 lanes with per-row constants, and the y / z quotients come down
+// to row 0 with four ds_bpermute_b32.  One asm statement: the DPP select reads the row-end mask from vcc, which must
+// survive the 16 steps (no instruction in between writes it), and the compiler must not re-schedule a write of the history
+// register next to its DPP read (2 wait states on gfx9: inside the block the previous write is 8 instructions away).
+#define GPH_RNGV_STEP \
+  "v_mul_hi_u32 %[q], %[st], %[mg]\n\t" \
+  "v_mul_lo_u32 %[t], %[st], %[a]\n\t" \
+  "v_sub_u32 %[st], %[st], %[q]\n\t" \
+  "v_lshrrev_b32 %[st], 1, %[st]\n\t" \
+  "v_add_u32 %[st], %[st], %[q]\n\t" \
+  "v_lshrrev_b32 %[st], 7, %[st]\n\t" \
+  "v_mul_lo_u32 %[st], %[st], %[nm]\n\t" \
+  "v_add_u32 %[st], %[st], %[t]\n\t" \
+  "v_cndmask_b32_dpp %[h], %[h], %[st], vcc row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define GPH_RNGV_STEP4 GPH_RNGV_STEP GPH_RNGV_STEP GPH_RNGV_STEP GPH_RNGV_STEP
+GPH_DEV void rng_refill(GphRngB &g)
+{
+  static_assert(GPH_RNG_BATCH == 16, "one draw per lane of a 16-lane row");
+  const uint32_t x0 = (uint32_t)CNT(CN_RX), y0 = (uint32_t)CNT(CN_RY), z0 = (uint32_t)CNT(CN_RZ);
+  setISC(IS_RX, (int)x0); setISC(IS_RY, (int)y0); setISC(IS_RZ, (int)z0);
+#if defined(__HIP_DEVICE_COMPILE__)       /* (the host pass of hipcc only parses this) */
+  const int row = GPH_LANE >> 4;
+  const bool r0 = row == 0, r1 = row == 1;
+  uint32_t st = r0 ? x0 : r1 ? y0 : z0, h = 0, q, t;
+  const uint32_t mg = r0 ? 0x724287f5u : r1 ? 0x745d1746u : 0x702e05c1u;      /* M' of 177, 176, 178 */
+  const uint32_t a = r0 ? 171u : r1 ? 172u : 170u;
+  const uint32_t nm = r0 ? 0u - 30269u : r1 ? 0u - 30307u : 0u - 30323u;      /* -(a d + c): 171 * 177 + 2 = 30269, ... */
+  asm("s_mov_b32 vcc_lo, 0x80008000\n\t"
+      "s_mov_b32 vcc_hi, 0x80008000\n\t"
+      GPH_RNGV_STEP4 GPH_RNGV_STEP4 GPH_RNGV_STEP4 GPH_RNGV_STEP4
+      : [st] "+v"(st), [h] "+v"(h), [q] "=&v"(q), [t] "=&v"(t) : [mg] "v"(mg), [a] "v"(a), [nm] "v"(nm) : "vcc");
+  /* every lane of a row holds the state after the batch's last draw */
+  setCNT(CN_RX, __builtin_amdgcn_readlane((int)st, 0)); setCNT(CN_RY, __builtin_amdgcn_readlane((int)st, 16));
+  setCNT(CN_RZ, __builtin_amdgcn_readlane((int)st, 32));
+  {
+    const gph_cdbl *RC = GPH_RNGC;
+    const double rr = r0 ? RC[0] : r1 ? RC[1] : RC[2], mm = r0 ? RC[3] : r1 ? RC[4] : RC[5];
+    const double hd = (double)h, q0 = hd * rr;
+    const double qq = __builtin_fma(__builtin_fma(-q0, mm, hd), rr, q0);      /* x / 30269.0 | y / 30307.0 | z / 30323.0, exact (l_rndu above) */
+    union { double d; int32_t i[2]; } u, vy, vz;
+    u.d = qq;
+    const int ay = (GPH_LANE + 16) << 2, az = (GPH_LANE + 32) << 2;
+    vy.i[0] = __builtin_amdgcn_ds_bpermute(ay, u.i[0]); vy.i[1] = __builtin_amdgcn_ds_bpermute(ay, u.i[1]);
+    vz.i[0] = __builtin_amdgcn_ds_bpermute(az, u.i[0]); vz.i[1] = __builtin_amdgcn_ds_bpermute(az, u.i[1]);
+    g.u = __builtin_amdgcn_fract(qq + vy.d + vz.d);      /* lanes 0 .. 15: draw `lane` (the other rows hold sums nobody reads) */
+  }
+#endif
+  g.pos = 0;
+}
+#endif
 GPH_DEV double l_rndu(GphRngB &g)
 {
   if (g.pos >= GPH_RNG_BATCH) rng_refill(g);

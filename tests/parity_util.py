@@ -1,13 +1,14 @@
 """Comparison helpers for the parity tests.
 
 Bar (BASELINE.json north_star): accept/reject counters bit-exact, fp64 log-likelihoods within
-1e-10 relative.  The HIP path uses the device's exp/log (<= 1 ulp from glibc's), and reduces
-per-locus partial sums with a fixed-shape tree, so doubles are compared with REL_TOL; every
-integer (counters, topology, event ids, lineage counts, RNG state) must be identical."""
+1e-10 relative.  The HIP path keeps the reference's operand order per locus (and its libm's exp/log
+bit for bit), so everything PER LOCUS is compared byte for byte; only sums over loci -- reduced with a
+fixed-shape tree on the device, serially upstream -- get REL_TOL.  Every integer (counters, topology,
+event ids, lineage counts, RNG state) must be identical."""
 import math
 
-REL_TOL = 1e-10      # log-likelihoods / accumulators (north_star tolerance)
-STATE_TOL = 1e-9     # per-locus doubles (ages, elapsed times, statistics, conditionals)
+REL_TOL = 1e-10      # cross-locus sums: log-likelihoods / accumulators (north_star tolerance; the summation tree differs)
+STATE_TOL = 0.0      # per-locus doubles (ages, elapsed times, statistics, conditionals, per-locus lnL): byte-equal
 
 
 def _close(a, b, tol):
@@ -54,20 +55,56 @@ def _tok_close(u, v, tol):
     return False  # integers must match exactly
 
 
-def compare_states(path_a, path_b, tol=STATE_TOL, skip_global=False):
-    """canonical state dumps: integers exact, doubles within tol"""
+def _ulps(u, v):
+    """distance of two hex-float tokens in units of the last place of the larger one (None: not both floats)"""
+    try:
+        a, b = float.fromhex(u), float.fromhex(v)
+    except ValueError:
+        return None
+    if a == b:
+        return 0.0
+    m = max(abs(a), abs(b))
+    return abs(a - b) / math.ulp(m) if m > 0 else 0.0
+
+
+# Lines of a canonical state dump that sum over loci (fixed-shape tree on the device, serial order upstream): the only
+# ones compared with a tolerance.  Everything else -- MODEL, and per locus LOCUS / N / C / K / M / S: ages, elapsed times,
+# statistics, log-likelihoods, conditionals, RNG slots, event ids, lineage counts -- must be BYTE-EQUAL (DESIGN section 5:
+# the reference's operand order per locus, LocusDataLikelihood.c:471-479, patch.c:1730, 1671).
+CROSS_LOCUS_LINES = ("GLOBAL", "TOTALS")
+
+
+def compare_states(path_a, path_b, tol=REL_TOL, skip_global=False, per_locus_tol=0.0):
+    """canonical state dumps: per-locus lines byte for byte (per_locus_tol = 0), the cross-locus sums of the GLOBAL / TOTALS
+    lines within `tol` (their integers exact).  A failure lists EVERY differing field with its distance in ulps."""
     A = open(path_a).read().splitlines()
     B = open(path_b).read().splitlines()
     assert len(A) == len(B), f"state line count differs: {len(A)} vs {len(B)}"
+    bad, locus = [], "-"
     for x, y in zip(A, B):
+        if x.startswith("LOCUS "):
+            locus = x.split()[1]
         if x == y:
             continue
         xs, ys = x.split(), y.split()
         assert len(xs) == len(ys), f"state line differs:\n  {x[:200]}\n  {y[:200]}"
-        if skip_global and xs[0] in ("GLOBAL", "TOTALS"):
+        if xs[0] in CROSS_LOCUS_LINES:
+            if skip_global:
+                continue
+            for u, v in zip(xs, ys):
+                assert _tok_close(u, v, tol), f"state differs ({u} vs {v}):\n  {x[:300]}\n  {y[:300]}"
             continue
-        for u, v in zip(xs, ys):
-            assert _tok_close(u, v, tol), f"state differs ({u} vs {v}):\n  {x[:300]}\n  {y[:300]}"
+        for col, (u, v) in enumerate(zip(xs, ys)):
+            if u == v:
+                continue
+            if per_locus_tol > 0 and _tok_close(u, v, per_locus_tol):
+                continue
+            for a, b in zip(u.split(":"), v.split(":")):
+                if a != b:
+                    d = _ulps(a, b)
+                    bad.append(f"locus {locus} line {xs[0]} {xs[1] if len(xs) > 1 else ''} field {col}: {a} vs {b}"
+                               + (f" ({d:.3g} ulp)" if d is not None else " (integer)"))
+    assert not bad, (f"{len(bad)} per-locus field(s) not byte-equal ({path_a} vs {path_b}):\n  " + "\n  ".join(bad[:40]))
     return True
 
 
