@@ -256,7 +256,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_engine_num_loci", "gph_engine_hbm_bytes", "gph_debug_math", "gph_engine_class_stats",
     "gph_mcmc_create", "gph_mcmc_destroy", "gph_mcmc_initialize", "gph_mcmc_set_record_file",
     "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
-    "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
+    "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_engine_last_error", "gph_engine_debug_break_chain", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
     "gph_control_sample_name", "gph_loci_read", "gph_loci_free", "gph_loci_arrays", "gph_run_control_file", "gph_run_control_file_ranked",
     "gph_read_trace", "gph_engine_locus_rate_update", "gph_engine_set_locus_rates", "gph_mcmc_set_locus_rate_finetune",
     "gph_mcmc_locus_rate_state", "gph_engine_set_comm", "gph_engine_host_stats", "gph_engine_set_timing",
@@ -308,6 +308,8 @@ def _load_library(path):
     lib.gph_mcmc_iteration.argtypes = [C.c_void_p, C.c_int32]
     lib.gph_mcmc_dump_state.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     lib.gph_engine_dump_loci.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
+    lib.gph_engine_last_error.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    lib.gph_engine_debug_break_chain.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.gph_mcmc_set_record_file.argtypes = [C.c_void_p, C.c_char_p]
     lib.gph_engine_last_kernel_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
     lib.gph_engine_get_counters.argtypes = [C.c_void_p, C.POINTER(GphCounters), C.c_int32]
@@ -628,6 +630,12 @@ class Sampler:
 
     def dump_state(self, path, with_cond=False):
         self._chk(self.lib.gph_mcmc_dump_state(self.mcmc, path.encode(), int(with_cond)), "dump_state")
+
+    def last_error(self):
+        """(global locus index or -1, reference "Fatal Error" code) of the last call that failed with GPH_EKERNEL"""
+        g, c = C.c_int64(-1), C.c_int32(0)
+        self._chk(self.lib.gph_engine_last_error(self.engine, C.byref(g), C.byref(c)), "last_error")
+        return g.value, c.value
 
     def counters(self, reset=False):
         c = GphCounters()

@@ -321,6 +321,9 @@ struct gph_engine {
   // mirror does (host mode: a caller-supplied all-reduce hook forces a synchronisation per reduction anyway)
   GphGlobal *G_h = nullptr, *G_d = nullptr;
   bool G_dirty = true;               // the host mirror was changed since it was last pushed
+  int32_t last_error_code = 0;       // the last fatal error check_error reported (gph_engine_last_error)
+  long long last_error_locus = -1;
+  bool in_error_dump = false;
   int64_t L = 0;
   size_t cond_bytes = 0, pages_bytes = 0, seq_bytes_total = 0;
   std::vector<uint64_t> h_cond_off;
@@ -766,14 +769,79 @@ static int run_stage(gph_engine *e, int stage, int arg, int iteration)
   return push_G(e);
 }
 
+// one locus in the canonical text form (same format as oracle/gphocs_oracle_io.c go_dump_state's per-locus part): pg = its
+// page, cb = its conditionals (or null)
+static void dump_one_locus(const gph_engine *e, FILE *f, long long global_locus, const char *pg, const char *cb, int P)
+{
+  const GphLayout &y = e->lay;
+  const double *fs = (const double *)(pg + y.o_fscal);
+  const int32_t *is = (const int32_t *)(pg + y.o_iscal);
+  const GphNode *nd = (const GphNode *)(pg + y.o_nd);
+  const int16_t *ne = (const int16_t *)(pg + y.o_nev);
+  const int16_t *first = (const int16_t *)(pg + y.o_first);
+  const GphEv *evr = (const GphEv *)(pg + y.o_ev);
+  fprintf(f, "LOCUS %lld root %d dataLnL %a genLnL %a rng %u %u %u\n", (long long)global_locus, is[IS_ROOT],
+          fs[FS_DATALNL], fs[FS_GENLNL], (unsigned)is[IS_RX], (unsigned)is[IS_RY], (unsigned)is[IS_RZ]);
+  if (e->var_rates) fprintf(f, "R %a\n", fs[FS_MUTRATE]);
+  for (int i = 0; i < y.N; i++)
+    fprintf(f, "N %d %d %d %d %a %d %d\n", i, nd[i].father, nd[i].left, nd[i].right, nd[i].age, nd[i].npop, i < y.n ? -1 : ne[i]);
+  for (int pop = 0; pop < y.K; pop++) {
+    fprintf(f, "C %d", pop);
+    int guard = 0;
+    for (int ev = first[pop]; ev >= 0 && guard++ < y.E; ev = evr[ev].next)
+      fprintf(f, " %d:%d:%d:%d:%a", ev, evr[ev].type, evr[ev].node, evr[ev].nlin, evr[ev].time);
+    fprintf(f, "\n");
+  }
+  fprintf(f, "S");
+  for (int pop = 0; pop < y.K; pop++)
+    fprintf(f, " %a %d", ((const double *)(pg + y.o_coal))[pop], ((const int16_t *)(pg + y.o_ncoal))[pop]);
+  for (int b = 0; b < y.B; b++)
+    fprintf(f, " %a %d", ((const double *)(pg + y.o_migst))[b], ((const int16_t *)(pg + y.o_nmig))[b]);
+  fprintf(f, "\n");
+  fprintf(f, "M %d", is[IS_NUM_MIGS]);
+  for (int i = 0; i < is[IS_NUM_MIGS]; i++) {
+    int mg = ((const int16_t *)(pg + y.o_living))[i];
+    const int16_t *mi = (const int16_t *)(pg + y.o_mig_i) + mg * MG_COUNT;
+    fprintf(f, " %d:%d:%d:%d:%d:%d:%d:%a", mg, mi[MG_BRANCH], mi[MG_BAND], mi[MG_SPOP], mi[MG_TPOP], mi[MG_SEV],
+            mi[MG_TEV], ((const double *)(pg + y.o_mig_age))[mg]);
+  }
+  fprintf(f, "\n");
+  if (cb) {
+    for (int i = y.n; i < y.N; i++) {
+      const double *c = (const double *)(cb + ((size_t)((int)(((uint32_t)is[IS_CBIT0 + (i >> 5)] >> (i & 31)) & 1) * (y.n - 1) + (i - y.n)) * P) * 32);
+      fprintf(f, "K %d", i);
+      for (int k = 0; k < 4 * P; k++) fprintf(f, " %a", c[k]);
+      fprintf(f, "\n");
+    }
+  }
+}
+
 // after a host synchronisation: the error the stages recorded, the counters
 static int check_error(gph_engine *e)
 {
   const int code = e->G_h->error;
   if (code != 0) {
+    const long long gl = (code == 75 || code == 9999) ? -1 : e->G_h->error_locus;
+    e->last_error_code = code;
+    e->last_error_locus = gl;
     if (code == 75) fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n");
     else if (code == 9999) fprintf(stderr, "gphocs_hip: checkAll failed at iteration %d\n", e->G_h->iteration);
+    else if (gl >= 0) fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by a locus kernel, first in locus %lld (iteration %d)\n", code, gl, e->G_h->iteration);
     else fprintf(stderr, "gphocs_hip: Fatal Error %04d reported by a locus kernel\n", code);
+    /* what printGenealogyAndExit prints upstream (GPhoCS.c:660-676: the locus's genealogy and its event chains), in the
+     * canonical dump format, when the failing locus is one of this rank's; the state is the one the kernel left behind */
+    const long long lo = gl - e->cfg.locus_begin;
+    if (gl >= 0 && lo >= 0 && lo < e->L && !e->in_error_dump) {
+      e->in_error_dump = true;
+      int64_t slot = -1;
+      for (int64_t j = 0; j < e->L; j++) if (e->h_orig[j] == lo) { slot = j; break; }
+      std::vector<char> pg(e->lay.page_bytes);
+      if (slot >= 0 && !d2h(e, pg.data(), (const char *)e->dev.pages + (size_t)slot * e->lay.page_bytes, e->lay.page_bytes)) {
+        fprintf(stderr, "gphocs_hip: genealogy and event chains of locus %lld:\n", gl);
+        dump_one_locus(e, stderr, gl, pg.data(), nullptr, 0);
+      }
+      e->in_error_dump = false;
+    }
     return GPH_EKERNEL;
   }
   return 0;
@@ -2018,6 +2086,41 @@ int gph_engine_unit(gph_engine *e, int32_t op, int32_t arg, double *out, int32_t
   return rc;
 }
 
+// the last fatal error a call returned GPH_EKERNEL for: the reference's "Fatal Error NNNN" code and the global index of the
+// first locus that reported it (-1: not attributable to one locus, e.g. checkAll's accumulator test); 0 / -1 if none
+int gph_engine_last_error(gph_engine *e, int64_t *locus, int32_t *code)
+{
+  if (!e) return GPH_EARG;
+  if (locus) *locus = e->last_error_locus;
+  if (code) *code = e->last_error_code;
+  return 0;
+}
+
+// tests only: break the event chain of population `pop` of one locus (the `next` link of its first event becomes -1), so
+// that the next kernel's bounded chain walks raise a fatal code for exactly that locus (tests/test_host_logic.py,
+// tests/test_gpu_parity.py: the failure must name the locus and print its genealogy)
+int gph_engine_debug_break_chain(gph_engine *e, int64_t global_locus, int32_t pop)
+{
+  if (!e || !e->initialized || pop < 0 || pop >= e->cfg.K) return GPH_EARG;
+  const long long lo = global_locus - e->cfg.locus_begin;
+  if (lo < 0 || lo >= e->L) return GPH_EARG;
+  SETDEV(e);
+  { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
+  int64_t slot = -1;
+  for (int64_t j = 0; j < e->L; j++) if (e->h_orig[j] == lo) { slot = j; break; }
+  if (slot < 0) return GPH_ESTATE;
+  const GphLayout &y = e->lay;
+  std::vector<char> pg(y.page_bytes);
+  char *dp = (char *)e->dev.pages + (size_t)slot * y.page_bytes;
+  int rc = d2h(e, pg.data(), dp, y.page_bytes);
+  if (rc) return rc;
+  const int16_t *first = (const int16_t *)(pg.data() + y.o_first);
+  GphEv *evr = (GphEv *)(pg.data() + y.o_ev);
+  if (first[pop] < 0) return GPH_ESTATE;
+  evr[first[pop]].next = -1;
+  return h2d(e, dp, pg.data(), y.page_bytes);
+}
+
 // canonical text dump (same format as oracle/gphocs_oracle_io.c go_dump_state's per-locus part)
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int32_t append)
 {
@@ -2038,49 +2141,7 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int3
   for (int64_t go = 0; go < e->L; go++) {
     if ((go + e->cfg.locus_begin) % dstride != 0) continue;
     const int64_t g = slot_of[go];
-    const char *pg = pages.data() + (size_t)g * y.page_bytes;
-    const double *fs = (const double *)(pg + y.o_fscal);
-    const int32_t *is = (const int32_t *)(pg + y.o_iscal);
-    const GphNode *nd = (const GphNode *)(pg + y.o_nd);
-    const int16_t *ne = (const int16_t *)(pg + y.o_nev);
-    const int16_t *first = (const int16_t *)(pg + y.o_first);
-    const GphEv *evr = (const GphEv *)(pg + y.o_ev);
-    fprintf(f, "LOCUS %lld root %d dataLnL %a genLnL %a rng %u %u %u\n", (long long)(go + e->cfg.locus_begin), is[IS_ROOT],
-            fs[FS_DATALNL], fs[FS_GENLNL], (unsigned)is[IS_RX], (unsigned)is[IS_RY], (unsigned)is[IS_RZ]);
-    if (e->var_rates) fprintf(f, "R %a\n", fs[FS_MUTRATE]);
-    for (int i = 0; i < y.N; i++)
-      fprintf(f, "N %d %d %d %d %a %d %d\n", i, nd[i].father, nd[i].left, nd[i].right, nd[i].age, nd[i].npop, i < y.n ? -1 : ne[i]);
-    for (int pop = 0; pop < y.K; pop++) {
-      fprintf(f, "C %d", pop);
-      int guard = 0;
-      for (int ev = first[pop]; ev >= 0 && guard++ < y.E; ev = evr[ev].next)
-        fprintf(f, " %d:%d:%d:%d:%a", ev, evr[ev].type, evr[ev].node, evr[ev].nlin, evr[ev].time);
-      fprintf(f, "\n");
-    }
-    fprintf(f, "S");
-    for (int pop = 0; pop < y.K; pop++)
-      fprintf(f, " %a %d", ((const double *)(pg + y.o_coal))[pop], ((const int16_t *)(pg + y.o_ncoal))[pop]);
-    for (int b = 0; b < y.B; b++)
-      fprintf(f, " %a %d", ((const double *)(pg + y.o_migst))[b], ((const int16_t *)(pg + y.o_nmig))[b]);
-    fprintf(f, "\n");
-    fprintf(f, "M %d", is[IS_NUM_MIGS]);
-    for (int i = 0; i < is[IS_NUM_MIGS]; i++) {
-      int mg = ((const int16_t *)(pg + y.o_living))[i];
-      const int16_t *mi = (const int16_t *)(pg + y.o_mig_i) + mg * MG_COUNT;
-      fprintf(f, " %d:%d:%d:%d:%d:%d:%d:%a", mg, mi[MG_BRANCH], mi[MG_BAND], mi[MG_SPOP], mi[MG_TPOP], mi[MG_SEV],
-              mi[MG_TEV], ((const double *)(pg + y.o_mig_age))[mg]);
-    }
-    fprintf(f, "\n");
-    if (withCond) {
-      int P = e->h_P[g];
-      const char *cb = cond.data() + e->h_cond_off[g];
-      for (int i = y.n; i < y.N; i++) {
-        const double *c = (const double *)(cb + ((size_t)((int)(((uint32_t)is[IS_CBIT0 + (i >> 5)] >> (i & 31)) & 1) * (y.n - 1) + (i - y.n)) * P) * 32);
-        fprintf(f, "K %d", i);
-        for (int k = 0; k < 4 * P; k++) fprintf(f, " %a", c[k]);
-        fprintf(f, "\n");
-      }
-    }
+    dump_one_locus(e, f, go + e->cfg.locus_begin, pages.data() + (size_t)g * y.page_bytes, withCond ? cond.data() + e->h_cond_off[g] : nullptr, e->h_P[g]);
   }
   fclose(f);
   return 0;

@@ -198,8 +198,11 @@ GPH_HD void gg_count(GphGlobal &G, const GphRed &R, int which)
   G.cnt_notenough += R.sum(0, 13);
   if (!G.error) {
     const double e1 = R.mx(0, 11), e2 = R.errword();
-    if (e1 != 0.0) G.error = (int32_t)e1;
-    else if (e2 != 0.0) G.error = (int32_t)e2;
+    if (e1 != 0.0) {       /* out_common: (2^30 - first failing locus) 2^14 + its code */
+      const long long w = (long long)e1;
+      G.error = (int32_t)(w & 16383);
+      G.error_locus = ((long long)1 << 30) - (w >> 14);
+    } else if (e2 != 0.0) { G.error = (int32_t)e2; G.error_locus = -1; }
   }
 }
 GPH_HD void gg_totals(GphGlobal &G, const GphRed &R)

@@ -125,7 +125,9 @@ GPH_DEV void out_common(const GphDev &D, int g)
     o[8] = CNT(CN_EVALS);
     o[9] = CNT(CN_NODES);
     o[10] = bytes_;
-    o[11] = gph_errcode();
+    /* max over loci = the FIRST failing locus (smallest global index) with its own code: (2^30 - locus) 2^14 + code, exact in
+     * a double (GphGlobal::error / error_locus, gph_global.h: gg_count; the reference names the locus: GPhoCS.c:660-676) */
+    o[11] = gph_errcode() != 0 ? (double)((((long long)1 << 30) - (long long)(D.orig[g] + D.locus_begin)) * 16384 + (gph_errcode() & 16383)) : 0.0;
     o[13] = CNT(CN_NOTENOUGH);
     if (gph_errcode() != 0) {
       gph_raise(D.err, gph_errcode());

@@ -371,7 +371,7 @@ GPH_DEV void rng_store(const GphRngB &g)
   }
   setISC(IS_RX, (int)x); setISC(IS_RY, (int)y); setISC(IS_RZ, (int)z);
 }
-#ifdef GPH_RNG_SCALAR_REFILL      /* the refill of rounds 2-4, kept for A/B measurements: the three recurrences on the scalar unit */
+#ifndef GPH_RNG_VECTOR_REFILL      /* the three recurrences on the scalar unit: the product form (see the measurement at the vector form below) */
 GPH_DEV void rng_refill(GphRngB &g)
 {
   uint32_t x = (uint32_t)CNT(CN_RX), y = (uint32_t)CNT(CN_RY), z = (uint32_t)CNT(CN_RZ);
@@ -402,7 +402,11 @@ GPH_DEV void rng_refill(GphRngB &g)
   g.pos = 0;
 }
 #else
-// Round 5: the recurrences run on the VECTOR unit, one component per row of 16 lanes (row 0 = x, 1 = y, 2 = z; row 3 runs z
+// Round 5 experiment, NOT the product form: measured 3 % SLOWER (sweep 9.46 / 9.52 -> 9.77 / 9.78 ms, two
+// interleaved A/B pairs on one box, same accept counters: profiles/r05_ab_rng_vector.txt) -- the vector pipe is the busier one
+// (9 quarter-/full-rate vector instructions per draw = 28 SIMD-cycles replace 18 scalar ones + 12.6 SIMD-cycles of lane writes),
+// seven live vector registers at every refill site add spills (9 -> 28), and twelve inlined sites add 750 static instructions.
+// The recurrences run on the VECTOR unit, one component per row of 16 lanes (row 0 = x, 1 = y, 2 = z; row 3 runs z
 // again and is ignored), every lane of a row redundantly.  A step is
 //   q = x / d      by the 33-bit multiply-shift of Granlund & Montgomery: t = mulhi(x, M'), q = (t + ((x - t) >> 1)) >> 7
 //                  with M' = floor(2^32 (256 - d) / d) + 1 -- equal to x / d for ALL 2^32 x and d = 177, 176, 178

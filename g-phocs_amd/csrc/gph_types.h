@@ -330,6 +330,7 @@ struct alignas(16) GphGlobal {
   double tot_coal[GPH_MAXK], tot_ncoal[GPH_MAXK], tot_mig[GPH_MAXB], tot_nmig[GPH_MAXB];
   int64_t acc[9], accTau[GPH_MAXK], rubberband_conflicts;
   int32_t iteration, error;          // error: first fatal code seen by a stage (0 = none)
+  long long error_locus;             // global index of the first locus that reported it (-1: not a per-locus error)
   // pending proposal bookkeeping (between propose and decide)
   double pend_lnacc, pend_tauold, pend_taunew, pend_taufactor0, pend_taufactor1, pend_dGen;
   int32_t pend_pop, pend_kind;       // kind 0 none, 1 tau, 2 sample age: the model change applied AFTER the finish kernel

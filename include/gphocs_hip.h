@@ -176,6 +176,13 @@ int gph_engine_synchronize(gph_engine *e, int32_t refresh_genealogy_lnl, double 
                            double *sumNewGenLnL);
 int gph_engine_check_all(gph_engine *e, int32_t *ok, double *sumDataLnL, double *sumGenLnL);
 int gph_engine_get_counters(gph_engine *e, gph_counters *out, int32_t reset);
+/* After a call returned GPH_EKERNEL: the reference's "Fatal Error NNNN" code and the global index of the FIRST locus that
+ * reported it (-1 when the failure is not one locus's: checkAll's accumulator test, synchronizeEvents' flag).  The engine
+ * has then already printed, to stderr, the code, the locus and -- what printGenealogyAndExit(gen, ...) prints upstream,
+ * GPhoCS.c:660-676 -- that locus's genealogy and event chains in the canonical dump format. */
+int gph_engine_last_error(gph_engine *e, int64_t *locus, int32_t *code);
+/* tests only: break the event chain of population `pop` of one locus, so that the next kernel raises a fatal code for it */
+int gph_engine_debug_break_chain(gph_engine *e, int64_t global_locus, int32_t pop);
 /* debug / parity: canonical text dump of every local locus (same format as the oracle's) */
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditionals, int32_t append);
 /* debug / parity, kernel level: single calls of the per-locus functions with deterministic arguments on the current
