@@ -175,15 +175,21 @@ def _build_locked(verbose):
         with open(side, "w") as f:
             f.write(f"{want}:{hdr}:{ver}\n")
 
+    jobs = []
     for name, (cl, ck, cb, waves, fn) in VARIANTS.items():
-        library(os.path.join(_HERE, fn), name,
-                HIPCC_BASE + (HIPCC_TUNING_SPILLING if waves > 6 else HIPCC_TUNING) +
-                [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"])
+        jobs.append((os.path.join(_HERE, fn), name,
+                     HIPCC_BASE + (HIPCC_TUNING_SPILLING if waves > 6 else HIPCC_TUNING) +
+                     [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}"]))
     # control build without the backend switches (parity tests only)
     cl, ck, cb, waves, _ = VARIANTS["m"]
-    library(os.path.join(_HERE, PLAIN_LIB), "plain",
-            HIPCC_BASE + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}",
-                          "-DGPH_LOGSTEPS"])     # + the decision-level transcript (tests/test_logsteps.py)
+    jobs.append((os.path.join(_HERE, PLAIN_LIB), "plain",
+                 HIPCC_BASE + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}",
+                               "-DGPH_LOGSTEPS"]))     # + the decision-level transcript (tests/test_logsteps.py)
+    # every variant is one hipcc process of its own (half a minute each): a few at a time
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(5, (os.cpu_count() or 2) // 2))) as ex:
+        for f in [ex.submit(library, *j) for j in jobs]:
+            f.result()
     # the program: same command line as the reference's G-PhoCS binary (GPhoCS.c:84-238)
     exe, main = os.path.join(_HERE, "G-PhoCS-hip"), os.path.join(CSRC, "gph_main.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(main), os.path.getmtime(deps[-1])):
@@ -668,7 +674,7 @@ class Sampler:
 
     def unit(self, op, arg=0):
         """kernel-level fixture calls (gph_engine_unit): rows = local loci in input order"""
-        stride = max(4, 3 * (self.pack.n - 1))
+        stride = max(13, 3 * (self.pack.n - 1), 1 + 5 * (2 * self.pack.n - 1))
         out = np.zeros((self.end - self.begin, stride))
         self._chk(self.lib.gph_engine_unit(self.engine, op, arg, out.ctypes.data_as(C.POINTER(C.c_double)), stride), "unit")
         return out

@@ -54,7 +54,7 @@ GPH_KERNEL(k_mix_eval, GphKargs KA, GphDev D, int j0, int fuse) { GphCtxG lx; lx
 GPH_KERNEL(k_mix_finish, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_mix_finish(D, j0 + GPH_BLK); }
 GPH_KERNEL(k_sync, GphKargs KA, GphDev D, int j0, int refresh) { GphCtxG lx; lx.kb_sync(D, j0 + GPH_BLK, refresh); }
 GPH_KERNEL(k_check, GphKargs KA, GphDev D, int j0, int unused) { (void)unused; GphCtxG lx; lx.kb_check(D, j0 + GPH_BLK); }
-GPH_KERNEL(k_unit, GphKargs KA, GphDev D, int j0, int op, double *out, int stride) { GphCtxG lx; lx.kb_unit(D, j0 + GPH_BLK, op, out, stride); }
+GPH_KERNEL(k_unit, GphKargs KA, GphDev D, int j0, int op, int arg, double *out, int stride) { GphCtxG lx; lx.kb_unit(D, j0 + GPH_BLK, op, arg, out, stride); }
 GPH_KERNEL(k_lrate_prep, GphKargs KA, GphDev D, int j0, double finetune, GphLrPre *pre) { GphCtx lx; lx.kb_lrate_prep(D, j0 + GPH_BLK, finetune, pre); }
 GPH_KERNEL(k_lrate_scan, GphKargs KA, GphDev D, int j0, GphLrArgs A) { (void)j0; GphCtx lx; lx.kb_lrate_scan(D, A); }
 GPH_KERNEL(k_lrate_apply, GphKargs KA, GphDev D, int j0, const GphLrRec *rec) { GphCtx lx; lx.kb_lrate_apply(D, j0 + GPH_BLK, rec); }
@@ -2040,10 +2040,16 @@ int gph_engine_part_(gph_engine *e, int32_t part, int32_t iteration, const doubl
 // every call undone.  out: [local loci][stride] doubles in input order, stride >= 3 (n - 1).
 //   op 0: per internal node tnew, lnLd, dprior;  op 1: full recompute value;  op 2: rubber band (pre) of ancestral
 //   population `arg`: delta, n0, n1, lik -- the proposal (bounds, factors) is derived from the model exactly as
-//   oracle/ref_harness.c `unit` derives it
+//   oracle/ref_harness.c `unit` derives it;  ops 3-6 (ref_harness.c `unit2`): executeGenSPR of node arg onto a fixed list
+//   of branches (stride >= 1 + 5 N: calls, then target, age, return code, value, root per call), scaleAllNodeAges by
+//   1 + arg / 1000 + revert + full recompute (delta, value), rubberBandRipple do / undo (moved events, two deltas),
+//   traceLineage(arg, 0 / 1) + evaluation (stride >= 13: 1, res, target, father's new population, old / new migration
+//   events, both prior deltas, father's new age, data delta, generator state)
 int gph_engine_unit(gph_engine *e, int32_t op, int32_t arg, double *out, int32_t stride)
 {
-  if (!e || !e->initialized || !out || op < 0 || op > 2 || stride < 3 * (e->cfg.n - 1) || stride < 4) return GPH_EARG;
+  if (!e || !e->initialized || !out || op < 0 || op > 6 || stride < 3 * (e->cfg.n - 1) || stride < 4) return GPH_EARG;
+  if ((op == 3 && stride < 1 + 5 * (2 * e->cfg.n - 1)) || (op == 6 && stride < 13)) return GPH_EARG;
+  if ((op == 3 || op == 6) && (arg < 0 || arg >= 2 * e->cfg.n - 1)) return GPH_EARG;
   SETDEV(e);
   { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
   if (op == 2) {
@@ -2076,7 +2082,7 @@ int gph_engine_unit(gph_engine *e, int32_t op, int32_t arg, double *out, int32_t
   if (hipMemsetAsync(d_out, 0, bytes, e->stream) != hipSuccess) rc = GPH_EHIP;
 #endif
   if (!rc) {
-    auto launch = [&]() -> int { LAUNCH(e, 12, k_unit, (int)op, d_out, (int)stride); return 0; };
+    auto launch = [&]() -> int { LAUNCH(e, 12, k_unit, (int)op, (int)arg, d_out, (int)stride); return 0; };
     rc = launch();
   }
   if (!rc) rc = reduce_local(e, 0, GPH_OUT_SLOTS);

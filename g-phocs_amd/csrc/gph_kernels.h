@@ -1197,7 +1197,7 @@ GPH_DEV void kb_check(const GphDev &D, int g)
 //   op 1  computeLocusDataLikelihood(useOld=0) -> uo[0]
 //   op 2  rubberBand(pre) x3 of the ancestral population in the chain state's pending proposal + evaluation
 //         (UpdateTau loop 1 without the ripple, GPhoCS.c:3705-3831) -> uo[0..3] = delta, n0, n1, lik
-GPH_DEV void kb_unit(const GphDev &D, int g, int op, double *out, int stride)
+GPH_DEV void kb_unit(const GphDev &D, int g, int op, int arg, double *out, int stride)
 {
   double *uo = out + (size_t)D.orig[g] * stride;
   stage_in(D, g, D.pages, 1);
@@ -1232,7 +1232,7 @@ GPH_DEV void kb_unit(const GphDev &D, int g, int op, double *out, int stride)
     const double v = lik_compute(0);
     lik_reset_saved();
     if (GPH_LANE == 0) uo[0] = v;
-  } else {
+  } else if (op == 2) {
     gph_ctau &A = GPH_G->tau;
     int n0 = 0, n1 = 0;
     double d, lik = 0.0;
@@ -1243,6 +1243,92 @@ GPH_DEV void kb_unit(const GphDev &D, int g, int op, double *out, int stride)
     if (n0 + n1) { lik = -FS(FS_DATALNL); lik += lik_compute(1); }
     lik_revert();
     if (GPH_LANE == 0) { uo[0] = d; uo[1] = n0; uo[2] = n1; uo[3] = lik; }
+  } else if (op == 3) {
+    /* executeGenSPR of node `arg` onto its father's, its sibling's, the root's and every fifth other legal branch, at a
+     * fixed point of the legal age window, + computeLocusDataLikelihood(1), + revertToSaved (oracle/ref_harness.c: unit2 D):
+     * uo[0] = calls, then target, age, return code, value, root after the call */
+    const int node = arg, root = ISC(IS_ROOT);
+    int cnt = 0;
+    if (node != root) {
+      const int father = FATH(node), sibling = LEFT(father) + RGHT(father) - node, grandpa = FATH(father);
+      for (int target = 0; target < g_lay.N; target++) {
+        if (target == node) continue;
+        { int x = target, guard = 0, under = 0;
+          while (x >= 0 && guard++ < g_lay.N) { if (x == node) { under = 1; break; } x = FATH(x); }
+          if (under) continue; }
+        if (!(target == father || target == sibling || target == root || (target + node) % 5 == 0)) continue;
+        double lo, hi;
+        if (target == father || target == sibling) {
+          lo = gmax2(AGE(node), AGE(sibling));
+          hi = grandpa >= 0 ? AGE(grandpa) : lo * 1.3 + 1e-6;
+        } else {
+          const int tf = FATH(target);
+          lo = gmax2(AGE(node), AGE(target));
+          hi = tf >= 0 ? AGE(tf) : lo * 1.3 + 1e-6;
+        }
+        if (!UNI(hi > lo)) continue;
+        const double age = lo + 0.37 * (hi - lo);
+        const int ret = lik_spr(node, target, age);
+        const double lnl = lik_compute(1);
+        const int nroot = ISC(IS_ROOT);
+        lik_revert();
+        if (GPH_LANE == 0 && 1 + 5 * (cnt + 1) <= stride) {
+          double *r = uo + 1 + 5 * cnt;
+          r[0] = target; r[1] = age; r[2] = ret; r[3] = lnl; r[4] = nroot;
+        }
+        cnt++;
+      }
+    }
+    if (GPH_LANE == 0) uo[0] = cnt;
+  } else if (op == 4) {
+    /* scaleAllNodeAges(1 + arg / 1000), revertToSaved, full recompute (unit2 E) */
+    const double factor = 1.0 + arg * 0.001;
+    const double d = lik_scale_ages(factor);
+    lik_revert();
+    const double v2 = lik_compute(0);
+    lik_reset_saved();
+    if (GPH_LANE == 0) { uo[0] = d; uo[1] = v2; }
+  } else if (op == 5) {
+    /* rubberBandRipple(do) + rubberBandRipple(undo) over the source-side events of every migration event, 0.01 % older
+     * (unit2 F) */
+    int nm = 0;
+    for (int i = 0; i < ISC(IS_NUM_MIGS); i++) {
+      const int mig = LIVING(i), pop = MG(mig, MG_SPOP);
+      const double na = MAGE(mig) * 1.0001;
+      const double top = pop == g_lay.rootPop ? GPH_OLDAGE : g_model.popAge[g_model.popFather[pop]];
+      if (!UNI(na < top)) continue;
+      setRBI(0, nm, MG(mig, MG_SEV));
+      setRBI(2, nm, pop);
+      sf64(&GphLds::rb_age, nm, na);
+      nm++;
+    }
+    setISC(IS_RB_NUM, nm);
+    const double d1 = rubber_band_ripple(1);
+    const double d0 = rubber_band_ripple(0);
+    if (GPH_LANE == 0) { uo[0] = nm; uo[1] = d1; uo[2] = d0; }
+  } else {
+    /* op 6: traceLineage(arg, 0) + traceLineage(arg, 1) as UpdateGB_MigSPR calls them + the evaluation (unit2 G); nothing is
+     * undone: this kernel does not write the page back */
+    const int node = arg;
+    if (node != ISC(IS_ROOT)) {
+      const int father = FATH(node);
+      GphRng rng;
+      rng_load(rng);
+#if GPH_BIG_BANDS || defined(GPH_TWO_WALKS)
+      trace_lineage<0>(node, rng);
+      const int res = trace_lineage<1>(node, rng);
+#else
+      const int res = trace_pair(node, rng);
+#endif
+      double lnl = -FS(FS_DATALNL);
+      lnl += lik_compute(1);
+      rng_store(rng);
+      if (GPH_LANE == 0) {
+        uo[0] = 1; uo[1] = res; uo[2] = res >= 0 ? SPRI(SI_TARGET) : -1; uo[3] = res >= 0 ? SPRI(SI_FPOP_NEW) : -1;
+        uo[4] = SPRI(SI_NOLD); uo[5] = SPRI(SI_NNEW); uo[6] = SPRLN(0); uo[7] = SPRLN(1); uo[8] = AGE(father); uo[9] = lnl;
+        uo[10] = (double)(uint32_t)ISC(IS_RX); uo[11] = (double)(uint32_t)ISC(IS_RY); uo[12] = (double)(uint32_t)ISC(IS_RZ);
+      }
+    } else if (GPH_LANE == 0) uo[0] = 0;
   }
   out_common(D, g);
 }

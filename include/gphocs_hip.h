@@ -190,7 +190,14 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditiona
  * (tests/golden/ *.unit).  out[local loci][stride] in input order.  op 0: per internal node i (stride >= 3 (n-1)):
  * tnew, lnLd, dprior of adjustGenNodeAge + computeLocusDataLikelihood(1) + considerEventMove (GPhoCS.c:2316-2381);
  * op 1: computeLocusDataLikelihood(useOld=0); op 2: rubberBand(pre) x3 of ancestral population arg + evaluation
- * (GPhoCS.c:3705-3831): delta, n0, n1, lik */
+ * (GPhoCS.c:3705-3831): delta, n0, n1, lik.  Second set (`unit2`, tests/golden/ *.unit2): op 3: executeGenSPR of node arg
+ * (LocusDataLikelihood.c:931-1012; return codes 0 / 1 / 2) onto its father's, its sibling's, the root's and every fifth other
+ * legal branch + computeLocusDataLikelihood(1) + revertToSaved (stride >= 1 + 5 (2n-1): calls, then target, age, code, value,
+ * root); op 4: scaleAllNodeAges(1 + arg / 1000) (LocusDataLikelihood.c:895-917) + revertToSaved + full recompute: delta,
+ * value; op 5: rubberBandRipple(do) + (undo) (patch.c:815-869) over every migration event's source-side event moved 0.01 %
+ * up: events, two deltas; op 6: traceLineage(arg, 0) + traceLineage(arg, 1) (patch.c:886-1331) + evaluation (stride >= 13:
+ * 1, res, target, father's new population, migration events removed / created, both prior deltas, father's new age, data
+ * delta, the locus's generator state) */
 int gph_engine_unit(gph_engine *e, int32_t op, int32_t arg, double *out, int32_t stride);
 /* timing of the last launch of a named kernel class, measured with HIP events on the
  * engine's own stream: which = 0 sweep, 1 tau_eval, 2 mix_eval, 3 init, 4 check,

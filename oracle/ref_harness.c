@@ -423,6 +423,148 @@ static int cmd_unit(int argc, char **argv)
   return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* kernel-level fixtures, second set (the rest of G3 / G4): after `iters` iterations, single calls of
+ *   D g node target age ret lnl root     executeGenSPR(node, target, age) + computeLocusDataLikelihood(useOld=1), then
+ *                                        revertToSaved: every return code (0: same root, 1: regrafted above the root,
+ *                                        2: pruned from below the root), LocusDataLikelihood.c:931-1012.  For every non-root
+ *                                        node the targets are: its father, its sibling, the root, and every fifth other
+ *                                        node outside its subtree; the age is a fixed point of the legal window
+ *   E g arg delta v2                     scaleAllNodeAges(1 + arg / 1000) (LocusDataLikelihood.c:895-917), revertToSaved,
+ *                                        then a full recompute (v2 = the value before the call if the revert is complete)
+ *   F g n d_do d_undo                    rubberBandRipple(do) then rubberBandRipple(undo) (patch.c:815-869) over a list of
+ *                                        moved events made of every migration event's source-side event, 0.01 % older
+ *   G g node res target fpop nold nnew dl0 dl1 fage lnl x y z
+ *                                        traceLineage(node, 0) + traceLineage(node, 1) (patch.c:886-1331) as UpdateGB_MigSPR
+ *                                        calls them (GPhoCS.c:2659-2700) + computeLocusDataLikelihood(1): the sampled
+ *                                        regraft (target edge, father's new population and age), the migration events
+ *                                        removed / created, both prior deltas, the locus's generator state afterwards
+ * F and G change the chains; they run in forked children, so that every call starts from the same state. */
+#include <sys/wait.h>
+#include <unistd.h>
+static int u2_descends(LocusData *ld, int x, int anc)
+{
+  while (x >= 0) { if (x == anc) return 1; x = getNodeFather(ld, x); }
+  return 0;
+}
+static int cmd_unit2(int argc, char **argv)
+{
+  char *ctl = argv[2];
+  int iters = atoi(argv[3]);
+  FILE *of = fopen(argv[4], "w");
+  int it, gen, node, target, i, n, N, *acceptCountArray, k;
+  PopulationTree *pt;
+  static const int scale_args[2] = {-30, 4};
+  if (!of) { perror(argv[4]); return 2; }
+  startup(ctl);
+  pt = dataSetup.popTree;
+  n = dataSetup.numSamples; N = 2 * n - 1;
+  acceptCountArray = (int *)calloc(pt->numPops, sizeof(int));
+  misc_stats.rubberband_mig_conflicts = 0;
+  misc_stats.not_enough_migs = 0;
+  initializeMCMC();
+  { FILE *nul = fopen("/dev/null", "w"); for (it = 0; it < iters; it++) one_iteration(nul, it, acceptCountArray, 1); fclose(nul); }
+  /* D */
+  for (gen = 0; gen < dataSetup.numLoci; gen++) {
+    LocusData *ld = dataState.lociData[gen];
+    int root = getLocusRoot(ld);
+    for (node = 0; node < N; node++) {
+      int father, sibling, grandpa;
+      if (node == root) continue;
+      father = getNodeFather(ld, node);
+      sibling = getNodeSon(ld, father, 0) + getNodeSon(ld, father, 1) - node;
+      grandpa = getNodeFather(ld, father);
+      for (target = 0; target < N; target++) {
+        double lo, hi, age, lnl;
+        int ret, tf;
+        if (target == node || u2_descends(ld, target, node)) continue;
+        if (!(target == father || target == sibling || target == root || (target + node) % 5 == 0)) continue;
+        if (target == father || target == sibling) {
+          lo = max2(getNodeAge(ld, node), getNodeAge(ld, sibling));
+          hi = grandpa >= 0 ? getNodeAge(ld, grandpa) : lo * 1.3 + 1e-6;
+        } else {
+          tf = getNodeFather(ld, target);
+          lo = max2(getNodeAge(ld, node), getNodeAge(ld, target));
+          hi = tf >= 0 ? getNodeAge(ld, tf) : lo * 1.3 + 1e-6;
+        }
+        if (!(hi > lo)) continue;
+        age = lo + 0.37 * (hi - lo);
+        ret = executeGenSPR(ld, node, target, age);
+        lnl = computeLocusDataLikelihood(ld, 1);
+        fprintf(of, "D %d %d %d %a %d %a %d\n", gen, node, target, age, ret, lnl, getLocusRoot(ld));
+        revertToSaved(ld);
+      }
+    }
+  }
+  /* E */
+  for (k = 0; k < 2; k++) {
+    const double factor = 1.0 + scale_args[k] * 0.001;
+    for (gen = 0; gen < dataSetup.numLoci; gen++) {
+      LocusData *ld = dataState.lociData[gen];
+      double d = scaleAllNodeAges(ld, factor), v2;
+      revertToSaved(ld);
+      v2 = computeLocusDataLikelihood(ld, 0);
+      resetSaved(ld);
+      fprintf(of, "E %d %d %a %a\n", gen, scale_args[k], d, v2);
+    }
+  }
+  fflush(of);
+  /* F */
+  { pid_t pid = fork();
+    if (pid == 0) {
+      for (gen = 0; gen < dataSetup.numLoci; gen++) {
+        RUBBERBAND_MIGS *rb = &locus_data[gen].rubberband_migs;
+        double d1, d0;
+        int nm;
+        rb->num_moved_events = 0;
+        for (i = 0; i < genetree_migs[gen].num_migs; i++) {
+          int mig = genetree_migs[gen].living_mignodes[i], pop = genetree_migs[gen].mignodes[mig].source_pop;
+          double na = genetree_migs[gen].mignodes[mig].age * 1.0001;
+          double top = pop == pt->rootPop ? OLDAGE : pt->pops[pop]->father->age;
+          if (!(na < top)) continue;
+          rb->orig_events[rb->num_moved_events] = genetree_migs[gen].mignodes[mig].source_event;
+          rb->pops[rb->num_moved_events] = pop;
+          rb->new_ages[rb->num_moved_events] = na;
+          rb->num_moved_events++;
+        }
+        nm = rb->num_moved_events;
+        d1 = rubberBandRipple(gen, 1);
+        d0 = rubberBandRipple(gen, 0);
+        fprintf(of, "F %d %d %a %a\n", gen, nm, d1, d0);
+      }
+      fflush(of);
+      _exit(0);
+    }
+    { int st = 0; waitpid(pid, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) { fprintf(stderr, "unit2: F child failed\n"); return 3; } }
+  }
+  /* G */
+  for (node = 0; node < N; node++) {
+    pid_t pid = fork();
+    if (pid == 0) {
+      for (gen = 0; gen < dataSetup.numLoci; gen++) {
+        LocusData *ld = dataState.lociData[gen];
+        MIG_SPR_STATS *ms = &locus_data[gen].mig_spr_stats;
+        int res, father;
+        double lnl;
+        if (node == getLocusRoot(ld)) continue;
+        father = getNodeFather(ld, node);
+        traceLineage(gen, node, 0);
+        res = traceLineage(gen, node, 1);
+        lnl = -getLocusDataLikelihood(ld);
+        lnl += computeLocusDataLikelihood(ld, 1);
+        fprintf(of, "G %d %d %d %d %d %d %d %a %a %a %a %u %u %u\n", gen, node, res, res >= 0 ? ms->target : -1,
+                res >= 0 ? ms->father_pop_new : -1, ms->num_old_migs, ms->num_new_migs, ms->genetree_delta_lnLd[0],
+                ms->genetree_delta_lnLd[1], getNodeAge(ld, father), lnl, RndCtx.rndu_x[gen], RndCtx.rndu_y[gen], RndCtx.rndu_z[gen]);
+      }
+      fflush(of);
+      _exit(0);
+    }
+    { int st = 0; waitpid(pid, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) { fprintf(stderr, "unit2: G child failed (node %d)\n", node); return 3; } }
+  }
+  fclose(of);
+  return 0;
+}
+
 static double now_s(void)
 {
   struct timespec ts;
@@ -555,6 +697,7 @@ int main(int argc, char **argv)
   if (!strcmp(argv[1], "pack") && argc >= 4) return cmd_pack(argv[2], argv[3]);
   if (!strcmp(argv[1], "run") && argc >= 5) return cmd_run(argc, argv);
   if (!strcmp(argv[1], "unit") && argc >= 5) return cmd_unit(argc, argv);
+  if (!strcmp(argv[1], "unit2") && argc >= 5) return cmd_unit2(argc, argv);
   if (!strcmp(argv[1], "time") && argc >= 4) return cmd_time(argc, argv);
   if (!strcmp(argv[1], "timesweep") && argc >= 5) return cmd_timesweep(argc, argv);
   if (!strcmp(argv[1], "ingest") && argc >= 3) return cmd_ingest(argv[2]);

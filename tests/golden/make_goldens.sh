@@ -81,6 +81,7 @@ timeout 900 $REF main -n 1 x8.ctl >/dev/null 2>&1     # x8.trace: the reference'
 
 # kernel-level fixtures: single calls of the reference's per-locus functions after N iterations
 for c in "m4 60" "a7 40" "g2 20"; do set -- $c; timeout 300 $REF unit $1.ctl $2 $1.unit >/dev/null 2>&1; done
+for c in "m4 60" "a7 40" "g2 20"; do set -- $c; timeout 600 $REF unit2 $1.ctl $2 $1.unit2 >/dev/null 2>&1; done   # executeGenSPR, scaleAllNodeAges, rubberBandRipple, traceLineage
 
 # y9: beyond 32 leaves / 32 populations -- 40 leaves, 20 current populations (the reference's NSPECIES cap: 39 populations),
 # 16 migration bands (library variant `h`: two genealogy nodes per lane would not do, the node sets are 128 bits wide)

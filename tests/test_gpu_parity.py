@@ -320,6 +320,8 @@ def test_kernel_level_fixtures(G, name):
     pk = G.Pack.load(os.path.join(GOLDEN, name + ".gpk"))
     lib = G.load_library(dims=(pk.n, pk.K, pk.B))
     assert unit_fixture.check_unit(G, lib, GOLDEN, name) > 100
+    # second set: executeGenSPR (return codes 0 / 1 / 2), scaleAllNodeAges + revert, rubberBandRipple do / undo, traceLineage
+    assert unit_fixture.check_unit2(G, lib, GOLDEN, name) > 1000
 
 
 def test_native_library_is_the_path(G):

@@ -157,6 +157,8 @@ def test_kernel_level_fixtures_hostemu(hostemu, name):
     import unit_fixture
     _, lib = hostemu
     assert unit_fixture.check_unit(G, lib, GOLDEN, name) > 100
+    # executeGenSPR with every return code, scaleAllNodeAges + revert, rubberBandRipple do / undo, traceLineage outcomes
+    assert unit_fixture.check_unit2(G, lib, GOLDEN, name) > 1000
 
 
 def test_reinitialise_drops_an_owed_mixing_commit(hostemu, tmp_path):
