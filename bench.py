@@ -157,7 +157,10 @@ def cpu_baseline_reference(config, pack, nloci, iters, small_loci, small_iters):
                                 1000, 100000)
             counts = sorted({t for t in (1, 8, 16, 32, ncores) if t <= ncores})
             t0 = time.perf_counter()
-            r = subprocess.run([ref_omp, "timesweep", "b.ctl", str(iters), "1", ",".join(map(str, counts))], cwd=td,
+            # >= 5 timed iterations per thread count, each timed on its own, the MEDIAN is the figure; the all-cores count
+            # (never the best: the `omp atomic` accumulations and a static split over few loci per thread) gets 3
+            spec = ",".join(f"{t}:3" if t == ncores and t > 64 else str(t) for t in counts)
+            r = subprocess.run([ref_omp, "timesweep", "b.ctl", str(iters), "1", spec], cwd=td,
                                check=True, capture_output=True, text=True, timeout=1500)
             rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
             by = {int(x["threads"]): x for x in rows if "threads" in x}
@@ -165,10 +168,14 @@ def cpu_baseline_reference(config, pack, nloci, iters, small_loci, small_iters):
             out.update({"value": best["evals_per_s"], "cores": int(best["threads"]),
                         "sample": f"first {nloci} loci of the workload (sequence file, {nloci * 0.035:.0f} MB of per-locus state) "
                                   f"on the reference's OpenMP build: one start-up ({rows[0].get('startup_seconds', 0):.0f} s, untimed), "
-                                  f"then 1 warm-up + {iters} timed iterations at each of {counts} threads; best = "
-                                  f"{int(best['threads'])} threads ({best['seconds']:.1f} s); whole leg {time.perf_counter() - t0:.0f} s",
-                        "iters_per_s_at_sample": best["iters_per_s"],
-                        "by_threads": {str(t): {"value": x["evals_per_s"], "seconds": x["seconds"]} for t, x in sorted(by.items())}})
+                                  f"then 1 warm-up + {iters} iterations timed one by one at each of {counts} threads, value = from the "
+                                  f"MEDIAN iteration; best = {int(best['threads'])} threads ({best['seconds']:.1f} s); whole leg "
+                                  f"{time.perf_counter() - t0:.0f} s",
+                        "iters_per_s_at_sample": best["iters_per_s"], "statistic": "median of the timed iterations",
+                        "by_threads": {str(t): {"value": x["evals_per_s"], "seconds": x["seconds"], "iterations": x["iters"],
+                                                "median_iteration_s": x.get("median_iteration_seconds"),
+                                                "min_iteration_s": x.get("min_iteration_seconds"),
+                                                "max_iteration_s": x.get("max_iteration_seconds")} for t, x in sorted(by.items())}})
         write_seq_sample(pack, small_loci, os.path.join(td, "s.seq"))
         gen_synth.write_ctl(os.path.join(td, "s.ctl"), gen_synth.CONFIGS[config], "s.seq", "s.trace", small_loci, 12345,
                             1000, 100000)
@@ -383,7 +390,7 @@ def main():
                     "after 200 iterations from the prior-sampled start)")
     ap.add_argument("--samples-per-log", type=int, default=0, help="checkAll period (0 = the pack's: 100)")
     ap.add_argument("--cpu-loci", type=int, default=20000, help="loci of the CPU baseline's data set (the first ones of the workload)")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=5, help="timed iterations per thread count of the CPU baseline (median reported)")
     ap.add_argument("--cpu-small-loci", type=int, default=5000, help="the secondary, cache-friendlier CPU sample")
     ap.add_argument("--cpu-small-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -577,7 +584,14 @@ def main():
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                if tj.get("loci") == L_local and tj.get("build_id") == build_id:
+                compiler_now = lib.gph_build_compiler().decode()
+                # (the build id no longer hashes the compiler, so the counters are accepted only for the same
+                # sources + flags AND the same compiler as the library they were measured with)
+                same_compiler = tj.get("compiler") == compiler_now
+                if tj.get("loci") == L_local and tj.get("build_id") == build_id and tj.get("compiler") is not None and not same_compiler:
+                    traffic_src = (f"none: profiles/traffic_k_sweep.json was measured with a library built by '{tj.get('compiler')}', "
+                                   f"the loaded library was built by '{compiler_now}'")
+                elif tj.get("loci") == L_local and tj.get("build_id") == build_id:
                     traffic = tj["hbm_bytes_per_launch"]
                     traffic_src = "profiles/traffic_k_sweep.json (%s)" % tj.get("build", "committed rocprofv3 --pmc passes, not this run")
                     if tj.get("valu_per_wave") and sweep_ms > 0:
@@ -630,7 +644,12 @@ def main():
                        "parallelism": f"loci sharded over {world} rank(s), one process per GPU"
                                       + (f", native {comm_kind} exchange of the reduced row" + (" on the engine's stream" if hs1["resident"] else "") if comm else
                                          (", torch.distributed hook" + (" (fallback: the RCCL communicator could not be created)" if comm_fallback else "") if dist else ""))},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep (fused UpdateGB_InternalNode+MigrationNode+MigSPR)",
+            # bound: what BINDS the dominant kernel as measured ("issue": the length of a locus's dependent instruction
+            # stream, with the vector pipe, the CU's scalar unit and the LDS pipe each half to three-quarters busy -- the `issue`
+            # object; no memory pipe binds); achieved / peak / frac stay SURVEY 8d's accounting against the HBM peak, which is
+            # the roofline the path is HBM-bound by construction under (0.33 flop/B)
+            "roofline": {"bound": "issue", "bound_by_construction": "hbm",
+                         "kernel": "k_sweep (fused UpdateGB_InternalNode+MigrationNode+MigSPR)",
                          "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "accounting": "ALGORITHMIC bytes per evaluation (96 R P + 20 N + 8 U + 8, SURVEY 8d) / HIP-event "
                                        "kernel time; mostly L2 / Infinity-Cache hits, see hbm_counter_frac for DRAM",

@@ -321,6 +321,7 @@ struct gph_engine {
   // mirror does (host mode: a caller-supplied all-reduce hook forces a synchronisation per reduction anyway)
   GphGlobal *G_h = nullptr, *G_d = nullptr;
   bool G_dirty = true;               // the host mirror was changed since it was last pushed
+  int64_t n_huge = 0;                // loci whose sequence block stays in HBM (the first slots)
   int32_t last_error_code = 0;       // the last fatal error check_error reported (gph_engine_last_error)
   long long last_error_locus = -1;
   bool in_error_dump = false;
@@ -422,6 +423,7 @@ static void build_layout(GphLayout &y, int n, int Kc, int K, int B, int rootPop,
   y.cnt16 = cnt16;
   y.dyn_bytes = 0;
   y.lds_bytes = GPH_Q_TERMS(Pmax, n, cnt16) + (Pmax > GPH_WAVE ? 8 * Pmax : 8 * GPH_WAVE);
+  y.huge_P = 0x7fffffff;
 }
 
 static void build_model_static(gph_engine *e)
@@ -532,11 +534,11 @@ static void tm_end(gph_engine *e, int slot) { if (slot >= 0) (void)hipEventRecor
 #define LAUNCH_PRE(e) do { GphKargs &ka_ = (e)->ka; GPH_KA_MODEL(ka_, e); ka_.lay = (e)->lay; ka_.G = (e)->G_d; } while (0)
 #define LAUNCH(e, which, name, ...) do { { int rcf_ = flush_pending(e); if (rcf_) return rcf_; } LAUNCH_PRE(e); GphKargs &ka_ = (e)->ka; \
     const int tms_ = tm_begin((e), (which)); \
-    const bool fork_ = (e)->side_stream && (e)->buckets.size() == 2; \
+    const bool fork_ = (e)->side_stream && (e)->buckets.size() >= 2; \
     if (fork_) { HIPCHK(hipEventRecord((e)->ev_fork, (e)->stream)); HIPCHK(hipStreamWaitEvent((e)->stream_wide, (e)->ev_fork, 0)); } \
     for (size_t bi_ = 0; bi_ < (e)->buckets.size(); bi_++) { auto &bk_ = (e)->buckets[bi_]; \
       ka_.lay.dyn_bytes = bk_.lds_bytes; \
-      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes + (e)->lds_pad[which], fork_ && bi_ == 0 ? (e)->stream_wide : (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
+      hipLaunchKernelGGL(name, dim3((unsigned)bk_.count), dim3(GPH_WAVE), bk_.lds_bytes + (e)->lds_pad[which], fork_ && bi_ + 1 < (e)->buckets.size() ? (e)->stream_wide : (e)->stream, ka_, (e)->dev, bk_.j0, __VA_ARGS__); \
       HIPCHK(hipGetLastError()); (e)->n_launches++; } \
     if (fork_) { HIPCHK(hipEventRecord((e)->ev_join, (e)->stream_wide)); HIPCHK(hipStreamWaitEvent((e)->stream, (e)->ev_join, 0)); } \
     tm_end((e), tms_); \
@@ -1049,9 +1051,20 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   for (int64_t i = 0; i < poff[L]; i++) if (counts[i] < 0 || counts[i] > 65535) { cnt16 = 0; break; }
   if (const char *ov = getenv("GPH_CNT16")) cnt16 = cnt16 && atoi(ov) != 0;     /* tests: the 32-bit form */
   build_layout(e->lay, n, e->cfg.Kc, e->cfg.K, e->cfg.B, e->cfg.rootPop, Pmax, cnt16);
-  if (e->lay.lds_bytes + (int)sizeof(GphLds) > 160 * 1024) {
-    fprintf(stderr, "gphocs_hip: a locus with %d phased patterns needs %d bytes of LDS (> 160 KiB)\n", Pmax, e->lay.lds_bytes);
-    return GPH_EARG;
+  /* A locus whose sequence block does not fit the LDS budget of a launch group keeps it in HBM ("huge": its own launch
+   * group, the generic (pattern, base) paths read the block through GphSeq -- gph_rt.h; the reference mallocs any P,
+   * LocusDataLikelihood.c:251).  The budget is what ONE pattern-rich locus may cost every other one in resident
+   * wavefronts: the whole group is launched with the LDS of its largest block (default 32 KB = 5 wavefronts per CU, or
+   * the image + 16 KB for the big-tree builds;
+   * GPH_HUGE_LDS=bytes -- tests force the HBM path on small loci with it). */
+  {
+    int budget = 32 * 1024;
+    if (budget < (int)sizeof(GphLds) + 16 * 1024) budget = (int)sizeof(GphLds) + 16 * 1024;     /* (the big-tree builds' images alone are 9 - 44 KB) */
+    if (const char *ov = getenv("GPH_HUGE_LDS")) budget = atoi(ov);
+    if (budget > 160 * 1024) budget = 160 * 1024;
+    int hp = GPH_WAVE;     /* (a block of up to GPH_WAVE patterns always fits: the lane-per-pattern paths read LDS directly) */
+    while (hp < Pmax && (int)sizeof(GphLds) + GPH_Q_BYTES(hp + 1, n, cnt16) <= budget) hp++;
+    e->lay.huge_P = hp >= Pmax ? 0x7fffffff : hp;
   }
   e->L = L;
   // slots in decreasing P (stable): within a dispatch the longest wavefronts start first; loci with more
@@ -1062,12 +1075,28 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
     return (poff[a + 1] - poff[a]) > (poff[b + 1] - poff[b]); });
   e->buckets.clear();
   {
-    int64_t nwide = 0;
+    int64_t nwide = 0, nhuge = 0;
+    while (nhuge < L && (poff[e->h_orig[nhuge] + 1] - poff[e->h_orig[nhuge]]) > e->lay.huge_P) nhuge++;
+    nwide = nhuge;
     while (nwide < L && (poff[e->h_orig[nwide] + 1] - poff[e->h_orig[nwide]]) > GPH_WAVE) nwide++;
-    if (nwide > 0) {
+    e->n_huge = nhuge;
+    if (nhuge > 0 && e->cfg.locus_begin == 0)
+      fprintf(stderr, "gphocs_hip: %lld loci with more than %d phased patterns (up to %d) keep their sequence block in HBM\n",
+              (long long)nhuge, e->lay.huge_P, Pmax);
+    if (nhuge > 0) {        /* sequence block in HBM: no dynamic LDS beyond a token allocation */
       gph_engine::Bucket bk;
-      bk.j0 = 0; bk.count = (int)nwide;
-      bk.lds_bytes = GPH_Q_TERMS(Pmax, n, cnt16) + 8 * Pmax;
+      bk.j0 = 0; bk.count = (int)nhuge;
+      bk.lds_bytes = 64;
+      e->buckets.push_back(bk);
+    }
+    if (nwide > nhuge) {    /* the generic (pattern, base) mapping, block in LDS (the root sum needs no terms array on the device) */
+      const int pw = (int)(poff[e->h_orig[nhuge] + 1] - poff[e->h_orig[nhuge]]);
+      gph_engine::Bucket bk;
+      bk.j0 = (int)nhuge; bk.count = (int)(nwide - nhuge);
+      bk.lds_bytes = GPH_Q_TERMS(pw, n, cnt16);
+#ifdef GPH_HOSTEMU
+      bk.lds_bytes += 8 * pw;
+#endif
       e->buckets.push_back(bk);
     }
     if (nwide < L) {
@@ -1103,6 +1132,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
     }
   }
   /* (a group that was given the rest of its granules for the root sum's terms can be larger than block + 512 bytes) */
+  e->lay.lds_bytes = 0;
   for (auto &bk : e->buckets) if (bk.lds_bytes > e->lay.lds_bytes) e->lay.lds_bytes = bk.lds_bytes;
   e->h_cond_off.resize(L + 1);
   e->h_P.resize(L);
@@ -1117,6 +1147,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
     off += (uint64_t)2 * (n - 1) * P * 32;
     seq_off[j] = soff;
     soff += GPH_Q_BYTES(P, n, cnt16);
+    if (P > e->lay.huge_P) soff += (uint64_t)8 * ((P + 1) & ~1);     /* the root reduction's terms of the host build behind a block that lies in HBM */
     if (mutRates) rates[j] = mutRates[g];
   }
   e->h_cond_off[L] = off;
@@ -1699,6 +1730,12 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
   io->accepted = 0;
   if (finetune <= 0.0) return 0;                       /* GPhoCS.c:4606 */
   const bool owner = e->cfg.locus_begin == 0;          /* this rank holds the reference locus (genRateRef = 0) */
+  if (e->n_huge > 0) {
+    /* the serial scan stages the sequence block of the reference locus (and of a locus it re-evaluates) in LDS */
+    fprintf(stderr, "gphocs_hip: locus-mut-rate VAR with a locus of more than %d phased patterns (sequence block beyond the LDS "
+                    "budget of %s) is not supported\n", e->lay.huge_P, getenv("GPH_HUGE_LDS") ? "GPH_HUGE_LDS" : "32 KB");
+    return GPH_EARG;
+  }
   SETDEV(e);
   if (!multi_rank(e) && (!owner || e->cfg.L_total != e->L)) {
     fprintf(stderr, "gphocs_hip: UpdateLocusRate over a shard of the loci needs the all-reduce hook (gph_engine_set_allreduce)\n");

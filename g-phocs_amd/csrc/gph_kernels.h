@@ -52,6 +52,10 @@ GPH_DEV void scratch_init(const GphDev &D, int g, int P, uint64_t cond_off)
   setCNT(CN_P, P);
   setCNT(CN_QPH, GPH_Q_PHASES(P, g_lay.n)); setCNT(CN_QCNT, GPH_Q_COUNT(P, g_lay.n)); setCNT(CN_QTERMS, GPH_Q_TERMS(P, g_lay.n, g_lay.cnt16));
   setCNT(CN_SUMLDS, g_lay.lds_sum && GPH_Q_TERMS(P, g_lay.n, g_lay.cnt16) + 8 * ((P + 7) & ~7) <= g_lay.dyn_bytes);
+  if (P > g_lay.huge_P) {       /* the block stays in HBM: its address for the generic paths (seq_ref) */
+    const uint64_t a_ = (uint64_t)(uintptr_t)(D.seq + D.seq_off[g]);
+    setCNT(CN_HUGE, 1); setCNT(CN_SEQLO, (int)(uint32_t)a_); setCNT(CN_SEQHI, (int)(uint32_t)(a_ >> 32));
+  }
   sf64(&GphLds::s_cntf, 0, 0.0);
 #if defined(GPH_STAMPS) || defined(GPH_HOSTEMU)
   for (k = 0; k < 8; k++) gph_lds.s_stamp[k] = 0.0;
@@ -74,7 +78,9 @@ GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withSeq)
   if (withSeq) { o0 = D.seq_off[g]; o1 = D.seq_off[g + 1]; }
   const int P_ = D.P[g];                   /* per-locus table entries: scalar loads, in flight with everything else */
   const uint64_t co_ = D.cond_off[g];
-  gph_copy16_in2<PCH, SCH>(GPH_LDSP(&gph_lds), pages + (size_t)g * g_lay.page_bytes, g_lay.page_bytes >> 4, GPH_SMB, D.seq + o0, (int)(o1 - o0) >> 4);
+  /* (a locus whose block outgrows the launch group's LDS reads it where it lies: nothing to stage) */
+  gph_copy16_in2<PCH, SCH>(GPH_LDSP(&gph_lds), pages + (size_t)g * g_lay.page_bytes, g_lay.page_bytes >> 4, GPH_SMB, D.seq + o0,
+                           P_ > g_lay.huge_P ? 0 : (int)(o1 - o0) >> 4);
   GPH_SYNC();
   load_scalars();
   scratch_init(D, g, P_, co_);
@@ -107,12 +113,13 @@ GPH_DEV double eval_bytes()
   if (P <= 0 || full <= 0) return 0.0;
   const int q_phases = GPH_Q_PHASES(P, g_lay.n);
   int U = 0;
+  const GphSeq SQ = seq_ref();
 #ifdef GPH_HOSTEMU
-  for (int p = 0; p < P; p++) U += gu16v(q_phases, p) > 0;
+  for (int p = 0; p < P; p++) U += sq_u16v(SQ, q_phases, p) > 0;
 #else
   for (int p0 = 0; p0 < P; p0 += GPH_WAVE) {
     const int p = p0 + GPH_LANE;
-    U += __builtin_popcountll(__ballot(p < P && gu16v(q_phases, p < P ? p : 0) > 0));
+    U += __builtin_popcountll(__ballot(p < P && sq_u16v(SQ, q_phases, p < P ? p : 0) > 0));
   }
 #endif
   return (double)(96ll * (CNT(CN_NODES) - CNT(CN_NODES0)) * P + (long long)(20 * g_lay.N + 8 * U + 8) * full);
@@ -200,7 +207,7 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate, int
   int i;
   /* blank page */
   for (i = GPH_LANE; i < (int)(sizeof(GphLds) / 4); i += GPH_NLANES) ((GPH_LDS int32_t *)&gph_lds)[i] = 0;
-  copy16_g2l(0, D.seq + D.seq_off[g], (int)(D.seq_off[g + 1] - D.seq_off[g]));
+  if (D.P[g] <= g_lay.huge_P) copy16_g2l(0, D.seq + D.seq_off[g], (int)(D.seq_off[g + 1] - D.seq_off[g]));
   GPH_SYNC();
   scratch_init(D, g, D.P[g], D.cond_off[g]);
   setISC(IS_RX, 11);

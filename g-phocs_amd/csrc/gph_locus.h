@@ -608,6 +608,16 @@ GPH_DEV gdbl *cond_base()
   uint64_t lo = (uint32_t)RFL(gph_lds.s_condptr[0]), hi = (uint32_t)RFL(gph_lds.s_condptr[1]);
   return (gdbl *)(uintptr_t)(lo | (hi << 32));
 }
+// the sequence block as the generic (pattern, base) paths see it: dynamic LDS, or HBM for a locus whose block outgrows it
+GPH_DEV GphSeq seq_ref()
+{
+  GphSeq S; S.g = nullptr;
+  if (CNT(CN_HUGE)) {
+    const uint64_t lo = (uint32_t)CNT(CN_SEQLO), hi = (uint32_t)CNT(CN_SEQHI);
+    S.g = (GPH_GLB char *)(uintptr_t)(lo | (hi << 32));
+  }
+  return S;
+}
 GPH_DEV void set_cond_base(const void *p)
 {
   uint64_t v = (uint64_t)(uintptr_t)p;
@@ -624,11 +634,11 @@ GPH_DEV int cond_off(int node, int bit)
 // one child's factor for (pattern p, base a): computeSubtreeConditionals_new,
 // LocusDataLikelihood.c:1650-1673.  A leaf child is a base code (one-hot / N).
 template <class CP>
-GPH_DEV double child_factor(int child, CP cnd, int p, int a, double pe, double qe, int q_leaf = GPH_Q_LEAF)
+GPH_DEV double child_factor(int child, CP cnd, int p, int a, double pe, double qe, int q_leaf = GPH_Q_LEAF, const GphSeq SQ = GphSeq{nullptr})
 {
   double s0, s1, s2, s3, sa, S, Sp;
   if (child < g_lay.n) {
-    int code = GPH_LEAFCODE(q_leaf, p, child);
+    int code = GPH_LEAFCODE_S(SQ, q_leaf, p, child);
     s0 = (code == 4 || code == 0) ? 1.0 : 0.0;
     s1 = (code == 4 || code == 1) ? 1.0 : 0.0;
     s2 = (code == 4 || code == 2) ? 1.0 : 0.0;
@@ -664,13 +674,14 @@ GPH_DEV void prune_node(int node)
   gdbl *pc = cb + cond_off(node, CBIT(node));
   const gdbl *lc = cb + (l >= g_lay.n ? cond_off(l, CBIT(l)) : 0);
   const gdbl *rc = cb + (r >= g_lay.n ? cond_off(r, CBIT(r)) : 0);
+  const GphSeq SQ = seq_ref();
   int idx;
   for (idx = GPH_LANE; idx < 4 * P; idx += GPH_NLANES) {
     int p = idx >> 2, a = idx & 3;
     double v = 1.0, f;
-    f = child_factor(l, lc, p, a, pl, ql);
+    f = child_factor(l, lc, p, a, pl, ql, GPH_Q_LEAF, SQ);
     v *= f;
-    f = child_factor(r, rc, p, a, pr, qr);
+    f = child_factor(r, rc, p, a, pr, qr, GPH_Q_LEAF, SQ);
     v *= f;
     pc[idx] = v;
   }
@@ -762,10 +773,51 @@ GPH_DEVHOT double ordered_sum64_lds(double term, int P, int q_terms)
   return s;
 }
 #endif
+// root reduction of the generic (pattern, base) paths, LocusDataLikelihood.c:466-479: per unphased pattern
+// log(sum over phases and bases / (4 phases)) * count, summed in pattern order.  Device: 64 patterns at a time -- a lane per
+// pattern computes its term (a pattern that is a further phase of another one, or lies beyond P, contributes +0.0: x + 0.0
+// == x bit for bit, and the running sum is never -0.0), the 64 terms are added to the running sum in lane order: the
+// additions of the serial loop.  (Rounds 1-4 kept a per-pattern terms array in LDS and walked it with two LDS round trips
+// per pattern; a locus whose block lies in HBM would pay two memory round trips per pattern for that.)  Host: the serial
+// loop, terms behind the block.
+template <class CP>
+GPH_DEVHOT double root_sum_generic(CP rc, int P, int q_phases, int q_count, int q_terms, const GphSeq SQ)
+{
+  double lnl = 0.0;
+#ifdef GPH_HOSTEMU
+  for (int p = 0; p < P; p++) {
+    const int ph = sq_u16v(SQ, q_phases, p);
+    if (ph > 0) {
+      const int nc = 4 * ph;
+      double prob = 0.0;
+      for (int c = 0; c < nc; c++) prob += rc[p * 4 + c];
+      sq_sf64(SQ, q_terms, p, gph_log(prob / nc) * GPH_PATCOUNT_S(SQ, q_count, p));
+    }
+  }
+  for (int p = 0; p < P; p++)
+    if (sq_u16v(SQ, q_phases, p) > 0) lnl += sq_f64(SQ, q_terms, p);
+#else
+  (void)q_terms;
+  for (int p0 = 0; p0 < P; p0 += GPH_WAVE) {
+    const int p = p0 + GPH_LANE;
+    double term = 0.0;
+    const int ph = p < P ? sq_u16v(SQ, q_phases, p) : 0;
+    if (ph > 0) {
+      const int nc = 4 * ph;
+      double prob = 0.0;
+      for (int c = 0; c < nc; c++) prob += rc[p * 4 + c];
+      term = gph_log(prob / nc) * GPH_PATCOUNT_S(SQ, q_count, p);
+    }
+    const int cnt = P - p0 < GPH_WAVE ? P - p0 : GPH_WAVE;
+    for (int k = 0; k < cnt; k++) lnl += gph_readlane64(term, k);
+  }
+#endif
+  return lnl;
+}
 // prune_node() with every tree scalar already in (scalar) registers
 template <class DP>
 GPH_DEV void prune_node_r(int node, int l, int r, double pl, double pr, int cbn, int cbl, int cbr, int P, DP cb,
-                          int q_leaf = GPH_Q_LEAF)
+                          int q_leaf = GPH_Q_LEAF, const GphSeq SQ = GphSeq{nullptr})
 {
   double ql = 1 - 4.0 * pl;
   double qr = 1 - 4.0 * pr;
@@ -776,9 +828,9 @@ GPH_DEV void prune_node_r(int node, int l, int r, double pl, double pr, int cbn,
   for (int idx = GPH_LANE; idx < 4 * P; idx += GPH_NLANES) {
     int p = idx >> 2, a = idx & 3;
     double v = 1.0, f;
-    f = child_factor(l, lc, p, a, pl, ql, q_leaf);
+    f = child_factor(l, lc, p, a, pl, ql, q_leaf, SQ);
     v *= f;
-    f = child_factor(r, rc, p, a, pr, qr, q_leaf);
+    f = child_factor(r, rc, p, a, pr, qr, q_leaf, SQ);
     v *= f;
     pc[idx] = v;
   }
@@ -989,7 +1041,9 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   /* the two mappings are separate loops (the choice is per locus): the per-pattern one keeps the conditionals of the
    * node just computed in registers from step to step, and its loop must stay simple enough for that */
   bool bad = false;
+  GphSeq SQ; SQ.g = nullptr;
   if (wide) {
+    SQ = seq_ref();
     for (int guard = 0; todo != 0; guard++) {
       bool rdy = isnode && ((todo >> lane) & 1) && (le < n || !((todo >> le) & 1)) && (ri < n || !((todo >> ri) & 1));
       uint64_t rmask = __ballot(rdy);
@@ -1001,7 +1055,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
         const int l = __builtin_amdgcn_readlane(le, node), r = __builtin_amdgcn_readlane(ri, node);
         STAMP_BEGIN(7);
         prune_node_r<gdbl *>(node, l, r, gph_readlane64(pe, l), gph_readlane64(pe, r), (int)((cbit >> node) & 1),
-                             (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, cb);
+                             (int)((cbit >> l) & 1), (int)((cbit >> r) & 1), P, cb, GPH_Q_LEAF, SQ);
         STAMP_END(7);
         todo &= ~bit;
       }
@@ -1072,18 +1126,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     else lnl = ordered_sum64(term, P);
   } else {
     GPH_WAVE_FENCE();
-    for (int p = lane; p < P; p += GPH_NLANES) {
-      int ph = gu16v(q_phases, p);
-      if (ph > 0) {
-        int nc = 4 * ph;
-        double prob = 0.0;
-        for (int c = 0; c < nc; c++) prob += rc[p * 4 + c];
-        sf64(q_terms, p, gph_log(prob / nc) * GPH_PATCOUNT(q_count, p));
-      }
-    }
-    GPH_SYNC();
-    for (int p = 0; p < P; p++)
-      if (gu16(q_phases, p) > 0) lnl += gf64(q_terms, p);
+    lnl = root_sum_generic(rc, P, q_phases, q_count, q_terms, SQ);
   }
   setFS(FS_DATALNL, lnl);
   if (!useOld) setCNT(CN_NODES0, CNT(CN_NODES0) + nord);     /* (the algorithmic-byte count covers useOld evaluations: out_common) */
@@ -1204,21 +1247,7 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
    * gph_log_u(sum over phases and bases / (4*phases)) * count, summed in pattern order */
   {
     const gdbl *rc = cond_base() + cond_off(ISC(IS_ROOT), CBIT(ISC(IS_ROOT)));
-    int p;
-    for (p = GPH_LANE; p < P; p += GPH_NLANES) {
-      int ph = gu16v(q_phases, p);
-      if (ph > 0) {
-        int nc = 4 * ph, c;
-        double prob = 0.0;
-        for (c = 0; c < nc; c++) prob += rc[p * 4 + c];
-        sf64(q_terms, p, gph_log(prob / nc) * GPH_PATCOUNT(q_count, p));
-      }
-    }
-    GPH_SYNC();
-    lnl = 0.0;
-    for (p = 0; p < P; p++) {
-      if (gu16(q_phases, p) > 0) lnl += gf64(q_terms, p);
-    }
+    lnl = root_sum_generic(rc, P, q_phases, q_count, q_terms, seq_ref());
   }
   setFS(FS_DATALNL, lnl);
   if (!useOld) setCNT(CN_NODES0, CNT(CN_NODES0) + nord);

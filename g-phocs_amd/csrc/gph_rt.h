@@ -289,6 +289,19 @@ GPH_DEV int gu8v(int off, int i) { return ((lu8 *)(GPH_SMB + off))[i]; }
 GPH_DEV int gu16v(int off, int i) { return ((GPH_LDS uint16_t *)(GPH_SMB + off))[i]; }
 GPH_DEV int gu16(int off, int i) { return RFL(((GPH_LDS uint16_t *)(GPH_SMB + off))[i]); }
 GPH_DEV int gi32v(int off, int i) { return ((li32 *)(GPH_SMB + off))[i]; }
+// ---- the sequence block seen by the GENERIC (pattern, base) code paths (loci with more than GPH_WAVE phased patterns, and the
+// one-lane host build): in the wave's dynamic LDS like everybody's, or -- a locus whose block outgrows the launch group's
+// LDS budget ("huge": more than g_lay.huge_P patterns; the reference mallocs any P, LocusDataLikelihood.c:251) -- where it
+// lies in HBM, 8 bytes per pattern for the root reduction's terms behind it.  g == null: LDS.  The lane-per-pattern paths
+// (P <= GPH_WAVE: every hot loop) never come here: such a block always fits.
+struct GphSeq { GPH_GLB char *g; };
+GPH_DEV int sq_u8v(const GphSeq &S, int off, int i) { return S.g ? (int)((const GPH_GLB uint8_t *)(S.g + off))[i] : gu8v(off, i); }
+GPH_DEV int sq_u16v(const GphSeq &S, int off, int i) { return S.g ? (int)((const GPH_GLB uint16_t *)(S.g + off))[i] : gu16v(off, i); }
+GPH_DEV int sq_i32v(const GphSeq &S, int off, int i) { return S.g ? ((const GPH_GLB int32_t *)(S.g + off))[i] : gi32v(off, i); }
+GPH_DEV double sq_f64(const GphSeq &S, int off, int i) { return S.g ? ((const GPH_GLB double *)(S.g + off))[i] : gf64(off, i); }
+GPH_DEV void sq_sf64(const GphSeq &S, int off, int i, double v) { if (S.g) ((GPH_GLB double *)(S.g + off))[i] = v; else sf64(off, i, v); }
+#define GPH_LEAFCODE_S(S, q_leaf, p, child) ((sq_u8v((S), (q_leaf), (p) * GPH_Q_NH(g_lay.n) + ((child) >> 1)) >> (((child) & 1) << 2)) & 15)
+#define GPH_PATCOUNT_S(S, q_count, p) (g_lay.cnt16 ? sq_u16v((S), (q_count), (p)) : sq_i32v((S), (q_count), (p)))
 // leaf code (4 bits) of leaf `child` for pattern p, and pattern p's count (16 or 32 bits): gph_types.h, sequence block
 #define GPH_LEAFCODE(q_leaf, p, child) ((gu8v((q_leaf), (p) * GPH_Q_NH(g_lay.n) + ((child) >> 1)) >> (((child) & 1) << 2)) & 15)
 #define GPH_PATCOUNT(q_count, p) (g_lay.cnt16 ? gu16v((q_count), (p)) : gi32v((q_count), (p)))

@@ -113,6 +113,7 @@ struct GphLayout {
   int32_t lds_sum;         // 1: the root reduction hands its per-pattern terms over through dynamic LDS (ordered_sum64_lds) for the loci whose terms fit behind their block
   int32_t cnt16;           // 1: pattern counts are stored as u16 (every count of the data set is below 65536)
   int32_t dyn_bytes;       // dynamic LDS of THIS launch (set per launch group)
+  int32_t huge_P;          // a locus with more phased patterns keeps its sequence block in HBM (its own launch group; INT32_MAX: none)
 };
 struct GphGlobal;
 // model + layout tables travel BY VALUE as the first argument of every kernel: in the kernarg segment every
@@ -156,7 +157,7 @@ enum { DI_ORIG = 0, DI_UPD, DI_DLIN, DI_NEV, DI_NPOPS, DI_NBANDS, DI_SRCPOP, DI_
 enum { SI_FEV_OLD = 0, SI_FEV_NEW, SI_FPOP_NEW, SI_TARGET, SI_NOLD, SI_NNEW, SI_COUNT };
 enum { SA_OLD = 0, SA_NEWIN, SA_NEWOUT, SA_NEWBAND };
 // counters (s_cnt i32): evals, evalNodes, error, P, U ; (s_cntf f64): evalBytes
-enum { CN_EVALS = 0, CN_NODES, CN_ERROR, CN_P, CN_NOTENOUGH, CN_RX, CN_RY, CN_RZ, CN_EMPTY, CN_NODES0, CN_QPH, CN_QCNT, CN_QTERMS, CN_SUMLDS, CN_COUNT };   // CN_QPH / CN_QCNT / CN_QTERMS: byte offsets of the phases, the counts and the terms inside the locus's sequence block (GPH_Q_*: functions of P alone, derived once per kernel instead of in every evaluation); CN_SUMLDS: 1 when the locus's per-pattern terms fit behind its block in this launch's dynamic LDS (ordered_sum64_lds); CN_EMPTY: useOld evaluations that found nothing to recompute; CN_NODES0: nodes recomputed by useOld = 0 evaluations (both off the hot path: out_common derives the algorithmic bytes from them)
+enum { CN_EVALS = 0, CN_NODES, CN_ERROR, CN_P, CN_NOTENOUGH, CN_RX, CN_RY, CN_RZ, CN_EMPTY, CN_NODES0, CN_QPH, CN_QCNT, CN_QTERMS, CN_SUMLDS, CN_HUGE, CN_SEQLO, CN_SEQHI, CN_COUNT };   // CN_HUGE: the locus's sequence block outgrows the launch group's LDS and is read where it lies in HBM (CN_SEQLO / CN_SEQHI: its address; GphSeq, gph_rt.h);   // CN_QPH / CN_QCNT / CN_QTERMS: byte offsets of the phases, the counts and the terms inside the locus's sequence block (GPH_Q_*: functions of P alone, derived once per kernel instead of in every evaluation); CN_SUMLDS: 1 when the locus's per-pattern terms fit behind its block in this launch's dynamic LDS (ordered_sum64_lds); CN_EMPTY: useOld evaluations that found nothing to recompute; CN_NODES0: nodes recomputed by useOld = 0 evaluations (both off the hot path: out_common derives the algorithmic bytes from them)
 //   // CN_RX..: the batched generator's state after its current batch
 
 // f64 scalars in the page (index into o_fscal)

@@ -629,13 +629,23 @@ static int cmd_timesweep(int argc, char **argv)
     threads = 1;
 #endif
     for (k = 0; k < warm; k++, it++) one_iteration(NULL, it, acceptCountArray, 0);
-    t0 = now_s();
-    for (k = 0; k < iters; k++, it++) one_iteration(NULL, it, acceptCountArray, 0);
-    t1 = now_s();
-    printf("{\"threads\": %d, \"loci\": %d, \"iters\": %d, \"seconds\": %.6f, \"iters_per_s\": %.6f, "
-           "\"evals_per_s\": %.3f, \"nominal_evals_per_locus_iter\": %ld}\n",
-           threads, dataSetup.numLoci, iters, t1 - t0, iters / (t1 - t0),
-           (double)evalsPerLocusIter * dataSetup.numLoci * iters / (t1 - t0), evalsPerLocusIter);
+    /* every iteration timed on its own: the MEDIAN is the figure (a two-iteration mean was a single draw);
+     * "threads:iters" in the list overrides the iteration count for that thread count */
+    { double per[64], tmp;
+      int n_it = strchr(tok, ':') ? atoi(strchr(tok, ':') + 1) : iters, a, b;
+      if (n_it < 1) n_it = 1;
+      if (n_it > 64) n_it = 64;
+      t0 = now_s();
+      for (k = 0; k < n_it; k++, it++) { double s0 = now_s(); one_iteration(NULL, it, acceptCountArray, 0); per[k] = now_s() - s0; }
+      t1 = now_s();
+      for (a = 0; a < n_it; a++) for (b = a + 1; b < n_it; b++) if (per[b] < per[a]) { tmp = per[a]; per[a] = per[b]; per[b] = tmp; }
+      tmp = n_it % 2 ? per[n_it / 2] : 0.5 * (per[n_it / 2 - 1] + per[n_it / 2]);
+      printf("{\"threads\": %d, \"loci\": %d, \"iters\": %d, \"seconds\": %.6f, \"median_iteration_seconds\": %.6f, "
+             "\"min_iteration_seconds\": %.6f, \"max_iteration_seconds\": %.6f, \"iters_per_s\": %.6f, "
+             "\"evals_per_s\": %.3f, \"nominal_evals_per_locus_iter\": %ld}\n",
+             threads, dataSetup.numLoci, n_it, t1 - t0, tmp, per[0], per[n_it - 1], 1.0 / tmp,
+             (double)evalsPerLocusIter * dataSetup.numLoci / tmp, evalsPerLocusIter);
+    }
     fflush(stdout);
   }
   return 0;

@@ -113,6 +113,14 @@ timeout 900 $REF main -n 1 b2.ctl >/dev/null 2>&1     # b2.trace: the reference'
 # n7: more than 64 leaves (36 diploids over 6 populations = 72; the reference allows NS 200, patch.h:22): library variant `n`
 gen n7 13 6 200 12 6 --mig-beta 0.0000001
 timeout 900 $REF main -n 1 n7.ctl >/dev/null 2>&1     # n7.trace: the reference's own trace file
+# q6: a locus whose sequence block outgrows the LDS budget -- 72 leaves, two 20-kb loci: 145 and 698 phased patterns, up to 512
+# phases per pattern.  State dumps WITHOUT the conditional arrays (4 MB of hex floats); the 1.4-MB sequence file is regenerated
+# here (deterministic generator) and not kept: the tests read the pack
+$GEN --config 13 --loci 2 --seqlen 20000 --iters 8 --per-log 4 --mut-scale 1 --mig-beta 0.0000001 --out q6 2>/dev/null
+timeout 600 $REF pack q6.ctl q6.gpk >/dev/null
+timeout 600 $REF run q6.ctl 0 q6.init.rtrace q6.init.state -1 0 >/dev/null; rm -f q6.init.rtrace
+timeout 1800 $REF run q6.ctl 8 q6.rtrace q6.state 7 0 >/dev/null
+rm -f q6.seq
 
 # decision-level fixtures: the reference compiled with -DLOG_STEPS (oracle/_ref/gphocs_ref_log), two loci each of m3 and a7
 python3 make_logsteps.py

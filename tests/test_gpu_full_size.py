@@ -248,3 +248,15 @@ def test_long_trajectory_keeps_the_reference_invariants(G):
     s.close()
     assert all(a > 0 for a in acc[:8]), acc
     assert hs["resident"] and hs["syncs"] <= 400 + 64     # one per iteration, + initialisation and the checkAll passes
+
+
+def test_end_to_end_through_the_unchanged_files_at_100k_loci(G):
+    """the bench data set as a 100 000-locus sequence file + control file through `G-PhoCS-hip`
+    (gph_loci_read -> engine -> trace writer); the trace file against the REAL binary's on the same files
+    (tests/golden/e2e100k.trace, generated in the build container by tools/e2e_files.py golden): parameter columns
+    character-identical, log-likelihood columns within 1e-10 relative.  Also times gph_loci_read at 20k / 50k / 100k loci
+    (gpurun_out/e2e_100k.json; the reference's start-up seconds sit in tests/golden/e2e100k.ref.json)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import e2e_files
+    out = e2e_files.run(100000, 24)
+    assert out["trace_rows_compared"] == 24 and out["worst_relative_difference_of_a_log_likelihood_column"] <= 1e-10

@@ -22,6 +22,7 @@ CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, 
          "x8": 24,   # x8: 32 leaves, 31 populations, 16 bands: the largest lane-per-node build (library variant x)
          "y9": 16,   # y9: 40 leaves, 39 populations (the reference's NSPECIES cap), 16 bands: library variant h
          "n7": 12,   # n7: 72 leaves: library variant n (200 leaves / 39 populations / 100 bands, the reference's own caps)
+         "q6": 8,    # q6: 72 leaves, two 20-kb loci with 145 and 698 phased patterns (up to 512 phases): the second one's sequence block (28 KB) lies beyond the LDS budget next to variant n's 44-KB image and stays in HBM
          "b2": 24}   # b2: 20 migration bands: library variant b (live-band list in LDS, model read from HBM, 384-column reduced rows)
 
 
@@ -34,15 +35,18 @@ def G():
     return G
 
 
+NOCOND = {"q6"}      # goldens whose state dumps carry no conditional arrays (4 MB of hex floats for q6's 698 patterns x 71 nodes)
+
+
 def _run(G, pack, iters, tmp_path, tag):
     s = G.Sampler(G.Pack.load(pack))
     tr, st0, st1 = tmp_path / f"{tag}.trace", tmp_path / f"{tag}.init.state", tmp_path / f"{tag}.state"
     s.set_record_file(str(tr))
     s.initialize()
-    s.dump_state(str(st0), True)
+    s.dump_state(str(st0), tag not in NOCOND)
     for it in range(iters):
         s.iteration(it)
-    s.dump_state(str(st1), True)
+    s.dump_state(str(st1), tag not in NOCOND)
     s.set_record_file(None)
     cnt = s.counters()
     s.close()
@@ -568,6 +572,24 @@ def test_odd_leaf_count_and_pattern_rich_loci_against_live_oracle(G, oracle_cli,
     subprocess.run([oracle_cli, "run", pack, "10", str(ot), str(os_), "9", "1"], check=True, timeout=600)
     compare_records(tr, ot)
     compare_states(st1, os_)
+
+
+@pytest.mark.parametrize("budget", [5200, 6000, 8000])
+def test_loci_whose_sequence_block_outgrows_lds_read_it_from_hbm(G, oracle_cli, tmp_path, budget):
+    """a locus whose sequence block does not fit the LDS budget of a launch group keeps it in HBM
+    (its own launch group; the reference mallocs any P, LocusDataLikelihood.c:251) instead of being refused.  GPH_HUGE_LDS
+    shrinks the budget so that the `stress` pack (loci with up to 485 phased patterns at 13 leaves) runs as three launch
+    groups on the MI355X: byte-identical to the run with every block in LDS, and equal to the oracle"""
+    pack = os.path.join(GOLDEN, "stress.gpk")
+    a, b = str(tmp_path / "lds.rec"), str(tmp_path / "hbm.rec")
+    _records(G, pack, 10, a)
+    _records(G, pack, 10, b, env={"GPH_HUGE_LDS": str(budget)})
+    assert open(a).read() == open(b).read()
+    assert open(a + ".state").read() == open(b + ".state").read()
+    ot, os_ = tmp_path / "o.trace", tmp_path / "o.state"
+    subprocess.run([oracle_cli, "run", pack, "10", str(ot), str(os_), "9", "1"], check=True, timeout=600)
+    compare_records(b, ot)
+    compare_states(b + ".state", os_)
 
 
 def test_side_stream_equals_serial_launch_groups(G, tmp_path):

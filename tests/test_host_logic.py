@@ -48,7 +48,7 @@ def test_sequence_block_with_32bit_counts(hostemu, name, iters, tmp_path, monkey
     assert worst < 1e-12
 
 
-@pytest.mark.parametrize("name,iters", [("y9", 16), ("x8", 24), ("m3", 120), ("a7", 100), ("v8", 60), ("b2", 24), ("n7", 12)])
+@pytest.mark.parametrize("name,iters", [("y9", 16), ("x8", 24), ("m3", 120), ("a7", 100), ("v8", 60), ("b2", 24), ("n7", 12), ("q6", 8)])
 def test_big_tree_build_matches_reference_goldens(name, iters, tmp_path):
     """the 64-leaf / 39-population capacities (library variant `h`: 128-bit node sets, 64-bit population sets, 16-bit
     event ids, list-driven forms instead of the lane-per-node programs): golden y9 -- 40 leaves, 20 current populations
@@ -57,7 +57,9 @@ def test_big_tree_build_matches_reference_goldens(name, iters, tmp_path):
     import gphocs_amd as G
     lib = G.load_library(R.build_hostemu(big=True))
     tr, st = tmp_path / "t", tmp_path / "s"
-    R.run(os.path.join(GOLDEN, name + ".gpk"), iters, str(tr), str(st), iters - 1, lib=lib)
+    # q6: 72 leaves, two 20-kb loci with 145 / 698 phased patterns: the second one's sequence block stays in HBM (no
+    # conditional arrays in its golden state: 4 MB of hex floats)
+    R.run(os.path.join(GOLDEN, name + ".gpk"), iters, str(tr), str(st), iters - 1, with_cond=name != "q6", lib=lib)
     worst = compare_records(tr, os.path.join(GOLDEN, name + ".rtrace"))
     compare_states(st, os.path.join(GOLDEN, name + ".state"))
     assert worst < 1e-12
@@ -120,6 +122,24 @@ def test_odd_leaf_count_and_pattern_rich_loci_against_live_oracle(hostemu, oracl
     patterns (30 of the 40 with more than 64): the front end's `stress` pack through the engine sources, against the
     oracle's serial loop on the same pack"""
     R, lib = hostemu
+    pack = os.path.join(GOLDEN, "stress.gpk")
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(pack, 10, str(tr), str(st), 9, lib=lib)
+    ot, os_ = tmp_path / "o.t", tmp_path / "o.s"
+    subprocess.run([oracle_cli, "run", pack, "10", str(ot), str(os_), "9", "1"], check=True, timeout=300)
+    assert compare_records(tr, ot) < 1e-12
+    compare_states(st, os_)
+
+
+@pytest.mark.parametrize("budget", [8000, 10000, 11000])
+def test_loci_whose_sequence_block_outgrows_lds_read_it_from_hbm(hostemu, oracle_cli, tmp_path, monkeypatch, budget):
+    """a locus whose sequence block does not fit the LDS budget of a launch group is no longer
+    refused -- the block stays in HBM and the generic (pattern, base) paths read it there (the reference mallocs any P,
+    LocusDataLikelihood.c:251).  GPH_HUGE_LDS shrinks the budget so that the `stress` pack's pattern-rich loci (up to 485
+    phased patterns) split into the three launch groups -- HBM block / LDS block with the generic mapping / a pattern per
+    lane: records and per-locus state against the oracle's serial loop, as with everything in LDS"""
+    R, lib = hostemu
+    monkeypatch.setenv("GPH_HUGE_LDS", str(budget))
     pack = os.path.join(GOLDEN, "stress.gpk")
     tr, st = tmp_path / "t", tmp_path / "s"
     R.run(pack, 10, str(tr), str(st), 9, lib=lib)

@@ -19,7 +19,9 @@ CASES = {  # name: iterations (must match make_goldens.sh)
     "y9": 16,   # 40 leaves, 39 populations (the reference's NSPECIES cap), 16 bands
     "n7": 12,   # 72 leaves (beyond the 64 of 128-bit node sets; the reference allows 200)
     "b2": 24,   # 20 migration bands (beyond the 16 of the nibble list; the reference allows 100)
+    "q6": 8,    # 72 leaves, two 20-kb loci with 145 / 698 phased patterns, up to 512 phases per pattern (state dumps without conditionals)
 }
+NOCOND = {"q6"}
 
 
 @pytest.mark.parametrize("seed", [12345, 777])
@@ -40,7 +42,7 @@ def test_initial_state(oracle_cli, name, tmp_path):
     """initializeMCMC: prior-sampled genealogies, event chains, statistics, full pruning."""
     st = tmp_path / "init.state"
     subprocess.run([oracle_cli, "run", os.path.join(GOLDEN, name + ".gpk"), "0", str(tmp_path / "t"),
-                    str(st), "-1", "1"], check=True, timeout=300)
+                    str(st), "-1", "0" if name in NOCOND else "1"], check=True, timeout=300)
     assert filecmp.cmp(st, os.path.join(GOLDEN, name + ".init.state"), shallow=False)
 
 
@@ -50,7 +52,7 @@ def test_full_run(oracle_cli, name, tmp_path):
     tr, st = tmp_path / "trace", tmp_path / "state"
     it = CASES[name]
     subprocess.run([oracle_cli, "run", os.path.join(GOLDEN, name + ".gpk"), str(it), str(tr), str(st),
-                    str(it - 1), "1"], check=True, timeout=900)
+                    str(it - 1), "0" if name in NOCOND else "1"], check=True, timeout=900)
     assert open(tr).read() == open(os.path.join(GOLDEN, name + ".rtrace")).read()
     assert filecmp.cmp(st, os.path.join(GOLDEN, name + ".state"), shallow=False)
 

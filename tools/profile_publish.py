@@ -24,6 +24,7 @@ b = json.load(open(f"gpurun_out/bench_{tag}.json"))
 build_id = b["config"].get("library_build_id")
 json.dump({"kernel": "k_sweep", "loci": 100000, "hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch,
            "write_bytes": write, "build": f"{rnd} {tag}, library variant s", "build_id": build_id,
+           "compiler": b["config"].get("compiler"),      # the counters are the measurement of ONE compiler's code (bench.py checks both)
            "valu_per_wave": s["SQ_INSTS_VALU"]["sum"] / n, "salu_per_wave": s["SQ_INSTS_SALU"]["sum"] / n,
            "lds_per_wave": s["SQ_INSTS_LDS"]["sum"] / n, "smem_per_wave": s["SQ_INSTS_SMEM"]["sum"] / n,
            "wave_cycles_per_wave": s["SQ_WAVE_CYCLES"]["sum"] / n,
