@@ -1089,9 +1089,22 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
         r = __builtin_amdgcn_readlane(ri, node);
       }
       STAMP_BEGIN(7);
-      prune_node_q<gdbl *, gdbl2 *>(l, r, gph_readlane64(pe, l), gph_readlane64(pe, r), __builtin_amdgcn_readlane(coff, node),
+      /* the two edge probabilities of the step: lane l's and lane r's value of `pe` in EVERY lane -- through the LDS crossbar
+       * (ds_bpermute_b32 with a uniform lane: no storage, no vector-pipe cycles) instead of four lane reads with the lane in a
+       * scalar register, 8.3 vector-pipe cycles each (profiles/r04_class_probe.txt) */
+#if !defined(GPH_PE_READLANE)      /* -0.4 % sweep time, two interleaved A/B pairs (profiles/r05_ab_pe_bpermute.txt); the offsets of the three arrays the same way: +0.3 %, not kept */
+      const double pl_ = gph_bcast64(pe, l), pr_ = gph_bcast64(pe, r);
+#else
+      const double pl_ = gph_readlane64(pe, l), pr_ = gph_readlane64(pe, r);
+#endif
+#if defined(GPH_PE_BPERMUTE) && GPH_PE_BPERMUTE >= 2
+      prune_node_q<gdbl *, gdbl2 *>(l, r, pl_, pr_, gph_bcast32(coff, node), gph_bcast32(coff, l), gph_bcast32(coff, r), P, lc, cb, prev,
+                                    q0, q1, q2, q3);
+#else
+      prune_node_q<gdbl *, gdbl2 *>(l, r, pl_, pr_, __builtin_amdgcn_readlane(coff, node),
                                     __builtin_amdgcn_readlane(coff, l), __builtin_amdgcn_readlane(coff, r), P, lc, cb, prev,
                                     q0, q1, q2, q3);
+#endif
       STAMP_END(7);
       todo &= ~((uint64_t)1 << node);
       prev = node;

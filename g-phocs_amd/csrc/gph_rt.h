@@ -123,6 +123,17 @@ __device__ inline double gph_readlane64(double v, int l)
   u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
   return u.d;
 }
+// lane l's value in every lane, through the LDS crossbar (l wave-uniform)
+__device__ inline double gph_bcast64(double v, int l)
+{
+  union { double d; int32_t i[2]; } u;
+  u.d = v;
+  const int a = l << 2;
+  u.i[0] = __builtin_amdgcn_ds_bpermute(a, u.i[0]);
+  u.i[1] = __builtin_amdgcn_ds_bpermute(a, u.i[1]);
+  return u.d;
+}
+__device__ inline int gph_bcast32(int v, int l) { return __builtin_amdgcn_ds_bpermute(l << 2, v); }
 #define GPH_LANEVAL32(v, i) __builtin_amdgcn_readlane((int)(v), (i))
 #define GPH_LANEVAL64(v, i) gph_readlane64((v), (i))
 #endif
