@@ -1644,9 +1644,18 @@ int gph_engine_steplog_enable(gph_engine *e, const int64_t *loci, int32_t n, int
     for (int k = 0; k < n; k++)
       if (e->h_orig[j] + e->cfg.locus_begin == loci[k]) map[j] = k;
   std::vector<int32_t> zero((size_t)n, 0);
-  if (dev_alloc((void **)&e->dev.slog_map, sizeof(int32_t) * e->L) || dev_alloc((void **)&e->dev.slog, sizeof(double) * 8 * (size_t)n * cap) ||
-      dev_alloc((void **)&e->dev.slog_n, sizeof(int32_t) * n)) return GPH_EHIP;
-  if (h2d(e, (void *)e->dev.slog_map, map.data(), sizeof(int32_t) * e->L) || h2d(e, e->dev.slog_n, zero.data(), sizeof(int32_t) * n)) return GPH_EHIP;
+  /* allocate into locals and publish them to the kernels' view only when every copy has succeeded: a partial failure
+   * must not leave dev.slog_map pointing at uninitialised memory */
+  int32_t *d_map = nullptr, *d_n = nullptr;
+  double *d_log = nullptr;
+  if (dev_alloc((void **)&d_map, sizeof(int32_t) * e->L) || dev_alloc((void **)&d_log, sizeof(double) * 8 * (size_t)n * cap) ||
+      dev_alloc((void **)&d_n, sizeof(int32_t) * n) ||
+      h2d(e, d_map, map.data(), sizeof(int32_t) * e->L) || h2d(e, d_n, zero.data(), sizeof(int32_t) * n)) {
+    dev_free(d_map); dev_free(d_log); dev_free(d_n);
+    e->slog_sel = 0;
+    return GPH_EHIP;
+  }
+  e->dev.slog_map = d_map; e->dev.slog = d_log; e->dev.slog_n = d_n;
   e->dev.slog_cap = cap;
   return 0;
 #endif

@@ -2071,6 +2071,7 @@ GPH_DEV double rubber_band_ripple(int do_or_redo)
       setETYPE(orig, GPH_DUMMY);
     } else {
       nw = RBI(1, i);
+      if (nw < 0) continue;      /* (the "do" pass failed on this entry -- Fatal Error 0005, a chain already corrupted: nothing to undo) */
       setETYPE(orig, ETYPE(nw));
       if (FIRSTEV(pop) == nw) setENLIN(ENEXT(nw), ENLIN(nw));
       remove_event(nw, pop);
@@ -2085,6 +2086,9 @@ GPH_DEV double rubber_band_ripple(int do_or_redo)
 // traceLineage's consistency check when a walk enters the parent population (patch.c:1053: fabs(age / popAge - 1) >
 // 0.01 is fatal): |age - popAge| > 0.01 popAge -- the same test without the fp64 division (14 instructions, once per
 // population a walk crosses); a valid chain is off by rounding errors, nowhere near the threshold where the two forms differ
+// (pop_age is the age of the ANCESTRAL population the walk enters: a split time, positive in every model the front end and
+// gph_engine_set_model accept -- tau-initial 0 is refused upstream too; for pop_age == 0 the reference's quotient is inf or
+// NaN and never "> 0.01", this form flags any age != 0: both are outside what a run can reach)
 GPH_DEV bool pop_age_off(double age, double pop_age) { return UNI(fabs(age - pop_age) > 0.01 * pop_age); }
 
 // the migration bands a lineage in population `pop` at time `age` is exposed to (patch.c:934-944, 1285-1294: a scan of all

@@ -31,7 +31,10 @@ struct Variant { const char *file; int leaves, pops, bands; };
 static const Variant VARIANTS[] = {{"libgphocs_hip_s.so", 16, 9, 4}, {"libgphocs_hip_l.so", 20, 13, 4}, {"libgphocs_hip.so", 24, 16, 8},
                                    {"libgphocs_hip_x.so", 32, 32, 16}, {"libgphocs_hip_g.so", 48, 16, 8}, {"libgphocs_hip_h.so", 64, 40, 16},
                                    {"libgphocs_hip_b.so", 64, 40, 100}, {"libgphocs_hip_n.so", 200, 40, 100}};
-static const int DEFAULT_VARIANT = 5;   /* the largest capacities: always able to read the control file */
+/* the library whose gph_control_read reads the control file BEFORE the capacity variant is chosen: the control parser has
+ * no compile-time capacities (it keeps the reference's own caps, patch.h:17-22, in every build), so any variant can read
+ * any control file; the dimensions it returns then select the tightest variant above */
+static const int DEFAULT_VARIANT = 5;
 
 template <class F> static F sym(void *h, const char *name)
 {

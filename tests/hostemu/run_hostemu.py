@@ -13,13 +13,19 @@ import gphocs_amd as G  # noqa: E402
 HOSTEMU = os.path.join(REPO, "tests", "hostemu", "libgphocs_hostemu.so")
 
 
-def build_hostemu(sanitize=False, big=False):
-    """big: the 64-leaf / 39-population capacities (library variant `h`: 128-bit node sets, 64-bit population sets,
-    16-bit event ids) -- a separate host build, as the capacities are compile-time"""
+def build_hostemu(sanitize=False, big=False, mid=False, two_walks=False):
+    """big: the reference's own caps 200 / 39 / 100 (library variant `n`: node sets of seven words, band lists in LDS) -- a
+    separate host build, as the capacities are compile-time.  mid: 64 leaves / 39 populations / 16 bands, the configuration
+    of library variants `g` and `h` (GPH_BIG_TREE with two-word node sets, the nibble band list, the fused trace_pair walk
+    parking its state over s_targets): ADVICE round 4 -- the only CPU build of that configuration, also under the sanitizers"""
     csrc = os.path.join(REPO, "g-phocs_amd", "csrc")
     srcs = [os.path.join(csrc, f) for f in ("gph_engine.hip", "gph_mcmc.cpp", "gph_input.cpp", "gph_program.cpp", "gph_readtrace.cpp", "gph_comm.cpp")]
     deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.abspath(__file__)]
-    out = HOSTEMU.replace(".so", "_san.so") if sanitize else HOSTEMU.replace(".so", "_h.so") if big else HOSTEMU
+    out = HOSTEMU.replace(".so", "_h.so") if big else HOSTEMU.replace(".so", "_mid.so") if mid else HOSTEMU
+    if two_walks:      # -DGPH_TWO_WALKS: traceLineage(0) and traceLineage(1) as two separate walks (the many-band builds' form)
+        out = out.replace(".so", "_2w.so")
+    if sanitize:
+        out = out.replace(".so", "_san.so")
 
     import hashlib
     h = hashlib.sha256()
@@ -44,7 +50,7 @@ def build_hostemu(sanitize=False, big=False):
         try:
             if fresh():
                 return out
-            r = _build(out, srcs, sanitize, big)
+            r = _build(out, srcs, sanitize, big, mid, two_walks)
             with open(side, "w") as f:
                 f.write(want + "\n")
             return r
@@ -52,10 +58,13 @@ def build_hostemu(sanitize=False, big=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build(out, srcs, sanitize, big):
+def _build(out, srcs, sanitize, big, mid=False, two_walks=False):
     # the engine's hard caps (library variant `x`): every golden fits, the image size does not matter on the host
-    caps = ["-DGPH_CAP_LEAVES=200", "-DGPH_CAP_K=40", "-DGPH_CAP_B=100"] if big else ["-DGPH_CAP_LEAVES=32", "-DGPH_CAP_K=32", "-DGPH_CAP_B=16"]
+    caps = ["-DGPH_CAP_LEAVES=200", "-DGPH_CAP_K=40", "-DGPH_CAP_B=100"] if big else \
+           ["-DGPH_CAP_LEAVES=64", "-DGPH_CAP_K=40", "-DGPH_CAP_B=16"] if mid else ["-DGPH_CAP_LEAVES=32", "-DGPH_CAP_K=32", "-DGPH_CAP_B=16"]
     tmp = f"{out}.tmp.{os.getpid()}"
+    if two_walks:
+        caps = caps + ["-DGPH_TWO_WALKS"]
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU", "-DGPH_LOGSTEPS"] + caps + [
            "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
            "-x", "c++"] + srcs + ["-lrt", "-o", tmp]

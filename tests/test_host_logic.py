@@ -65,6 +65,21 @@ def test_big_tree_build_matches_reference_goldens(name, iters, tmp_path):
     assert worst < 1e-12
 
 
+@pytest.mark.parametrize("name,iters", [("y9", 16), ("m3", 120), ("a7", 100), ("m4", 60), ("x8", 24)])
+def test_variant_h_configuration_matches_reference_goldens(name, iters, tmp_path):
+    """the configuration of library variants g / h (64 leaves / 39 populations / 16 bands: GPH_BIG_TREE with
+    two-word node sets and WITHOUT the many-band forms -- the fused trace_pair walk with its parked state, lik_spr over
+    multi-word node sets) has a CPU build of its own: y9 and the SPR- / migration-heavy goldens"""
+    import run_hostemu as R
+    import gphocs_amd as G
+    lib = G.load_library(R.build_hostemu(mid=True))
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(os.path.join(GOLDEN, name + ".gpk"), iters, str(tr), str(st), iters - 1, lib=lib)
+    worst = compare_records(tr, os.path.join(GOLDEN, name + ".rtrace"))
+    compare_states(st, os.path.join(GOLDEN, name + ".state"))
+    assert worst < 1e-12
+
+
 def test_c_abi_library_exports_every_declared_symbol():
     """build the real HIP library (hipcc cross-compiles without a GPU) and check that every function
     declared in include/gphocs_hip.h is exported (no compute calls: there is no GPU here)"""

@@ -104,13 +104,15 @@ def test_sampler_over_native_shm_comm(hostemu, tmp_path, name, iters):
     compare_records(out + ".0", str(tmp_path / "g"))
 
 
-@pytest.mark.parametrize("name,ranks", [("m3", 1), ("a7", 2), ("v8", 1), ("x8", 1)])
+@pytest.mark.parametrize("name,ranks", [("m3", 1), ("a7", 2), ("v8", 1), ("x8", 1), ("y9@mid", 1), ("m3@mid", 1)])
 def test_engine_sources_under_asan_ubsan(hostemu, tmp_path, name, ranks):
     """the engine sources (host build) under AddressSanitizer + UndefinedBehaviorSanitizer, whole program through the
     launcher: no report (either aborts the run) and the reference's trace file.  The GPU pool offers no sanitizer, so
     this is where out-of-bounds indices into the locus image, the chain state and the reduced rows would show."""
     import run_hostemu
-    san = run_hostemu.build_hostemu(sanitize=True)
+    mid = name.endswith("@mid")        # the variant-h configuration (64 / 39 / 16: two-word node sets, fused walk): ADVICE round 4
+    name = name.split("@")[0]
+    san = run_hostemu.build_hostemu(sanitize=True, mid=mid)
     rt = [subprocess.run(["gcc", "-print-file-name=" + n], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
     if not all(os.path.isabs(p) and os.path.exists(p) for p in rt):
         pytest.skip("sanitizer runtimes are not installed")
@@ -151,3 +153,50 @@ def test_shm_exchange_ignores_a_leftover_segment(hostemu, tmp_path):
     golden = open(os.path.join(GOLDEN, "m3.rtrace")).read().splitlines()[:len(open(out + ".0").read().splitlines())]
     (tmp_path / "g").write_text("\n".join(golden) + "\n")
     compare_records(out + ".0", str(tmp_path / "g"))
+
+
+BROKEN = r"""
+import sys
+sys.path.insert(0, %(repo)r)
+import gphocs_amd as G
+lib = G.load_library(%(lib)r)
+out = []
+for pop in range(5):
+    s = G.Sampler(G.Pack.load(%(pack)r), lib=lib)
+    s.initialize()
+    for it in range(5):
+        s.iteration(it)
+    assert lib.gph_engine_debug_break_chain(s.engine, 11, pop) == 0
+    try:
+        s.iteration(5)
+        out.append((pop, -1, 0))
+    except RuntimeError:
+        out.append((pop,) + s.last_error())
+    s.close()
+print("RESULT", out)
+"""
+
+
+def test_broken_chains_fail_cleanly_and_alike_in_both_walk_forms(hostemu, tmp_path):
+    """the fused pruning + sampling walk (trace_pair) finishes the step that found an inconsistency and
+    reports it behind its loop; the two-walk form (GPH_TWO_WALKS) returns at once.  A broken event chain in each of five
+    populations of one locus must give the SAME first failing locus and reference-style code from both forms (8: the age
+    check at a population boundary, 92: a walk off the end of a chain), the run must end with GPH_EKERNEL -- and the
+    failure path must not touch memory it does not own: the fused form runs under AddressSanitizer + UBSan here (a failed
+    rubberBandRipple used to be undone through event id -1)."""
+    import run_hostemu
+    rt = [subprocess.run(["gcc", "-print-file-name=" + n], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
+    have_san = all(os.path.isabs(p) and os.path.exists(p) for p in rt)
+    res = {}
+    for tag, lib, san in (("fused", run_hostemu.build_hostemu(sanitize=have_san), have_san), ("two", run_hostemu.build_hostemu(two_walks=True), False)):
+        script = tmp_path / f"b_{tag}.py"
+        script.write_text(BROKEN % dict(repo=REPO, lib=lib, pack=os.path.join(GOLDEN, "m3.gpk")))
+        env = dict(os.environ)
+        if san:
+            env.update(LD_PRELOAD=":".join(rt), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+        res[tag] = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1]
+    assert res["fused"] == res["two"], res
+    got = eval(res["fused"].split(" ", 1)[1])
+    assert all(locus == 11 and code in (6, 8, 91, 92, 96) for _, locus, code in got), got
