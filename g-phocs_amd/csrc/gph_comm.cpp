@@ -20,6 +20,7 @@
 #endif
 
 #define GPH_COMM_MAXN 448      /* >= the columns a stage exchanges: counters + 2 * 39 populations + 2 * 100 bands */
+#define GPH_COMM_XROW 2320     /* doubles of a reduced row of the widest build (GPH_RED_ROW with 384 columns, gph_types.h) */
 
 struct ShmSeg {                       // one cache line per rank's arrival counter
   std::atomic<uint32_t> magic;
@@ -242,6 +243,10 @@ struct gph_comm_group {
   double hbuf[64][GPH_COMM_MAXN];
 #ifndef GPH_HOSTEMU
   hipEvent_t ready[64], done[64];
+  // in-kernel exchange (gph_comm_peer_exchange): per rank two row slots (generation parity) + a generation word, in one
+  // device allocation every rank's kernels can address -- the layout a peer-mapped allocation per GPU would have
+  double *xrows = nullptr;
+  unsigned long long *xflags = nullptr;
 #endif
 };
 static int group_barrier(gph_comm_group *g)
@@ -281,6 +286,13 @@ gph_comm_group *gph_comm_local_group(int32_t world, int32_t device)
   for (int r = 0; r < world; r++)
     if (hipEventCreateWithFlags(&g->ready[r], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming) != hipSuccess) { delete g; return nullptr; }
+  const size_t rb = sizeof(double) * 2 * GPH_COMM_XROW * (size_t)world, fb = sizeof(unsigned long long) * 64;
+  if (hipMalloc((void **)&g->xrows, rb) != hipSuccess || hipMalloc((void **)&g->xflags, fb) != hipSuccess ||
+      hipMemset(g->xrows, 0, rb) != hipSuccess || hipMemset(g->xflags, 0, fb) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    if (g->xrows) (void)hipFree(g->xrows);
+    if (g->xflags) (void)hipFree(g->xflags);
+    g->xrows = nullptr; g->xflags = nullptr;       /* the event-ordered gather still works */
+  }
   return g;
 #endif
 }
@@ -323,6 +335,8 @@ void gph_comm_destroy(gph_comm *c)
 #ifndef GPH_HOSTEMU
       (void)hipSetDevice(g->device);
       for (int r = 0; r < g->world; r++) { (void)hipEventDestroy(g->ready[r]); (void)hipEventDestroy(g->done[r]); }
+      if (g->xrows) (void)hipFree(g->xrows);
+      if (g->xflags) (void)hipFree(g->xflags);
 #endif
       delete g;
     }
@@ -330,6 +344,29 @@ void gph_comm_destroy(gph_comm *c)
   delete c;
 }
 
+// In-kernel exchange of the reduced rows (gph_engine.hip: k_reduce_stage): the base of the row slots
+// [world][2][GPH_COMM_XROW] and of the per-rank generation words, addressable by every rank's kernels.  Thread ranks: one
+// device allocation of the group.  (Ranks on different GPUs would each own their slot in peer-mapped fine-grained memory;
+// not built: it could not be run.)  Returns 1 when the communicator offers it.
+int gph_comm_peer_exchange(const gph_comm *c, double **rows, unsigned long long **flags, int32_t *row_stride)
+{
+#ifdef GPH_HOSTEMU
+  (void)c; (void)rows; (void)flags; (void)row_stride;
+  return 0;
+#else
+  if (!c || c->kind != 3 || !c->group || !c->group->xrows || !c->group->xflags) return 0;
+  /* OPT-IN (GPH_PEER_EXCHANGE=1): a kernel that waits for another stream's kernel needs the two streams on different
+   * hardware queues -- HIP hands streams to a few queues round-robin (GPU_MAX_HW_QUEUES, default 4), and in a process that
+   * has created and destroyed many streams two thread ranks can end up behind each other: the bounded wait then fails the
+   * run (measured: world 3 at the end of the full test suite).  Ranks on GPUs of their own -- what the exchange is for --
+   * have queues of their own; thread ranks default to the event-ordered gather. */
+  { const char *ov = getenv("GPH_PEER_EXCHANGE"); if (!ov || atoi(ov) == 0) return 0; }
+  if (rows) *rows = c->group->xrows;
+  if (flags) *flags = c->group->xflags;
+  if (row_stride) *row_stride = GPH_COMM_XROW;
+  return 1;
+#endif
+}
 int gph_comm_world(const gph_comm *c) { return c ? c->world : 1; }
 int gph_comm_rank(const gph_comm *c) { return c ? c->rank : 0; }
 int gph_comm_on_stream(const gph_comm *c) { return c && (c->kind == 1 || c->kind == 3); }

@@ -271,8 +271,12 @@ __device__ void reduce_final_body(int ncols, int cbase, const double *part, doub
 // reduction of section 0 (nc0 columns of the per-locus outputs) and / or section 1 (nc1 columns of the statistics) into
 // this rank's row; the LAST block to finish its partials (ticket) does the final pass and -- single rank -- runs the
 // stages that consume the row in the same launch
+// In-kernel exchange of the reduced rows between ranks whose kernels can address each other's memory (gph_comm_peer_exchange):
+// rank r owns slots rows[(2 r + parity) * stride ...] and the generation word flags[r]; `gather` is this rank's copy of
+// everybody's row of the current generation.
+struct GphPeerX { int world, rank, stride, pad; double *rows; unsigned long long *flags; double *gather; unsigned long long gen; };
 __global__ void __launch_bounds__(GPH_RED_THREADS) k_reduce_stage(GphKargs KA, GphDev D, int nc0, int nc1, double *part, unsigned *ticket, double *red,
-                                                                  int do_stage, GphStageList SL, int iteration)
+                                                                  int do_stage, GphStageList SL, int iteration, GphPeerX X)
 {
   __shared__ union { double p[3][GPH_RED_SUBS * 4][16]; double f[3][GPH_RED_SUBS][128]; GphStageShared st; } sh;
   __shared__ int s_last;
@@ -292,7 +296,45 @@ __global__ void __launch_bounds__(GPH_RED_THREADS) k_reduce_stage(GphKargs KA, G
   for (int cb = 0; cb < nc1; cb += 128) reduce_final_body(nc1 - cb < 128 ? nc1 - cb : 128, cb, part + 3 * GPH_RED_BLOCKS * GPH_RED_COLS, red + GPH_RED_STRIDE, sh.f);
   if (threadIdx.x == 0) { red[3 * GPH_RED_COLS] = (double)*D.err; *ticket = 0; }
   __syncthreads();
-  if (do_stage) stages_body(KA, red, 1, SL, iteration, sh.st);
+  const double *rows = red;
+  int world = 1;
+  if (X.world > 1) {
+    /* publish this rank's row in its slot of this generation's parity, then the generation word (release, system scope:
+     * the layout and the scopes are those of slots in peer-mapped memory); wait for every other rank's word; copy the rows
+     * in rank order.  Two slots suffice: a rank can only finish generation g + 1 after everybody has published g + 1, i.e.
+     * has finished reading generation g.  The wait is BOUNDED (a rank that never comes must not hang the device): after
+     * ~4 s of the 100-MHz counter the launch's error word is raised and the run ends with GPH_EKERNEL. */
+    double *mine = X.rows + (size_t)(2 * X.rank + (int)(X.gen & 1)) * X.stride;
+    for (int c = threadIdx.x; c < GPH_RED_ROW; c += blockDim.x) mine[c] = red[c];
+    /* EVERY storing wavefront drains and releases its own stores before the barrier: thread 0's release below covers only
+     * its own wavefront's (MI355X_MICROARCH.md, inter-workgroup visibility) -- without this the other ranks read a row
+     * that is partly the previous generation's, and a garbage conflict-locus index sent a later kernel to address 0 */
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __atomic_thread_fence(__ATOMIC_RELEASE);
+      __hip_atomic_store(&X.flags[X.rank], X.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (int r = 0; r < X.world; r++) {
+        while (__hip_atomic_load(&X.flags[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < X.gen) {
+          __builtin_amdgcn_s_sleep(32);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
+            atomicMax(D.err, 9997); red[3 * GPH_RED_COLS] = 9997.0; r = X.world; break; }
+        }
+      }
+    }
+    __syncthreads();
+    __threadfence_system();      /* every reading wavefront acquires for itself */
+    for (int r = 0; r < X.world; r++) {
+      const double *src = r == X.rank ? red : X.rows + (size_t)(2 * r + (int)(X.gen & 1)) * X.stride;
+      for (int c = threadIdx.x; c < GPH_RED_ROW; c += blockDim.x) X.gather[(size_t)r * GPH_RED_ROW + c] = src[c];
+    }
+    __syncthreads();
+    rows = X.gather; world = X.world;
+  }
+  /* (ONE call site: with two the compiler stops inlining the stage body, the by-reference kernel arguments go through a
+   * 72-byte stack frame, and the kernel faults at address 0 on its first launch with stages -- measured, round 5) */
+  if (do_stage) stages_body(KA, rows, world, SL, iteration, sh.st);
 }
 #endif
 
@@ -322,6 +364,9 @@ struct gph_engine {
   GphGlobal *G_h = nullptr, *G_d = nullptr;
   bool G_dirty = true;               // the host mirror was changed since it was last pushed
   int64_t n_huge = 0;                // loci whose sequence block stays in HBM (the first slots)
+  double *peer_rows = nullptr;       // in-kernel exchange of the reduced rows (gph_comm_peer_exchange), else null
+  unsigned long long *peer_flags = nullptr, peer_gen = 0;
+  int32_t peer_stride = 0;
   int32_t last_error_code = 0;       // the last fatal error check_error reported (gph_engine_last_error)
   long long last_error_locus = -1;
   bool in_error_dump = false;
@@ -620,12 +665,20 @@ static int flush_pending(gph_engine *e)
   const bool multi = e->comm && gph_comm_world(e->comm) > 1;
   LAUNCH_PRE(e);
   if (red) {
-    const int fuse = sl.n > 0 && !multi;
+    /* several ranks whose kernels can address each other's rows (gph_comm_peer_exchange): the exchange happens INSIDE the
+     * reduction kernel's last block and the stages run there on everybody's rows -- one launch per reduction point, as
+     * with a single rank */
+    const bool inkernel = multi && e->peer_rows != nullptr;
+    const int fuse = sl.n > 0 && (!multi || inkernel);
+    GphPeerX X{1, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+    if (inkernel) X = GphPeerX{gph_comm_world(e->comm), gph_comm_rank(e->comm), e->peer_stride, 0, e->peer_rows, e->peer_flags, e->d_gather, ++e->peer_gen};
     hipLaunchKernelGGL(k_reduce_stage, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_THREADS), 0, e->stream, e->ka, e->dev, nc0, nc1, e->d_part, e->d_ticket,
-                       e->d_red, fuse, sl, e->pend_iteration);
+                       e->d_red, fuse, sl, e->pend_iteration, X);
     HIPCHK(hipGetLastError());
     e->n_launches++;
-    if (multi) {
+    if (inkernel) {
+      e->n_collectives++;
+    } else if (multi) {
       if (gph_comm_allgather_stream(e->comm, e->d_red, e->d_gather, GPH_RED_ROW, (void *)e->stream)) return GPH_EHIP;
       e->n_collectives++;
     } else if (e->comm) {
@@ -672,7 +725,7 @@ static int reduce_local(gph_engine *e, int sec, int ncols)
   GphStageList none = {0, {0}, {0}};
   LAUNCH_PRE(e);
   hipLaunchKernelGGL(k_reduce_stage, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_THREADS), 0, e->stream, e->ka, e->dev, sec == 0 ? ncols : 0, sec == 1 ? ncols : 0,
-                     e->d_part, e->d_ticket, e->d_red, 0, none, 0);
+                     e->d_part, e->d_ticket, e->d_red, 0, none, 0, GphPeerX{1, 0, 0, 0, nullptr, nullptr, nullptr, 0});
   HIPCHK(hipGetLastError());
   e->n_launches += 1;
   return 0;
@@ -961,14 +1014,19 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
     return GPH_EHIP;
   }
   if (const char *ov = getenv("GPH_SIDE_STREAM")) e->side_stream = atoi(ov) != 0;
-  if (hipStreamCreate(&e->stream) != hipSuccess || hipStreamCreateWithFlags(&e->stream_wide, hipStreamNonBlocking) != hipSuccess ||
+  /* GPH_NONBLOCKING_STREAM=1 (tests): the engine's stream does not order itself against the legacy null stream -- what the
+   * in-kernel exchange of thread ranks needs (gph_engine_set_comm) */
+  const bool nb_ = getenv("GPH_NONBLOCKING_STREAM") && atoi(getenv("GPH_NONBLOCKING_STREAM")) != 0;
+  if ((nb_ ? hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) : hipStreamCreate(&e->stream)) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->stream_wide, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc((void **)&e->G_h, sizeof(GphGlobal), hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void **)&e->G_d, sizeof(GphGlobal)) != hipSuccess ||
       hipHostMalloc((void **)&e->h_red, sizeof(double) * GPH_RED_ROW * 64, hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void **)&e->d_red, sizeof(double) * GPH_RED_ROW) != hipSuccess ||
       hipMemset(e->d_red, 0, sizeof(double) * GPH_RED_ROW) != hipSuccess ||
-      hipMalloc((void **)&e->d_ticket, 64) != hipSuccess || hipMemset(e->d_ticket, 0, 64) != hipSuccess) { gph_engine_destroy(e); return GPH_EHIP; }
+      hipMalloc((void **)&e->d_ticket, 64) != hipSuccess || hipMemset(e->d_ticket, 0, 64) != hipSuccess ||
+      hipStreamSynchronize(nullptr) != hipSuccess) { gph_engine_destroy(e); return GPH_EHIP; }
   e->d_gather = e->d_red;
 #else
   e->G_h = (GphGlobal *)calloc(1, sizeof(GphGlobal));
@@ -1030,6 +1088,23 @@ int gph_engine_set_comm(gph_engine *e, gph_comm *c)
     if (gph_comm_world(c) > 64) return GPH_EARG;
     if (dev_alloc((void **)&e->d_gather, sizeof(double) * GPH_RED_ROW * gph_comm_world(c))) return GPH_EHIP;
   }
+  e->peer_rows = nullptr; e->peer_flags = nullptr; e->peer_gen = 0; e->peer_stride = 0;
+#ifndef GPH_HOSTEMU
+  if (c && gph_comm_world(c) > 1 && gph_comm_on_stream(c)) {
+    double *rows = nullptr; unsigned long long *flags = nullptr; int32_t stride = 0;
+    if (gph_comm_peer_exchange(c, &rows, &flags, &stride) && stride >= GPH_RED_ROW) {
+      e->peer_rows = rows; e->peer_flags = flags; e->peer_stride = stride;
+      /* a reduction kernel of this engine may WAIT for another rank's kernel: the engine's stream must not be a blocking
+       * stream then -- a blocking stream orders itself against the legacy null stream, and a null-stream operation of the
+       * other rank's host thread (hipMemset at load time) would wait for this rank's waiting kernel: a deadlock until the
+       * bounded wait gives up (found with tools/probe/peer_dbg.py; the plain two-stream probe, peer_probe.cpp, runs) */
+      hipStream_t ns = nullptr;
+      if (hipStreamSynchronize(e->stream) != hipSuccess || hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) != hipSuccess) return GPH_EHIP;
+      (void)hipStreamDestroy(e->stream);
+      e->stream = ns;
+    }
+  }
+#endif
   return 0;
 }
 
@@ -1188,7 +1263,8 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
 #ifdef GPH_HOSTEMU
   if (e->dev.err) *e->dev.err = 0;
 #else
-  if (!rc && hipMemset(e->dev.err, 0, sizeof(int32_t)) != hipSuccess) rc = GPH_EHIP;
+  /* (null-stream operations; the engine's stream may be a non-blocking one, which does not order itself against them) */
+  if (!rc && (hipMemset(e->dev.err, 0, sizeof(int32_t)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)) rc = GPH_EHIP;
 #endif
   if (mutRates) rc |= dev_alloc((void **)&e->d_mutRate, sizeof(double) * L);
   if (rc) { fprintf(stderr, "gphocs_hip: device allocation failed\n"); return GPH_EHIP; }

@@ -95,6 +95,10 @@ void gph_comm_destroy(gph_comm *c);
 int gph_comm_world(const gph_comm *c);
 int gph_comm_rank(const gph_comm *c);
 int gph_comm_on_stream(const gph_comm *c);
+/* 1 when the communicator's ranks can exchange their reduced rows INSIDE the reduction kernel (row slots + generation words
+ * every rank's kernels can address: thread ranks of one process today): a reduction point is then ONE launch per rank, as
+ * with a single rank, instead of reduction + all-gather + decision stage.  Opt-in: GPH_PEER_EXCHANGE=1 (see gph_comm.cpp). */
+int gph_comm_peer_exchange(const gph_comm *c, double **rows, unsigned long long **flags, int32_t *row_stride);
 const char *gph_comm_kind(const gph_comm *c);
 int gph_comm_allgather_stream(gph_comm *c, const double *d_in, double *d_out, int32_t count, void *hip_stream);
 int gph_comm_allreduce_host(gph_comm *c, double *sums, int32_t nsum, double *mins, int32_t nmin);

@@ -455,6 +455,73 @@ def test_thread_ranks_run_the_resident_multi_rank_path(G, tmp_path, name, world)
     compare_states(str(joined), os.path.join(GOLDEN, name + ".state"), skip_global=True)
 
 
+PEER_WORKER = r"""
+import json, os, sys, threading
+sys.path.insert(0, %(repo)r)
+import gphocs_amd as G
+pk = G.Pack.load(%(pack)r)
+lib = G.load_library(dims=(pk.n, pk.K, pk.B))
+iters, out = %(iters)d, %(out)r
+def one():
+    s = G.Sampler(pk, lib=lib)
+    s.set_record_file(out + ".one"); s.initialize()
+    for it in range(iters): s.iteration(it)
+    s.set_record_file(None); hs = s.host_stats(); s.close(); return hs
+def ranks(tag, world=2):
+    group = lib.gph_comm_local_group(world, 0)
+    comms = [lib.gph_comm_create_local(group, r) for r in range(world)]
+    stats, errs = [None] * world, []
+    def work(r):
+        try:
+            s = G.Sampler(pk, lib=lib, rank=r, world=world, comm=comms[r])
+            s.set_record_file(out + ".%%s.%%d" %% (tag, r)); s.initialize()
+            for it in range(iters): s.iteration(it)
+            s.dump_state(out + ".%%s.%%d.state" %% (tag, r), True)
+            s.set_record_file(None); stats[r] = s.host_stats(); s.close()
+        except Exception as ex:
+            errs.append((r, str(ex))); lib.gph_comm_destroy(comms[r]); comms[r] = None
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(timeout=600) for t in th]
+    [lib.gph_comm_destroy(c) for c in comms if c]
+    assert not errs, errs
+    return stats
+res = {"one": one()}
+os.environ["GPH_PEER_EXCHANGE"] = "1"
+res["exchange"] = ranks("x")
+os.environ["GPH_PEER_EXCHANGE"] = "0"
+res["gather"] = ranks("g")
+print("RESULT " + json.dumps(res))
+"""
+
+
+def test_in_kernel_exchange_makes_a_reduction_point_one_launch(tmp_path):
+    """ranks whose kernels can address each other's rows (thread ranks here, GPH_PEER_EXCHANGE=1)
+    exchange them INSIDE the reduction kernel's last block -- a slot per rank and generation parity, release / acquire on a
+    generation word, a bounded wait -- and run the decision stage there on everybody's rows in rank order: as many launches
+    per iteration as a single rank, no separate gather, no k_global launch.  Records byte-equal to the event-ordered gather
+    (reduction + copies + decision stage) and equal to the single-rank golden.  In a process of its own: a kernel that waits
+    for another stream's kernel wants its streams on hardware queues of their own (GPU_MAX_HW_QUEUES)."""
+    import json
+    name, iters = "m3", CASES["m3"]
+    out = str(tmp_path / "rec")
+    script = tmp_path / "peer.py"
+    script.write_text(PEER_WORKER % dict(repo=REPO, pack=os.path.join(GOLDEN, name + ".gpk"), iters=iters, out=out))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    recs = [open(out + f".{t}.{k}").read() for t in "xg" for k in (0, 1)]
+    assert recs[0] == recs[1] == recs[2] == recs[3]
+    compare_records(out + ".x.0", os.path.join(GOLDEN, name + ".rtrace"))
+    compare_records(out + ".one", os.path.join(GOLDEN, name + ".rtrace"))
+    assert open(out + ".x.0.state").read() == open(out + ".g.0.state").read() and open(out + ".x.1.state").read() == open(out + ".g.1.state").read()
+    # launches: the in-kernel exchange costs none, the gather path one k_global per reduction point with stages
+    x, g, one = res["exchange"], res["gather"], res["one"]
+    # (the rank runs dump their state at the end: one launch more than the single-rank run of this script)
+    assert x[0]["launches"] == x[1]["launches"] and 0 <= x[0]["launches"] - one["launches"] <= 2, (x, one)
+    assert g[0]["launches"] > x[0]["launches"] + 3 * iters, (g, x)
+    assert x[0]["collectives"] == g[0]["collectives"] and x[0]["syncs"] <= iters + 8 and x[0]["resident"]
+
+
 def _ndev():
     import torch
     return torch.cuda.device_count()
