@@ -1254,7 +1254,7 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   rc |= dev_alloc((void **)&e->dev.cond_off, sizeof(uint64_t) * (L + 1));
   rc |= dev_alloc((void **)&e->dev.seq, seq.size());
   rc |= dev_alloc((void **)&e->dev.seq_off, sizeof(uint64_t) * (L + 1));
-  rc |= dev_alloc((void **)&e->dev.P, sizeof(int32_t) * L);
+  rc |= dev_alloc((void **)&e->dev.P, sizeof(int32_t) * 2 * L);
   rc |= dev_alloc((void **)&e->dev.orig, sizeof(int32_t) * L);
   rc |= dev_alloc((void **)&e->dev.out, sizeof(double) * GPH_OUT_SLOTS * L);
   rc |= dev_alloc((void **)&e->dev.stats, sizeof(double) * (2 * e->cfg.K + 2 * e->cfg.B) * L);
@@ -1271,7 +1271,16 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   rc |= h2d(e, (void *)e->dev.cond_off, e->h_cond_off.data(), sizeof(uint64_t) * (L + 1));
   rc |= h2d(e, (void *)e->dev.seq, seq.data(), seq.size());
   rc |= h2d(e, (void *)e->dev.seq_off, seq_off.data(), sizeof(uint64_t) * (L + 1));
-  rc |= h2d(e, (void *)e->dev.P, e->h_P.data(), sizeof(int32_t) * L);
+  {
+    std::vector<int32_t> pu((size_t)2 * L);      /* {phased, unphased} patterns per slot */
+    for (int64_t j = 0; j < L; j++) {
+      const int64_t g = e->h_orig[j];
+      int U = 0;
+      for (int64_t p = poff[g]; p < poff[g + 1]; p++) U += numPhases[p] > 0;
+      pu[2 * j] = e->h_P[j]; pu[2 * j + 1] = U;
+    }
+    rc |= h2d(e, (void *)e->dev.P, pu.data(), sizeof(int32_t) * 2 * L);
+  }
   rc |= h2d(e, (void *)e->dev.orig, e->h_orig.data(), sizeof(int32_t) * L);
   if (mutRates) rc |= h2d(e, e->d_mutRate, rates.data(), sizeof(double) * L);
   if (rc) return GPH_EHIP;

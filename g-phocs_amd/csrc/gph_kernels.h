@@ -15,7 +15,7 @@ struct GphDev {            // device pointers (passed by value to every kernel)
   const uint64_t *cond_off;
   const char *seq;         // leaf codes, phases, counts; per-locus byte offset seq_off[g]
   const uint64_t *seq_off;
-  const int32_t *P;        // phased patterns per locus
+  const int32_t *P;        // per locus (slot g): P[2 g] phased patterns, P[2 g + 1] unphased patterns (those with a phase count: the U of the algorithmic-byte formula)
   const int32_t *orig;     // original (input-order) local index of the locus stored at slot g
   double *out;             // L * GPH_OUT_SLOTS
   double *stats;           // L * (2K+2B): coal_stats, num_coals, mig_stats, num_migs of every locus, compact
@@ -76,7 +76,7 @@ GPH_DEV void stage_in(const GphDev &D, int g, const char *pages, int withSeq)
   constexpr int SCH = 2;                                                   /* first 2 KB of the sequence block */
   uint64_t o0 = 0, o1 = 0;
   if (withSeq) { o0 = D.seq_off[g]; o1 = D.seq_off[g + 1]; }
-  const int P_ = D.P[g];                   /* per-locus table entries: scalar loads, in flight with everything else */
+  const int P_ = D.P[2 * g];               /* per-locus table entries: scalar loads, in flight with everything else */
   const uint64_t co_ = D.cond_off[g];
   /* (a locus whose block outgrows the launch group's LDS reads it where it lies: nothing to stage) */
   gph_copy16_in2<PCH, SCH>(GPH_LDSP(&gph_lds), pages + (size_t)g * g_lay.page_bytes, g_lay.page_bytes >> 4, GPH_SMB, D.seq + o0,
@@ -107,26 +107,17 @@ GPH_DEV void stage_out(const GphDev &D, int g, char *pages, int unused)
 // algorithmic bytes of the launch's useOld evaluations: 96 R P + 20 N + 8 U + 8 per evaluation that recomputed
 // anything -- derived ONCE here from the counters (recomputed nodes, evaluations, the empty ones) instead of being summed in
 // LDS by every evaluation: the same integers, a dozen instructions less per evaluation
-GPH_DEV double eval_bytes()
+GPH_DEV double eval_bytes(int U)
 {
   const int P = CNT(CN_P), full = CNT(CN_EVALS) - CNT(CN_EMPTY);
   if (P <= 0 || full <= 0) return 0.0;
-  const int q_phases = GPH_Q_PHASES(P, g_lay.n);
-  int U = 0;
-  const GphSeq SQ = seq_ref();
-#ifdef GPH_HOSTEMU
-  for (int p = 0; p < P; p++) U += sq_u16v(SQ, q_phases, p) > 0;
-#else
-  for (int p0 = 0; p0 < P; p0 += GPH_WAVE) {
-    const int p = p0 + GPH_LANE;
-    U += __builtin_popcountll(__ballot(p < P && sq_u16v(SQ, q_phases, p < P ? p : 0) > 0));
-  }
-#endif
+  /* U (the unphased patterns of the locus) comes from the per-locus table: counting the phase words here was 70 of the 3 300
+   * instructions of a tau evaluation -- the measurement on the hot path again (tools/bbcount.sh, round 5) */
   return (double)(96ll * (CNT(CN_NODES) - CNT(CN_NODES0)) * P + (long long)(20 * g_lay.N + 8 * U + 8) * full);
 }
 GPH_DEV void out_common(const GphDev &D, int g)
 {
-  const double bytes_ = eval_bytes();
+  const double bytes_ = eval_bytes(D.P[2 * g + 1]);
   if (GPH_LANE == 0) {
     double *o = D.out + (size_t)g * GPH_OUT_SLOTS;
     o[8] = CNT(CN_EVALS);
@@ -207,9 +198,9 @@ GPH_DEV void kb_init(const GphDev &D, int g, uint32_t seedz, double mutRate, int
   int i;
   /* blank page */
   for (i = GPH_LANE; i < (int)(sizeof(GphLds) / 4); i += GPH_NLANES) ((GPH_LDS int32_t *)&gph_lds)[i] = 0;
-  if (D.P[g] <= g_lay.huge_P) copy16_g2l(0, D.seq + D.seq_off[g], (int)(D.seq_off[g + 1] - D.seq_off[g]));
+  if (D.P[2 * g] <= g_lay.huge_P) copy16_g2l(0, D.seq + D.seq_off[g], (int)(D.seq_off[g + 1] - D.seq_off[g]));
   GPH_SYNC();
-  scratch_init(D, g, D.P[g], D.cond_off[g]);
+  scratch_init(D, g, D.P[2 * g], D.cond_off[g]);
   setISC(IS_RX, 11);
   setISC(IS_RY, 23);
   setISC(IS_RZ, (int)seedz);
@@ -1072,7 +1063,7 @@ GPH_DEV void kb_lrate_scan(const GphDev &D, const GphLrArgs &A)
       } else {
         GphRng unused_rng;
         GPH_SYNC();
-        P = RFL(D.P[j]);
+        P = RFL(D.P[2 * j]);
         lr_load(D.pages + (size_t)j * g_lay.page_bytes, D.seq + D.seq_off[j], (int)(D.seq_off[j + 1] - D.seq_off[j]), A.o_gnd, 0, root,
                 dummy_r, dummy_l, unused_rng);
         lg = lik_private(A.o_gnd, 0, P, root, rnew, A.o_scr, P > A.Pscr ? gs : (gdbl *)0);
