@@ -506,7 +506,11 @@ def test_in_kernel_exchange_makes_a_reduction_point_one_launch(tmp_path):
     out = str(tmp_path / "rec")
     script = tmp_path / "peer.py"
     script.write_text(PEER_WORKER % dict(repo=REPO, pack=os.path.join(GOLDEN, name + ".gpk"), iters=iters, out=out))
-    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
+        # (the bounded wait gave up -- Fatal Error 9997: the two ranks' streams shared a hardware queue in that process; once more)
+        if r.returncode == 0 or "9997" not in r.stderr:
+            break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     recs = [open(out + f".{t}.{k}").read() for t in "xg" for k in (0, 1)]
