@@ -74,7 +74,7 @@ def main():
            "accept_counters": "exact on every record", "accept_counts_total": [int(a) for a in acc],
            "evaluations": int(cnt["evals"]),
            "worst_rel_diff": max(per_it.values()), "worst_rel_diff_per_iteration": [per_it.get(i, 0.0) for i in range(-1, iters)],
-           "per_locus_state_compared": nstate, "per_locus_state": "every 50th locus after the last iteration: integers exact, doubles within 1e-9",
+           "per_locus_state_compared": nstate, "per_locus_state": "every 50th locus after the last iteration: every per-locus line byte for byte (tests/parity_util.py: STATE_TOL = 0)",
            "wall_s_hip_incl_record_io": t_hip, "wall_s_oracle_one_thread": t_oracle,
            "library_build_id": G.load_library(dims=(pk.n, pk.K, pk.B)).gph_build_id().decode()}
     json.dump(res, open(os.path.join(out_dir, "full_size_100it.json"), "w"), indent=1)
