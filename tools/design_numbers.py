@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""DESIGN.md = tools/DESIGN.template.md with section 8's figures filled in from the committed profile set:
+"""Fills the figures of DESIGN.md section 8 (and the first row of section 10) in from the committed profile set
+(tools/design_section8.template.md holds that text with placeholders; DESIGN.md carries the markers):
    python3 tools/design_numbers.py <tag, e.g. v1>"""
 import csv
 import json
@@ -35,8 +36,15 @@ for k, c in (("C2", c2), ("C3", c3), ("C5", c5)):
     rep[k + "_EVALS"] = M(c["evals_per_s"]); rep[k + "_ITS"] = f"{c['iters_per_s']:.1f}"; rep[k + "_MS"] = f"{c['ms_per_iteration']:.2f}"
     rep[k + "_SWEEP"] = f"{c['sweep_ms']:.2f}"; rep[k + "_FRAC"] = f"{c['sweep_roofline_frac']:.3f}"
     rep[k + "_CFRAC"] = f"{c['sweep_hbm_counter_frac']:.3f}" if "sweep_hbm_counter_frac" in c else "—"
-s = open(os.path.join(REPO, "tools", "DESIGN.template.md")).read()
+tpl = open(os.path.join(REPO, "tools", "design_section8.template.md")).read()
+tpl = tpl[tpl.index("-->\n") + 4:]
 for k in sorted(rep, key=len, reverse=True):
-    s = s.replace(k, rep[k])
-open(os.path.join(REPO, "DESIGN.md"), "w").write(s)
-print(len(s), "bytes;", {k: rep[k] for k in ("V_EVALS", "V_MS", "V_SWEEP", "V_FRAC", "C2_EVALS", "C3_EVALS", "C5_EVALS", "S_MS")})
+    tpl = tpl.replace(k, rep[k])
+body, row = tpl.split("<!-- ROW -->\n")
+d = open(os.path.join(REPO, "DESIGN.md")).read()
+a, b = d.index("<!-- SECTION8 BEGIN"), d.index("<!-- SECTION8 END -->")
+d = d[:d.index("\n", a) + 1] + body.strip("\n") + "\n" + d[b:]
+a, b = d.index("<!-- ROW1 BEGIN -->\n") + len("<!-- ROW1 BEGIN -->\n"), d.index("<!-- ROW1 END -->")
+d = d[:a] + row.strip("\n") + "\n" + d[b:]
+open(os.path.join(REPO, "DESIGN.md"), "w").write(d)
+print(len(d), "bytes;", {k: rep[k] for k in ("V_EVALS", "V_MS", "V_SWEEP", "V_FRAC", "C2_EVALS", "C3_EVALS", "C5_EVALS", "S_MS")})
