@@ -2239,10 +2239,12 @@ int gph_engine_last_error(gph_engine *e, int64_t *locus, int32_t *code)
 int gph_engine_debug_break_chain(gph_engine *e, int64_t global_locus, int32_t pop)
 {
   if (!e || !e->initialized || pop < 0 || pop >= e->cfg.K) return GPH_EARG;
+  SETDEV(e);
+  /* (several ranks: EVERY rank calls this -- a deferred synchronizeEvents pass runs here, with its exchange; the rank that
+   * does not hold the locus returns GPH_EARG after it) */
+  { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
   const long long lo = global_locus - e->cfg.locus_begin;
   if (lo < 0 || lo >= e->L) return GPH_EARG;
-  SETDEV(e);
-  { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
   int64_t slot = -1;
   for (int64_t j = 0; j < e->L; j++) if (e->h_orig[j] == lo) { slot = j; break; }
   if (slot < 0) return GPH_ESTATE;

@@ -2160,8 +2160,10 @@ GPH_DEVHOT int trace_lineage(int node, RNG &rng, const GphWalkResume *rs = nullp
   if (node < g_lay.n) {
     ev = FIRSTEV(pop);
     GphEvS S0 = ld_ev(ev);
-    while (S0.type != GPH_SAMPLES_START && S0.type != GPH_END_CHAIN) { ev = S0.next; S0 = ld_ev(ev); }
-    if (S0.type == GPH_END_CHAIN) { gph_fail(101); setDI(inst, DI_NEV, 0); setSPRLN(RECONNECT, 0.0); return RECONNECT ? -1 : 0; }
+    /* (bounded like every chain walk: a broken link or a cycle must not hang the wavefront -- Fatal Error 0101 as for a chain
+     * without its SAMPLES_START; found by tests/test_native_comm.py: a host-build rank spun here on a chain broken for the test) */
+    for (int guard_ = 0; S0.type != GPH_SAMPLES_START && S0.type != GPH_END_CHAIN && S0.next >= 0 && guard_ < GPH_CAP_E; guard_++) { ev = S0.next; S0 = ld_ev(ev); }
+    if (S0.type != GPH_SAMPLES_START) { gph_fail(101); setDI(inst, DI_NEV, 0); setSPRLN(RECONNECT, 0.0); return RECONNECT ? -1 : 0; }
     ev = S0.next;
   } else {
     ev = ENEXT(NEV(node));
@@ -2447,8 +2449,8 @@ template <class RNG> GPH_DEVHOT int trace_pair(int node, RNG &rng)
   if (node < g_lay.n) {
     ev = FIRSTEV(pop);
     GphEvS S0 = ld_ev(ev);
-    while (S0.type != GPH_SAMPLES_START && S0.type != GPH_END_CHAIN) { ev = S0.next; S0 = ld_ev(ev); }
-    if (S0.type == GPH_END_CHAIN) { gph_fail(101); setDI(0, DI_NEV, 0); setSPRLN(0, 0.0); setDI(1, DI_NEV, 0); setSPRLN(1, 0.0); return -1; }
+    for (int guard_ = 0; S0.type != GPH_SAMPLES_START && S0.type != GPH_END_CHAIN && S0.next >= 0 && guard_ < GPH_CAP_E; guard_++) { ev = S0.next; S0 = ld_ev(ev); }
+    if (S0.type != GPH_SAMPLES_START) { gph_fail(101); setDI(0, DI_NEV, 0); setSPRLN(0, 0.0); setDI(1, DI_NEV, 0); setSPRLN(1, 0.0); return -1; }
     ev = S0.next;
   } else {
     ev = ENEXT(NEV(node));

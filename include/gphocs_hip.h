@@ -185,7 +185,9 @@ int gph_engine_get_counters(gph_engine *e, gph_counters *out, int32_t reset);
  * has then already printed, to stderr, the code, the locus and -- what printGenealogyAndExit(gen, ...) prints upstream,
  * GPhoCS.c:660-676 -- that locus's genealogy and event chains in the canonical dump format. */
 int gph_engine_last_error(gph_engine *e, int64_t *locus, int32_t *code);
-/* tests only: break the event chain of population `pop` of one locus, so that the next kernel raises a fatal code for it */
+/* tests only: break the event chain of population `pop` of one locus, so that the next kernel raises a fatal code for it
+ * (with several ranks every rank calls it: it completes a deferred synchronizeEvents pass first, which is a collective;
+ * GPH_EARG on the ranks that do not hold the locus) */
 int gph_engine_debug_break_chain(gph_engine *e, int64_t global_locus, int32_t pop);
 /* debug / parity: canonical text dump of every local locus (same format as the oracle's) */
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditionals, int32_t append);

@@ -200,3 +200,43 @@ def test_broken_chains_fail_cleanly_and_alike_in_both_walk_forms(hostemu, tmp_pa
     assert res["fused"] == res["two"], res
     got = eval(res["fused"].split(" ", 1)[1])
     assert all(locus == 11 and code in (6, 8, 91, 92, 96) for _, locus, code in got), got
+
+
+ERR_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(repo)r)
+import gphocs_amd as G
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+lib = G.load_library(%(lib)r)
+comm = lib.gph_comm_create_shm(%(name)r.encode(), rank, world)
+assert comm
+s = G.Sampler(G.Pack.load(%(pack)r), lib=lib, rank=rank, world=world, comm=comm)
+s.initialize()
+for it in range(4):
+    s.iteration(it)
+victim = %(victim)d
+rc = lib.gph_engine_debug_break_chain(s.engine, victim, 1)      # every rank calls it (it completes a deferred collective pass first)
+assert (rc == 0) == (s.begin <= victim < s.end), rc     # ... and the rank that holds the locus breaks one of its chains
+try:
+    s.iteration(4)
+    print("RESULT", rank, "no error")
+except RuntimeError:
+    print("RESULT", rank, s.last_error())
+'''
+
+
+def test_fatal_error_of_one_shard_names_the_locus_on_every_rank(hostemu, tmp_path):
+    """the first failing locus and its code ride in the reduced row as ONE column combined by maximum over the ranks
+    ((2^30 - locus) 2^14 + code): a broken chain in rank 1's shard ends the iteration on BOTH ranks with GPH_EKERNEL, and
+    gph_engine_last_error names the same global locus and code on both"""
+    script = tmp_path / "w.py"
+    script.write_text(ERR_WORKER % dict(repo=REPO, lib=hostemu, name=f"/gphocs-test-err-{os.getpid()}",
+                                        pack=os.path.join(GOLDEN, "m3.gpk"), victim=13))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    res = sorted(ln for o, _ in outs for ln in o.splitlines() if ln.startswith("RESULT"))
+    assert len(res) == 2, outs
+    r0, r1 = (eval(ln.split(" ", 2)[2]) for ln in res)
+    assert r0 == r1 and r0[0] == 13 and 0 < r0[1] < 10000, res
+    # only the rank that holds the locus can print its genealogy
+    assert sum("genealogy and event chains of locus 13" in e for _, e in outs) == 1
