@@ -228,7 +228,7 @@ def test_big_build_against_live_oracle(oracle_cli, tmp_path, config, loci, iters
         assert max(int(m.group(1)) for ln in open(st) for m in re.finditer(r" \d+:\d+:-?\d+:(-?\d+):0x", ln)) > 127
 
 
-def fatal_error_names_the_locus(G, lib, tmp_path, capfd=None):
+def fatal_error_names_the_locus(G, lib, tmp_path, capfd=None, victim=11, second=14):
     """a broken event chain in ONE locus: the failing call returns GPH_EKERNEL, gph_engine_last_error names that locus (the
     first failing one, global index) and a reference-style code, and stderr carries the locus's genealogy and event chains
     -- what printGenealogyAndExit prints upstream (GPhoCS.c:660-676)"""
@@ -238,9 +238,8 @@ def fatal_error_names_the_locus(G, lib, tmp_path, capfd=None):
     for it in range(5):
         s.iteration(it)
     assert s.last_error() == (-1, 0)
-    victim = 11
-    assert lib.gph_engine_debug_break_chain(s.engine, victim, 0) == 0
-    assert lib.gph_engine_debug_break_chain(s.engine, 14, 1) == 0        # a second broken locus: the FIRST one is reported
+    assert lib.gph_engine_debug_break_chain(s.engine, victim, 0 if victim == 11 else 1) == 0
+    assert lib.gph_engine_debug_break_chain(s.engine, second, 1) == 0        # a second broken locus: the FIRST one is reported
     with pytest.raises(RuntimeError):
         s.iteration(5)
     locus, code = s.last_error()
@@ -249,10 +248,11 @@ def fatal_error_names_the_locus(G, lib, tmp_path, capfd=None):
     return locus, code
 
 
-def test_fatal_error_names_the_locus_and_prints_its_genealogy(hostemu, tmp_path, capfd):
+@pytest.mark.parametrize("victim,second", [(11, 14), (13, 15)])
+def test_fatal_error_names_the_locus_and_prints_its_genealogy(hostemu, tmp_path, capfd, victim, second):
     import gphocs_amd as G
     R, lib = hostemu
-    locus, code = fatal_error_names_the_locus(G, lib, tmp_path)
+    locus, code = fatal_error_names_the_locus(G, lib, tmp_path, victim=victim, second=second)
     err = capfd.readouterr().err
     assert f"Fatal Error {code:04d}" in err and f"first in locus {locus}" in err
     assert f"LOCUS {locus} root" in err and "\nC 0" in err and "\nN 0 " in err
