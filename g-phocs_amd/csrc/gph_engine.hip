@@ -2175,10 +2175,11 @@ int gph_engine_part_(gph_engine *e, int32_t part, int32_t iteration, const doubl
 //   of branches (stride >= 1 + 5 N: calls, then target, age, return code, value, root per call), scaleAllNodeAges by
 //   1 + arg / 1000 + revert + full recompute (delta, value), rubberBandRipple do / undo (moved events, two deltas),
 //   traceLineage(arg, 0 / 1) + evaluation (stride >= 13: 1, res, target, father's new population, old / new migration
-//   events, both prior deltas, father's new age, data delta, generator state)
+//   events, both prior deltas, father's new age, data delta, generator state);  op 7 (`unit2` H): rubberBandRipple do / undo over
+//   the MIG_BAND_START / MIG_BAND_END events of every band (UpdateTau's start_or_end list): moved events, two deltas
 int gph_engine_unit(gph_engine *e, int32_t op, int32_t arg, double *out, int32_t stride)
 {
-  if (!e || !e->initialized || !out || op < 0 || op > 6 || stride < 3 * (e->cfg.n - 1) || stride < 4) return GPH_EARG;
+  if (!e || !e->initialized || !out || op < 0 || op > 7 || stride < 3 * (e->cfg.n - 1) || stride < 4) return GPH_EARG;
   if ((op == 3 && stride < 1 + 5 * (2 * e->cfg.n - 1)) || (op == 6 && stride < 13)) return GPH_EARG;
   if ((op == 3 || op == 6) && (arg < 0 || arg >= 2 * e->cfg.n - 1)) return GPH_EARG;
   SETDEV(e);

@@ -1304,6 +1304,35 @@ GPH_DEV void kb_unit(const GphDev &D, int g, int op, int arg, double *out, int s
     const double d1 = rubber_band_ripple(1);
     const double d0 = rubber_band_ripple(0);
     if (GPH_LANE == 0) { uo[0] = nm; uo[1] = d1; uo[2] = d0; }
+  } else if (op == 7) {
+    /* rubberBandRipple(do / undo) over migration-band events (unit2 H): per band the MIG_BAND_START event of the target
+     * population's chain 30 % into the gap to its successor, the MIG_BAND_END event 30 % into the gap to its predecessor */
+    int nm = 0;
+    for (int b = 0; b < g_lay.B; b++) {
+      const int tp = g_model.bandTgt[b];
+      double age = g_model.popAge[tp];
+      int guard = 0;
+      for (int ev = FIRSTEV(tp); ev >= 0 && guard++ <= GPH_CAP_E;) {
+        const GphEvS R = ld_ev(ev);
+        age += R.time;
+        if (R.node == b && nm < GPH_CAP_RB) {
+          if (R.type == GPH_MIG_BAND_START && R.next >= 0 && UNI(ld_ev(R.next).time > 0.0)) {
+            setRBI(0, nm, ev); setRBI(2, nm, tp);
+            sf64(&GphLds::rb_age, nm, age + 0.3 * ld_ev(R.next).time);
+            nm++;
+          } else if (R.type == GPH_MIG_BAND_END && UNI(R.time > 0.0)) {
+            setRBI(0, nm, ev); setRBI(2, nm, tp);
+            sf64(&GphLds::rb_age, nm, age - 0.3 * R.time);
+            nm++;
+          }
+        }
+        ev = R.next;
+      }
+    }
+    setISC(IS_RB_NUM, nm);
+    const double d1 = rubber_band_ripple(1);
+    const double d0 = rubber_band_ripple(0);
+    if (GPH_LANE == 0) { uo[0] = nm; uo[1] = d1; uo[2] = d0; }
   } else {
     /* op 6: traceLineage(arg, 0) + traceLineage(arg, 1) as UpdateGB_MigSPR calls them + the evaluation (unit2 G); nothing is
      * undone: this kernel does not write the page back */

@@ -203,7 +203,9 @@ int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditiona
  * value; op 5: rubberBandRipple(do) + (undo) (patch.c:815-869) over every migration event's source-side event moved 0.01 %
  * up: events, two deltas; op 6: traceLineage(arg, 0) + traceLineage(arg, 1) (patch.c:886-1331) + evaluation (stride >= 13:
  * 1, res, target, father's new population, migration events removed / created, both prior deltas, father's new age, data
- * delta, the locus's generator state) */
+ * delta, the locus's generator state); op 7: rubberBandRipple(do) + (undo) over the MIG_BAND_START / MIG_BAND_END events of
+ * every band, moved 30 % into the neighbouring gap (the entries UpdateTau adds with start_or_end 1 / 0, GPhoCS.c:3708-3745):
+ * events, two deltas */
 int gph_engine_unit(gph_engine *e, int32_t op, int32_t arg, double *out, int32_t stride);
 /* timing of the last launch of a named kernel class, measured with HIP events on the
  * engine's own stream: which = 0 sweep, 1 tau_eval, 2 mix_eval, 3 init, 4 check,

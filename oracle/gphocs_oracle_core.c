@@ -18,6 +18,7 @@ void go_fatal(go_state *s, int code, const char *what)
 {
   fprintf(stderr, "oracle: fatal %d (%s)\n", code, what);
   s->error = code;
+  fflush(NULL);        /* the records written so far are evidence too: the reference's exit() flushes its files */
   abort();
 }
 

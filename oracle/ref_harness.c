@@ -439,7 +439,12 @@ static int cmd_unit(int argc, char **argv)
  *                                        calls them (GPhoCS.c:2659-2700) + computeLocusDataLikelihood(1): the sampled
  *                                        regraft (target edge, father's new population and age), the migration events
  *                                        removed / created, both prior deltas, the locus's generator state afterwards
- * F and G change the chains; they run in forked children, so that every call starts from the same state. */
+ *   H g n d_do d_undo                    rubberBandRipple(do / undo) over MIGRATION-BAND events (start_or_end == 1 in UpdateTau's
+ *                                        list, GPhoCS.c:3708-3745): per band the MIG_BAND_START event of the target population's
+ *                                        chain moved 30 % into the gap to its successor, the MIG_BAND_END event 30 % into the gap
+ *                                        to its predecessor -- only models whose bands start above their target population's age
+ *                                        (an ancestral end) have a START event that is not the first of its chain
+ * F, G and H change the chains; they run in forked children, so that every call starts from the same state. */
 #include <sys/wait.h>
 #include <unistd.h>
 static int u2_descends(LocusData *ld, int x, int anc)
@@ -536,6 +541,40 @@ static int cmd_unit2(int argc, char **argv)
       _exit(0);
     }
     { int st = 0; waitpid(pid, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) { fprintf(stderr, "unit2: F child failed\n"); return 3; } }
+  }
+  /* H */
+  { pid_t pid = fork();
+    if (pid == 0) {
+      for (gen = 0; gen < dataSetup.numLoci; gen++) {
+        RUBBERBAND_MIGS *rb = &locus_data[gen].rubberband_migs;
+        double d1, d0;
+        int nm, b, ev;
+        rb->num_moved_events = 0;
+        for (b = 0; b < pt->numMigBands; b++) {
+          int tp = pt->migBands[b].targetPop;
+          double age = pt->pops[tp]->age;
+          for (ev = event_chains[gen].first_event[tp]; ev >= 0; ev = event_chains[gen].events[ev].next) {
+            Event *e = &event_chains[gen].events[ev];
+            age += e->elapsed_time;
+            if (e->node_id != b) continue;
+            if (e->type == MIG_BAND_START && e->next >= 0 && event_chains[gen].events[e->next].elapsed_time > 0.0) {
+              rb->orig_events[rb->num_moved_events] = ev; rb->pops[rb->num_moved_events] = tp;
+              rb->new_ages[rb->num_moved_events++] = age + 0.3 * event_chains[gen].events[e->next].elapsed_time;
+            } else if (e->type == MIG_BAND_END && e->elapsed_time > 0.0) {
+              rb->orig_events[rb->num_moved_events] = ev; rb->pops[rb->num_moved_events] = tp;
+              rb->new_ages[rb->num_moved_events++] = age - 0.3 * e->elapsed_time;
+            }
+          }
+        }
+        nm = rb->num_moved_events;
+        d1 = rubberBandRipple(gen, 1);
+        d0 = rubberBandRipple(gen, 0);
+        fprintf(of, "H %d %d %a %a\n", gen, nm, d1, d0);
+      }
+      fflush(of);
+      _exit(0);
+    }
+    { int st = 0; waitpid(pid, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) { fprintf(stderr, "unit2: H child failed\n"); return 3; } }
   }
   /* G */
   for (node = 0; node < N; node++) {

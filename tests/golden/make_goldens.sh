@@ -79,9 +79,19 @@ timeout 900 $REF main -n 1 w2.ctl w2b.ctl > w2.stdout 2>/dev/null
 gen x8 8 10 300 24 8 --mig-beta 0.00000004
 timeout 900 $REF main -n 1 x8.ctl >/dev/null 2>&1     # x8.trace: the reference's own trace file at the caps
 
+# j1-j3 (round 6): population trees that are NOT caterpillars, migration bands with ANCESTRAL endpoints (tools/gen_synth.py configs
+# 20-22): j1 = (((A,B),(C,D)),E) with AB->CD, CD->AB, C->AB, E->ABCD; j2 = ((A,(B,C)),((D,E),F)) with 8 mixed bands; j3 =
+# ((A,B),(C,D)) with an ESTIMATED ancient sample in C below the band target CD.  UpdateTau's band-start branches (GPhoCS.c:3353-3431)
+gen j1 20 12 300 150 50 --mig-beta 0.00000004
+gen j2 21 10 300 100 25 --mig-beta 0.00000004
+gen j3 22 12 300 120 40 --mig-beta 0.00000004
+# randomised model shapes (tools/random_models.py: random binary trees, random legal bands incl. ancestral ends, optional ancient
+# sample): the reference's pack and records of 12 models that run through and 3 on which the reference itself aborts
+python3 $REPO/tools/random_models.py fixtures rnd 2 3 6 17 19 23 24 42 43 55 59 72 34 46 35
+
 # kernel-level fixtures: single calls of the reference's per-locus functions after N iterations
-for c in "m4 60" "a7 40" "g2 20"; do set -- $c; timeout 300 $REF unit $1.ctl $2 $1.unit >/dev/null 2>&1; done
-for c in "m4 60" "a7 40" "g2 20"; do set -- $c; timeout 600 $REF unit2 $1.ctl $2 $1.unit2 >/dev/null 2>&1; done   # executeGenSPR, scaleAllNodeAges, rubberBandRipple, traceLineage
+for c in "m4 60" "a7 40" "g2 20" "j1 70" "j2 50"; do set -- $c; timeout 300 $REF unit $1.ctl $2 $1.unit >/dev/null 2>&1; done
+for c in "m4 60" "a7 40" "g2 20" "j1 70" "j2 50"; do set -- $c; timeout 600 $REF unit2 $1.ctl $2 $1.unit2 >/dev/null 2>&1; done   # executeGenSPR, scaleAllNodeAges, rubberBandRipple (migration events; band START / END events), traceLineage
 
 # y9: beyond 32 leaves / 32 populations -- 40 leaves, 20 current populations (the reference's NSPECIES cap: 39 populations),
 # 16 migration bands (library variant `h`: two genealogy nodes per lane would not do, the node sets are 128 bits wide)

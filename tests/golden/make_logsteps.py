@@ -11,7 +11,7 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.path.join(HERE, "..", "..", "oracle", "_ref", "gphocs_ref_log")
-CASES = {"m3": (3, 11), "a7": (2, 9)}      # case: the two loci (global indices, "gen" upstream)
+CASES = {"m3": (3, 11), "a7": (2, 9), "j1": (2, 7)}      # case: the two loci (global indices, "gen" upstream)
 KEEP = 200
 
 for name, loci in CASES.items():

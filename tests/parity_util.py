@@ -40,6 +40,30 @@ def compare_records(path_a, path_b, tol=REL_TOL):
     return worst
 
 
+def compare_trace_files(want_path, got_path, lnl_tol=REL_TOL):
+    """the trace file of the real binary (GPhoCS.c:1763-1769) against the program's: header and row count equal; every
+    PARAMETER column (thetas, taus, migration rates, sample ages, rate variance: printParamVals, %8.5f of per-chain values that
+    follow from exact accept decisions) character-identical; only the two log-likelihood columns at the end of a row (sums
+    over loci, %.6f) within `lnl_tol` relative, plus one unit of their last printed digit.  Returns the number of rows whose
+    log-likelihood text differs."""
+    want = open(want_path).read().splitlines()
+    got = open(got_path).read().splitlines()
+    assert want[0] == got[0], "trace header differs"
+    assert len(want) == len(got), f"trace rows: {len(want)} vs {len(got)}"
+    ndiff = 0
+    for w, g in zip(want[1:], got[1:]):
+        if w == g:
+            continue
+        ndiff += 1
+        wt, gt = w.split("\t"), g.split("\t")
+        assert len(wt) == len(gt), (w, g)
+        assert wt[:-2] == gt[:-2], f"a parameter column differs:\n  {w}\n  {g}"
+        for a, b in zip(wt[-2:], gt[-2:]):
+            x, y = float(a), float(b)
+            assert abs(x - y) <= lnl_tol * abs(x) + 1.000001e-6, f"log-likelihood column differs beyond {lnl_tol}:\n  {w}\n  {g}"
+    return ndiff
+
+
 def _tok_close(u, v, tol):
     """compare one whitespace token that may be int, hexfloat or colon-joined mixture"""
     if u == v:

@@ -1,9 +1,11 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes), against
  (a) the committed golden vectors generated from the REAL reference, and
  (b) the oracle restatement run live on the same seeded inputs.
-Accept/reject counters of every proposal in every iteration must be identical; accumulators
-within 1e-10 relative; the full per-locus state (topology, event chains with ids and lineage
-counts, statistics, RNG slots exact; ages/times/conditionals within 1e-9 relative)."""
+Accept/reject counters of every proposal in every iteration must be identical; accumulators (sums over
+loci) within 1e-10 relative; the full per-locus state -- topology, event chains with ids and lineage
+counts, statistics, RNG slots, ages, elapsed times, conditionals, per-locus log-likelihoods -- BYTE FOR BYTE
+(parity_util.STATE_TOL = 0).  Trace files of the program: every parameter column character-identical to the
+real binary's, the two log-likelihood columns within 1e-10 relative (parity_util.compare_trace_files)."""
 import os
 import subprocess
 import sys
@@ -12,7 +14,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, REPO
-from parity_util import compare_records, compare_states
+from parity_util import compare_records, compare_states, compare_trace_files
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +25,11 @@ CASES = {"g1": 30, "g2": 30, "m3": 120, "m4": 60, "c5": 30, "s3": 40, "a6": 80, 
          "y9": 16,   # y9: 40 leaves, 39 populations (the reference's NSPECIES cap), 16 bands: library variant h
          "n7": 12,   # n7: 72 leaves: library variant n (200 leaves / 39 populations / 100 bands, the reference's own caps)
          "q6": 8,    # q6: 72 leaves, two 20-kb loci with 145 and 698 phased patterns (up to 512 phases): the second one's sequence block (28 KB) lies beyond the LDS budget next to variant n's 44-KB image and stays in HBM
+         # round 6: population trees that are not caterpillars, migration bands with ancestral endpoints (the band-start branches of
+         # UpdateTau, GPhoCS.c:3353-3431; tau bounds from two ancestral sons, :3266-3267; rubberBandRipple with start_or_end == 1)
+         "j1": 150,  # (((A,B),(C,D)),E), bands AB->CD, CD->AB, C->AB, E->ABCD
+         "j2": 100,  # ((A,(B,C)),((D,E),F)), 8 bands: leaf<->ancestral, ancestral<->ancestral, leaf->leaf, D->BC across the root
+         "j3": 120,  # ((A,B),(C,D)) with an ESTIMATED ancient sample in C under the band target CD
          "b2": 24}   # b2: 20 migration bands: library variant b (live-band list in LDS, model read from HBM, 384-column reduced rows)
 
 
@@ -294,7 +301,7 @@ def test_native_rccl_communicator_single_rank(G, tmp_path):
     compare_records(out, str(tmp_path / "g"))
 
 
-@pytest.mark.parametrize("name,ranks", [("m3", 2), ("a7", 2), ("v8", 3)])
+@pytest.mark.parametrize("name,ranks", [("m3", 2), ("a7", 2), ("v8", 3), ("j1", 3)])
 def test_launcher_ranks_share_the_device(tmp_path, name, ranks):
     """`G-PhoCS-hip -g N <control-file>`: the C launcher forks N ranks before any GPU call; with one GPU on the box the
     ranks share it and exchange through host shared memory (RCCL refuses two ranks on one GPU).  One chain, loci
@@ -305,17 +312,10 @@ def test_launcher_ranks_share_the_device(tmp_path, name, ranks):
         shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
     r = subprocess.run([exe, "-g", str(ranks), "-v", name + ".ctl"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
-    got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
-    assert want[0] == got[0] and len(want) == len(got)
-    for w, g in zip(want[1:], got[1:]):
-        if w == g:
-            continue
-        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
-        assert len(wf) == len(gf) and all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
+    compare_trace_files(os.path.join(GOLDEN, name + ".trace"), os.path.join(tmp_path, name + ".trace"))
 
 
-@pytest.mark.parametrize("name", ["m4", "a7", "g2"])
+@pytest.mark.parametrize("name", ["m4", "a7", "g2", "j1", "j2"])     # j1 / j2: bands with ancestral ends (band START events inside a chain)
 def test_kernel_level_fixtures(G, name):
     """single calls of computeLocusDataLikelihood / considerEventMove / rubberBand(pre) on the device
     (gph_engine_unit) against the outputs of the real reference's own functions for the same chain state
@@ -337,10 +337,11 @@ def test_native_library_is_the_path(G):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "y9", "r5", "b2", "n7"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "y9", "r5", "b2", "n7", "j1", "j2", "j3"])
 def test_program_trace_file(name, tmp_path):
     """G-PhoCS-hip <control-file> on the MI355X: the trace file of the real G-PhoCS binary for the same
-    control + sequence files (tests/golden/*.trace), to the printed precision (%8.5f / %.6f)."""
+    control + sequence files (tests/golden/*.trace): parameter columns character-identical, the two log-likelihood
+    columns within 1e-10 relative (GPhoCS.c:1763-1769)."""
     import shutil
     import subprocess
     exe = os.path.join(REPO, "g-phocs_amd", "G-PhoCS-hip")
@@ -354,19 +355,8 @@ def test_program_trace_file(name, tmp_path):
         extra = ["w2b.ctl"]
     r = subprocess.run([exe, name + ".ctl"] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
-    got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
-    assert want[0] == got[0] and len(want) == len(got)
-    ndiff = 0
-    for w, g in zip(want[1:], got[1:]):
-        if w == g:
-            continue
-        ndiff += 1
-        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
-        assert len(wf) == len(gf) and wf[0] == gf[0]
-        # one unit of the last printed digit at most (values agree to 1e-10 relative)
-        assert all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
-    assert ndiff <= len(want) // 10
+    ndiff = compare_trace_files(os.path.join(GOLDEN, name + ".trace"), os.path.join(tmp_path, name + ".trace"))
+    assert ndiff <= len(open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()) // 10
 
 
 @pytest.mark.gpu
@@ -381,14 +371,7 @@ def test_program_through_rccl_launcher(tmp_path, name):
            "--master-port", "29533", os.path.join(REPO, "tools", "run_multi_gpu.py"), name + ".ctl"]
     r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
-    got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
-    assert want[0] == got[0] and len(want) == len(got)
-    for w, g in zip(want[1:], got[1:]):
-        if w == g:
-            continue
-        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
-        assert len(wf) == len(gf) and all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
+    compare_trace_files(os.path.join(GOLDEN, name + ".trace"), os.path.join(tmp_path, name + ".trace"))
 
 
 # ---------------------------------------------------------------- world > 1 on the device-resident path
@@ -544,14 +527,7 @@ def test_launcher_two_real_rccl_ranks(tmp_path, name):
     r = subprocess.run([exe, "-g", "2", "-v", name + ".ctl"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "shared-memory exchange" not in r.stdout
-    want = open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()
-    got = open(os.path.join(tmp_path, name + ".trace")).read().splitlines()
-    assert want[0] == got[0] and len(want) == len(got)
-    for w, g in zip(want[1:], got[1:]):
-        if w == g:
-            continue
-        wf, gf = [float(x) for x in w.split()], [float(x) for x in g.split()]
-        assert len(wf) == len(gf) and all(abs(x - y) <= 1.5e-5 * max(1.0, abs(x)) for x, y in zip(wf, gf)), (w, g)
+    compare_trace_files(os.path.join(GOLDEN, name + ".trace"), os.path.join(tmp_path, name + ".trace"))
 
 
 def test_bench_two_real_rccl_ranks():

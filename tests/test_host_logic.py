@@ -25,7 +25,7 @@ def hostemu():
     return R, G.load_library(R.build_hostemu())
 
 
-@pytest.mark.parametrize("name,iters", [("g1", 30), ("g2", 30), ("m3", 120), ("m4", 60), ("c5", 30), ("s3", 40), ("a6", 80), ("a7", 100), ("z0", 12), ("v8", 60), ("v9", 60), ("w2", 50), ("x8", 24), ("r5", 60)])
+@pytest.mark.parametrize("name,iters", [("g1", 30), ("g2", 30), ("m3", 120), ("m4", 60), ("c5", 30), ("s3", 40), ("a6", 80), ("a7", 100), ("z0", 12), ("v8", 60), ("v9", 60), ("w2", 50), ("x8", 24), ("r5", 60), ("j1", 150), ("j2", 100), ("j3", 120)])
 def test_hostemu_matches_reference_goldens(hostemu, name, iters, tmp_path):
     R, lib = hostemu
     tr, st = tmp_path / "t", tmp_path / "s"
@@ -48,7 +48,7 @@ def test_sequence_block_with_32bit_counts(hostemu, name, iters, tmp_path, monkey
     assert worst < 1e-12
 
 
-@pytest.mark.parametrize("name,iters", [("y9", 16), ("x8", 24), ("m3", 120), ("a7", 100), ("v8", 60), ("b2", 24), ("n7", 12), ("q6", 8)])
+@pytest.mark.parametrize("name,iters", [("y9", 16), ("x8", 24), ("m3", 120), ("a7", 100), ("v8", 60), ("b2", 24), ("n7", 12), ("q6", 8), ("j1", 150), ("j2", 100), ("j3", 120)])
 def test_big_tree_build_matches_reference_goldens(name, iters, tmp_path):
     """the 64-leaf / 39-population capacities (library variant `h`: 128-bit node sets, 64-bit population sets, 16-bit
     event ids, list-driven forms instead of the lane-per-node programs): golden y9 -- 40 leaves, 20 current populations
@@ -65,7 +65,7 @@ def test_big_tree_build_matches_reference_goldens(name, iters, tmp_path):
     assert worst < 1e-12
 
 
-@pytest.mark.parametrize("name,iters", [("y9", 16), ("m3", 120), ("a7", 100), ("m4", 60), ("x8", 24)])
+@pytest.mark.parametrize("name,iters", [("y9", 16), ("m3", 120), ("a7", 100), ("m4", 60), ("x8", 24), ("j1", 150), ("j2", 100), ("j3", 120)])
 def test_variant_h_configuration_matches_reference_goldens(name, iters, tmp_path):
     """the configuration of library variants g / h (64 leaves / 39 populations / 16 bands: GPH_BIG_TREE with
     two-word node sets and WITHOUT the many-band forms -- the fused trace_pair walk with its parked state, lik_spr over
@@ -185,7 +185,7 @@ def test_pattern_counts_beyond_16_bits_against_live_oracle(hostemu, oracle_cli, 
     compare_states(st, os_)
 
 
-@pytest.mark.parametrize("name", ["m4", "a7", "g2"])
+@pytest.mark.parametrize("name", ["m4", "a7", "g2", "j1", "j2"])     # j1 / j2: bands with ancestral ends (band START events inside a chain)
 def test_kernel_level_fixtures_hostemu(hostemu, name):
     """single calls of the per-locus functions against the real reference's (tests/golden/*.unit), host-emulation build"""
     import gphocs_amd as G

@@ -15,7 +15,7 @@ from conftest import GOLDEN, REPO
 
 sys.path.insert(0, os.path.join(REPO, "tests", "hostemu"))
 
-CASES = {"m3": (3, 11), "a7": (2, 9)}
+CASES = {"m3": (3, 11), "a7": (2, 9), "j1": (2, 7)}
 KEEP = 200
 NUM = re.compile(r"-?\d+\.?\d*(?:e[-+]?\d+)?")
 

@@ -19,6 +19,7 @@ CASES = {  # name: iterations (must match make_goldens.sh)
     "y9": 16,   # 40 leaves, 39 populations (the reference's NSPECIES cap), 16 bands
     "n7": 12,   # 72 leaves (beyond the 64 of 128-bit node sets; the reference allows 200)
     "b2": 24,   # 20 migration bands (beyond the 16 of the nibble list; the reference allows 100)
+    "j1": 150, "j2": 100, "j3": 120,   # balanced / mixed population trees, bands with ancestral endpoints, estimated ancient sample below a band target
     "q6": 8,    # 72 leaves, two 20-kb loci with 145 / 698 phased patterns, up to 512 phases per pattern (state dumps without conditionals)
 }
 NOCOND = {"q6"}

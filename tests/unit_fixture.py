@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 
-UNIT_CASES = {"m4": 60, "a7": 40, "g2": 20}     # case -> iterations before the calls (tests/golden/make_goldens.sh)
+UNIT_CASES = {"m4": 60, "a7": 40, "g2": 20, "j1": 70, "j2": 50}     # case -> iterations before the calls (tests/golden/make_goldens.sh)
 
 
 def load_unit(path):
@@ -59,7 +59,7 @@ def check_unit(G, lib, golden_dir, name, exact=True):
 
 
 def load_unit2(path):
-    D, E, F, Gt = {}, {}, {}, {}
+    D, E, F, Gt, H = {}, {}, {}, {}, {}
     for l in open(path):
         t = l.split()
         if t[0] == "D":
@@ -68,10 +68,12 @@ def load_unit2(path):
             E[(int(t[1]), int(t[2]))] = (float.fromhex(t[3]), float.fromhex(t[4]))
         elif t[0] == "F":
             F[int(t[1])] = (int(t[2]), float.fromhex(t[3]), float.fromhex(t[4]))
+        elif t[0] == "H":
+            H[int(t[1])] = (int(t[2]), float.fromhex(t[3]), float.fromhex(t[4]))
         elif t[0] == "G":
             Gt[(int(t[1]), int(t[2]))] = (int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]), float.fromhex(t[8]),
                                           float.fromhex(t[9]), float.fromhex(t[10]), float.fromhex(t[11]), int(t[12]), int(t[13]), int(t[14]))
-    return D, E, F, Gt
+    return D, E, F, Gt, H
 
 
 def check_unit2(G, lib, golden_dir, name):
@@ -82,7 +84,7 @@ def check_unit2(G, lib, golden_dir, name):
     s.initialize()
     for it in range(UNIT_CASES[name]):
         s.iteration(it)
-    D, E, F, Gt = load_unit2(os.path.join(golden_dir, name + ".unit2"))
+    D, E, F, Gt, H = load_unit2(os.path.join(golden_dir, name + ".unit2"))
     N = 2 * pk.n - 1
     codes = set()
     for node in range(N):
@@ -103,6 +105,10 @@ def check_unit2(G, lib, golden_dir, name):
     f = s.unit(5)
     for g in range(pk.L):
         assert (int(f[g, 0]), float(f[g, 1]), float(f[g, 2])) == F[g], ("F", g, f[g, :3], F[g])
+    if H:      # rubberBandRipple over band START / END events (start_or_end == 1): fixtures made from round 6 on
+        h = s.unit(7)
+        for g in range(pk.L):
+            assert (int(h[g, 0]), float(h[g, 1]), float(h[g, 2])) == H[g], ("H", g, h[g, :3], H[g])
     for node in range(N):
         t = s.unit(6, node)
         for g in range(pk.L):
@@ -116,4 +122,4 @@ def check_unit2(G, lib, golden_dir, name):
     # nothing of it was written back: the chain continues as if nothing had happened
     s.iteration(UNIT_CASES[name])
     s.close()
-    return sum(len(v) for v in D.values()) + len(E) + len(F) + len(Gt)
+    return sum(len(v) for v in D.values()) + len(E) + len(F) + len(Gt) + len(H)

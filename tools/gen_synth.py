@@ -42,35 +42,76 @@ CONFIGS = {
              [(i + 2, i) for i in range(4)] + [(0, 3), (3, 0)], loci=1000, tau_factor=1.6),
     # more than 64 leaves (the reference allows NS 200, patch.h:22): 36 diploids over 6 populations = 72 leaves, 4 bands
     13: dict(pops=[6] * 6, bands=[(0, 1), (1, 0), (3, 2), (4, 3)], loci=1000, tau_factor=1.6),
+    # --- population trees that are NOT caterpillars, migration bands with ANCESTRAL endpoints (round 6).  `tree` is a nested
+    # tuple over the current populations' names; an ancestral population is named by the sorted names below it ("root" at the top);
+    # its tau-initial is 5e-6 * 2^(height-1), cousins spread by 7 % so that no two splits coincide.  These shapes reach what a
+    # caterpillar with leaf-to-leaf bands cannot: a band whose start time moves with a tau (UpdateTau types 1b / 2a / 3,
+    # GPhoCS.c:3353-3431), tau bounds set by two ancestral sons (GPhoCS.c:3266-3267), rubberBandRipple with start_or_end == 1
+    # (patch.c:815-869)
+    20: dict(pops=[1, 1, 1, 1, 1], tree=((("A", "B"), ("C", "D")), "E"),
+             bands=[("AB", "CD"), ("CD", "AB"), ("C", "AB"), ("E", "ABCD")], loci=1000),
+    21: dict(pops=[1, 1, 1, 1, 1, 1], tree=(("A", ("B", "C")), (("D", "E"), "F")),
+             bands=[("A", "BC"), ("BC", "A"), ("DE", "F"), ("F", "DE"), ("ABC", "DEF"), ("DEF", "ABC"), ("B", "C"), ("D", "BC")],
+             loci=1000, tau_base=4e-6),
+    22: dict(pops=[1, 1, 2, 1], tree=(("A", "B"), ("C", "D")), bands=[("AB", "CD"), ("CD", "AB"), ("D", "C"), ("A", "B")],
+             loci=1000, ancient=2, ancient_est=True),
 }
 
 
-def pop_names(kc):
-    cur = [chr(ord("A") + i) for i in range(kc)]
-    anc = []
-    name = cur[0]
-    for i in range(1, kc):
-        name = name + cur[i]
-        anc.append(name if i < kc - 1 else "root")
-    return cur, anc
-
-
 def build_tree(cfg):
-    """caterpillar population tree: ((((A,B),C),D),...); tau-initial doubles per level"""
+    """the population tree of a configuration: current names, and per ancestral population (in the order of the control
+    file: children before parents, root last) its name, two children names and tau-initial.  Without a `tree` entry: the
+    caterpillar ((((A,B),C),D),...) with tau-initial doubling per level.  Returns (cur, anc, taus, children)."""
     kc = len(cfg["pops"])
-    cur, anc = pop_names(kc)
-    taus = []
-    t = 5e-6
-    for i in range(kc - 1):
-        taus.append(t)
-        t *= cfg.get("tau_factor", 2.0) if i < kc - 3 else 5.0 if i == kc - 3 else 1.0
-    return cur, anc, taus
+    cur = [chr(ord("A") + i) for i in range(kc)]
+    if "tree" not in cfg:
+        anc, children = [], []
+        name, prev = cur[0], cur[0]
+        for i in range(1, kc):
+            name = name + cur[i]
+            anc.append(name if i < kc - 1 else "root")
+            children.append((prev, cur[i]))
+            prev = anc[-1]
+        taus = []
+        t = 5e-6
+        for i in range(kc - 1):
+            taus.append(t)
+            t *= cfg.get("tau_factor", 2.0) if i < kc - 3 else 5.0 if i == kc - 3 else 1.0
+        return cur, anc, taus, children
+    anc, taus, children = [], [], []
+    base = cfg.get("tau_base", 5e-6)
+    explicit = cfg.get("taus", {})
+
+    def walk(t):      # -> (name, leaves below, height)
+        if isinstance(t, str):
+            assert t in cur, t
+            return t, [t], 0
+        assert len(t) == 2
+        a, la, ha = walk(t[0])
+        b, lb, hb = walk(t[1])
+        leaves = sorted(la + lb)
+        h = max(ha, hb) + 1
+        nm = "".join(leaves)
+        anc.append(nm)
+        children.append((a, b))
+        taus.append(explicit.get(nm, base * 2.0 ** (h - 1) * (1.0 + 0.07 * (len(anc) - 1))))
+        return nm, leaves, h
+    _, leaves, _ = walk(cfg["tree"])
+    assert leaves == cur, "the tree must name every current population once"
+    anc[-1] = "root"
+    if "root" in explicit:
+        taus[-1] = explicit["root"]
+    return cur, anc, taus, children
+
+
+def ancient_pops(cfg):
+    a = cfg.get("ancient")
+    return [] if a is None else list(a) if isinstance(a, (list, tuple)) else [a]
 
 
 def write_ctl(path, cfg, seqfile, tracefile, loci, seed, iters, samples_per_log, no_mixing=False,
               start_mig=0, mig_beta=0.00001, var_rates=None, fixed_rates=None):
-    cur, anc, taus = build_tree(cfg)
-    kc = len(cur)
+    cur, anc, taus, children = build_tree(cfg)
     out = []
     out.append("GENERAL-INFO-START\n")
     out.append(f"\tseq-file            {seqfile}")
@@ -113,22 +154,20 @@ def write_ctl(path, cfg, seqfile, tracefile, loci, seed, iters, samples_per_log,
         samples = " ".join(f"s{sid + j} d" for j in range(cfg["pops"][i]))
         sid += cfg["pops"][i]
         out.append(f"\t\tsamples\t\t{samples}")
-        if cfg.get("ancient") == i:
+        if i in ancient_pops(cfg):
             out.append("\t\tage\t\t0.000002 " + ("e" if cfg.get("ancient_est") else "f"))
         out.append("\tPOP-END\n")
     out.append("CURRENT-POPS-END\n")
     out.append("ANCESTRAL-POPS-START\n")
-    prev = cur[0]
     for i, nm in enumerate(anc):
         out.append("\tPOP-START")
         out.append(f"\t\tname\t\t\t{nm}")
-        out.append(f"\t\tchildren\t\t{prev}\t\t{cur[i + 1]}")
+        out.append(f"\t\tchildren\t\t{children[i][0]}\t\t{children[i][1]}")
         out.append(f"\t\ttau-initial\t{taus[i]:.9f}")
         out.append("\t\ttau-beta\t\t20000.0\t")
         ft = 0.0000008 if i < len(anc) - 1 else 0.00000286
         out.append(f"\t\tfinetune-tau\t\t\t{ft:.8f}")
         out.append("\tPOP-END\n")
-        prev = nm
     out.append("ANCESTRAL-POPS-END\n")
     if cfg["bands"]:
         out.append("MIG-BANDS-START\t")
@@ -155,13 +194,14 @@ def simulate_locus(rng, cfg, taus, theta, seqlen, ancient_age):
     left = [-1] * nleaf
     right = [-1] * nleaf
     leaf = 0
-    pop_lineages = []
+    pop_lineages = {}
+    cur, anc, _, children = build_tree(cfg)
     for i in range(kc):
         k = 2 * cfg["pops"][i]
-        a0 = ancient_age if cfg.get("ancient") == i else 0.0
+        a0 = ancient_age if i in ancient_pops(cfg) else 0.0
         for j in range(k):
             age[leaf + j] = a0
-        pop_lineages.append((list(range(leaf, leaf + k)), a0))
+        pop_lineages[cur[i]] = (list(range(leaf, leaf + k)), a0)
         leaf += k
 
     def coalesce(lins, t0, t1):
@@ -181,13 +221,21 @@ def simulate_locus(rng, cfg, taus, theta, seqlen, ancient_age):
             lins = [x for idx, x in enumerate(lins) if idx not in (a, b)] + [new]
         return lins
 
-    lins, t0 = pop_lineages[0]
-    lins = coalesce(lins, t0, taus[0])
-    for i in range(1, kc):
-        l2, t2 = pop_lineages[i]
-        l2 = coalesce(l2, t2, taus[i - 1])
-        top = taus[i] if i < kc - 1 else None
-        lins = coalesce(lins + l2, taus[i - 1], top)
+    # populations in the order of the control file (children before parents); a population's lineages coalesce from its
+    # start (sample age / its tau) to its father's tau.  On a caterpillar this is the order A, B, AB, C, ABC, ...
+    tau_of = dict(zip(anc, taus))
+    top_of = {}
+    for nm, (a, b) in zip(anc, children):
+        top_of[a] = top_of[b] = tau_of[nm]
+
+    def run_pop(nm):
+        if nm in pop_lineages:
+            l0, t0 = pop_lineages[nm]
+        else:
+            a, b = children[anc.index(nm)]
+            l0, t0 = run_pop(a) + run_pop(b), tau_of[nm]
+        return coalesce(l0, t0, top_of.get(nm))
+    lins = run_pop(anc[-1])
     root = lins[0]
     seqs = {}
     seqs[root] = rng.integers(0, 4, size=seqlen, dtype=np.uint8)
@@ -226,7 +274,10 @@ def genotype_strings(haps, rng, nmask):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, required=True, choices=sorted(CONFIGS))
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS))
+    ap.add_argument("--model-json", default=None,
+                    help="a configuration as a JSON object instead of --config (keys as in CONFIGS; `tree` as nested lists; "
+                         "`data_seed` seeds the sequences): what tools/random_models.py writes")
     ap.add_argument("--loci", type=int, default=None)
     ap.add_argument("--seqlen", type=int, default=1000)
     ap.add_argument("--iters", type=int, default=100)
@@ -246,10 +297,22 @@ def main():
                          "(readRateFile, GPhoCS.c:491-579, normalises them to mean 1)")
     ap.add_argument("--out", required=True, help="output prefix: <out>.ctl, <out>.seq")
     a = ap.parse_args()
-    cfg = CONFIGS[a.config]
+    if a.model_json:
+        import json
+        cfg = json.load(open(a.model_json))
+
+        def tup(t):
+            return t if isinstance(t, str) else tuple(tup(x) for x in t)
+        if "tree" in cfg:
+            cfg["tree"] = tup(cfg["tree"])
+        cfg["bands"] = [tuple(b) for b in cfg.get("bands", [])]
+        a.config = int(cfg.get("data_seed", 0))
+    else:
+        assert a.config is not None, "--config or --model-json"
+        cfg = CONFIGS[a.config]
     L = a.loci or cfg["loci"]
     rng = np.random.default_rng(20261002 + a.config)
-    cur, anc, taus = build_tree(cfg)
+    cur, anc, taus, _ = build_tree(cfg)
     theta = 1e-4
     seqfile = os.path.basename(a.out) + ".seq"
     write_ctl(a.out + ".ctl", cfg, seqfile, os.path.basename(a.out) + ".trace", L, a.mcmc_seed,
