@@ -22,10 +22,11 @@ value     = locus-likelihood evaluations per second (computeLocusDataLikelihood(
             equivalents, counted by the kernels); MCMC iterations/s is reported next to it.
 roofline  = dominant kernel (fused genealogy sweep): algorithmic bytes (96*R*P + 20*N + 8*U + 8 per
             evaluation, counted per evaluation by the kernel) / HIP-event duration, vs 8 TB/s HBM.
-cpu_baseline = the REAL reference (oracle/_ref, OpenMP build) on the first --cpu-loci loci (default 20 000: a 0.7-GB
-            working set, beyond any L3) of the same data set, started ONCE and timed at 1 / 8 / 16 / 32 / all host
-            threads; the best is the value, with its thread count and the CPU model.  Secondary, labelled: the serial
-            build and the oracle restatement on 5 000 loci.  Rank 0, N = 1 only.
+cpu_baseline = the REAL reference (oracle/_ref, OpenMP build).  VALUE: timed on ALL loci of the workload (--cpu-full-loci, default
+            100 000 = the size the metric is quoted on), one start-up, 1 warm-up + 5 iterations (median) at 1 thread and at the
+            best thread count of the thread sweep.  The thread sweep (`thread_sweep`): the first --cpu-loci loci (20 000: a
+            0.7-GB working set, beyond any L3) at 1 / 8 / 16 / 32 / all host threads.  Secondary, labelled: the serial build and
+            the oracle restatement on 5 000 loci.  Rank 0, N = 1 only.  The whole leg stays under five minutes.
 """
 import argparse
 import json
@@ -137,11 +138,14 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_reference(config, pack, nloci, iters, small_loci, small_iters):
-    """the REAL reference (oracle/_ref, compiled from its own sources in the build container) timed on the host cores
-    of this box.  Primary: its OpenMP build on the first `nloci` loci of the workload (>= 20 000: the working set is
-    far beyond L3), ONE start-up, then `iters` iterations at every thread count of {1, 8, 16, 32, all cores}; the best
-    is the value.  Secondary: the serial build on `small_loci` loci (the earlier rounds' figure)."""
+def cpu_baseline_reference(config, pack, nloci, iters, small_loci, small_iters, full_loci=0):
+    """the REAL reference (oracle/_ref, compiled from its own sources in the build container) timed on the host cores of this
+    box, on its OpenMP build (`-n threads`, GPhoCS.c:116-145).
+      1. thread sweep on the first `nloci` loci (20 000: a 0.7-GB working set, far beyond L3): ONE start-up, then 1 warm-up +
+         `iters` iterations timed one by one at each of {1, 8, 16, 32, all cores}; the median iteration counts.
+      2. THE VALUE (round 6: like for like): the same on ALL `full_loci` loci the metric is quoted on, at 1 thread and at the best
+         thread count of step 1 -- one start-up, 1 warm-up + `iters` iterations each, median.
+      3. secondary: the serial build on `small_loci` loci (the earlier rounds' figure)."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import gen_synth
     ref = os.path.join(REPO, "oracle", "_ref", "gphocs_ref")
@@ -150,32 +154,51 @@ def cpu_baseline_reference(config, pack, nloci, iters, small_loci, small_iters):
         return None
     ncores = os.cpu_count() or 1
     out = {"unit": "evals/s", "kind": "reference", "cpu_model": cpu_model(), "host_cores": ncores}
+
+    def sweep(td, tag, L, spec):
+        t0 = time.perf_counter()
+        write_seq_sample(pack, L, os.path.join(td, tag + ".seq"))
+        gen_synth.write_ctl(os.path.join(td, tag + ".ctl"), gen_synth.CONFIGS[config], tag + ".seq", tag + ".trace", L, 12345, 1000, 100000)
+        t1 = time.perf_counter()
+        r = subprocess.run([ref_omp, "timesweep", tag + ".ctl", str(iters), "1", spec], cwd=td, check=True, capture_output=True,
+                           text=True, timeout=1500)
+        os.unlink(os.path.join(td, tag + ".seq"))
+        rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+        by = {int(x["threads"]): x for x in rows if "threads" in x}
+        return by, rows[0].get("startup_seconds", 0.0), t1 - t0, time.perf_counter() - t0
+
+    def table(by):
+        return {str(t): {"value": x["evals_per_s"], "seconds": x["seconds"], "iterations": x["iters"],
+                         "median_iteration_s": x.get("median_iteration_seconds"), "min_iteration_s": x.get("min_iteration_seconds"),
+                         "max_iteration_s": x.get("max_iteration_seconds")} for t, x in sorted(by.items())}
     with tempfile.TemporaryDirectory() as td:
         if os.path.exists(ref_omp) and nloci > 0:
-            write_seq_sample(pack, nloci, os.path.join(td, "b.seq"))
-            gen_synth.write_ctl(os.path.join(td, "b.ctl"), gen_synth.CONFIGS[config], "b.seq", "b.trace", nloci, 12345,
-                                1000, 100000)
             counts = sorted({t for t in (1, 8, 16, 32, ncores) if t <= ncores})
-            t0 = time.perf_counter()
             # >= 5 timed iterations per thread count, each timed on its own, the MEDIAN is the figure; the all-cores count
             # (never the best: the `omp atomic` accumulations and a static split over few loci per thread) gets 3
             spec = ",".join(f"{t}:3" if t == ncores and t > 64 else str(t) for t in counts)
-            r = subprocess.run([ref_omp, "timesweep", "b.ctl", str(iters), "1", spec], cwd=td,
-                               check=True, capture_output=True, text=True, timeout=1500)
-            rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
-            by = {int(x["threads"]): x for x in rows if "threads" in x}
+            by, startup, wr, leg = sweep(td, "b", nloci, spec)
             best = max(by.values(), key=lambda x: x["evals_per_s"])
-            out.update({"value": best["evals_per_s"], "cores": int(best["threads"]),
-                        "sample": f"first {nloci} loci of the workload (sequence file, {nloci * 0.035:.0f} MB of per-locus state) "
-                                  f"on the reference's OpenMP build: one start-up ({rows[0].get('startup_seconds', 0):.0f} s, untimed), "
-                                  f"then 1 warm-up + {iters} iterations timed one by one at each of {counts} threads, value = from the "
-                                  f"MEDIAN iteration; best = {int(best['threads'])} threads ({best['seconds']:.1f} s); whole leg "
-                                  f"{time.perf_counter() - t0:.0f} s",
-                        "iters_per_s_at_sample": best["iters_per_s"], "statistic": "median of the timed iterations",
-                        "by_threads": {str(t): {"value": x["evals_per_s"], "seconds": x["seconds"], "iterations": x["iters"],
-                                                "median_iteration_s": x.get("median_iteration_seconds"),
-                                                "min_iteration_s": x.get("min_iteration_seconds"),
-                                                "max_iteration_s": x.get("max_iteration_seconds")} for t, x in sorted(by.items())}})
+            part = {"value": best["evals_per_s"], "cores": int(best["threads"]), "loci": nloci,
+                    "sample": f"first {nloci} loci of the workload (sequence file, {nloci * 0.035:.0f} MB of per-locus state) on the "
+                              f"reference's OpenMP build: one start-up ({startup:.0f} s, untimed), then 1 warm-up + {iters} iterations "
+                              f"timed one by one at each of {counts} threads, value = from the MEDIAN iteration; best = "
+                              f"{int(best['threads'])} threads ({best['seconds']:.1f} s); whole leg {leg:.0f} s",
+                    "iters_per_s_at_sample": best["iters_per_s"], "statistic": "median of the timed iterations", "by_threads": table(by)}
+            out.update(part)
+            if full_loci > nloci:
+                # the metric's own size: 1 thread and the best count of the sweep above (at most 16 + 7 iterations of ~5 M evaluations)
+                tb = int(best["threads"])
+                byf, startup_f, wr_f, leg_f = sweep(td, "f", full_loci, "1," + str(tb) if tb != 1 else "1")
+                bestf = max(byf.values(), key=lambda x: x["evals_per_s"])
+                out.update({"value": bestf["evals_per_s"], "cores": int(bestf["threads"]), "loci": full_loci,
+                            "sample": f"ALL {full_loci} loci of the workload ({full_loci * 0.035 / 1000:.1f} GB of per-locus state) on the "
+                                      f"reference's OpenMP build: sequence file written in {wr_f:.0f} s, one start-up ({startup_f:.0f} s, "
+                                      f"untimed), then 1 warm-up + {iters} iterations timed one by one at 1 thread and at {tb} threads "
+                                      f"(the best count of the {nloci}-locus thread sweep, `thread_sweep`); value = from the MEDIAN "
+                                      f"iteration of the better one ({int(bestf['threads'])} threads, {bestf['seconds']:.1f} s); whole leg "
+                                      f"{leg_f:.0f} s",
+                            "iters_per_s_at_sample": bestf["iters_per_s"], "by_threads": table(byf), "thread_sweep": part})
         write_seq_sample(pack, small_loci, os.path.join(td, "s.seq"))
         gen_synth.write_ctl(os.path.join(td, "s.ctl"), gen_synth.CONFIGS[config], "s.seq", "s.trace", small_loci, 12345,
                             1000, 100000)
@@ -390,6 +413,8 @@ def main():
                     "after 200 iterations from the prior-sampled start)")
     ap.add_argument("--samples-per-log", type=int, default=0, help="checkAll period (0 = the pack's: 100)")
     ap.add_argument("--cpu-loci", type=int, default=20000, help="loci of the CPU baseline's data set (the first ones of the workload)")
+    ap.add_argument("--cpu-full-loci", type=int, default=100000,
+                    help="the CPU baseline's VALUE is timed on this many loci (all of the workload's by default; 0 = thread sweep only)")
     ap.add_argument("--cpu-iters", type=int, default=5, help="timed iterations per thread count of the CPU baseline (median reported)")
     ap.add_argument("--cpu-small-loci", type=int, default=5000, help="the secondary, cache-friendlier CPU sample")
     ap.add_argument("--cpu-small-iters", type=int, default=8)
@@ -671,7 +696,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline and not emu:
             try:
                 cb = cpu_baseline_reference(a.config, pack, min(a.cpu_loci, L_total), a.cpu_iters,
-                                            min(a.cpu_small_loci, L_total), a.cpu_small_iters)
+                                            min(a.cpu_small_loci, L_total), a.cpu_small_iters,
+                                            full_loci=min(a.cpu_full_loci, L_total))
                 port = cpu_baseline(G, pack, min(a.cpu_small_loci, L_total), a.cpu_small_iters)
                 if cb is None:
                     cb = port

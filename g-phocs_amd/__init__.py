@@ -262,7 +262,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_engine_num_loci", "gph_engine_hbm_bytes", "gph_debug_math", "gph_engine_class_stats",
     "gph_mcmc_create", "gph_mcmc_destroy", "gph_mcmc_initialize", "gph_mcmc_set_record_file",
     "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
-    "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_engine_last_error", "gph_engine_debug_break_chain", "gph_comm_peer_exchange", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
+    "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_engine_last_error", "gph_engine_debug_break_chain", "gph_comm_peer_exchange", "gph_comm_peer_next_gen", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
     "gph_control_sample_name", "gph_loci_read", "gph_loci_free", "gph_loci_arrays", "gph_run_control_file", "gph_run_control_file_ranked",
     "gph_read_trace", "gph_engine_locus_rate_update", "gph_engine_set_locus_rates", "gph_mcmc_set_locus_rate_finetune",
     "gph_mcmc_locus_rate_state", "gph_engine_set_comm", "gph_engine_host_stats", "gph_engine_set_timing",

@@ -248,6 +248,7 @@ struct gph_comm_group {
   double *xrows = nullptr;
   unsigned long long *xflags = nullptr;
 #endif
+  unsigned long long xgen[64] = {0};    // per rank: generations of the in-kernel exchange published so far (all ranks issue the same reductions)
 };
 static int group_barrier(gph_comm_group *g)
 {
@@ -366,6 +367,13 @@ int gph_comm_peer_exchange(const gph_comm *c, double **rows, unsigned long long 
   if (row_stride) *row_stride = GPH_COMM_XROW;
   return 1;
 #endif
+}
+// the next generation of the in-kernel exchange for this rank: the counter lives with the row slots and flags it numbers (the
+// group), not with an engine -- engines come and go on one communicator
+unsigned long long gph_comm_peer_next_gen(gph_comm *c)
+{
+  if (!c || c->kind != 3 || !c->group) return 0;
+  return ++c->group->xgen[c->rank];
 }
 int gph_comm_world(const gph_comm *c) { return c ? c->world : 1; }
 int gph_comm_rank(const gph_comm *c) { return c ? c->rank : 0; }

@@ -365,7 +365,8 @@ struct gph_engine {
   bool G_dirty = true;               // the host mirror was changed since it was last pushed
   int64_t n_huge = 0;                // loci whose sequence block stays in HBM (the first slots)
   double *peer_rows = nullptr;       // in-kernel exchange of the reduced rows (gph_comm_peer_exchange), else null
-  unsigned long long *peer_flags = nullptr, peer_gen = 0;
+  unsigned long long *peer_flags = nullptr;
+  std::vector<void *> deferred_free; // device blocks released while the in-kernel exchange is on: hipFree waits for the device, and a peer's kernel may be waiting for THIS rank
   int32_t peer_stride = 0;
   int32_t last_error_code = 0;       // the last fatal error check_error reported (gph_engine_last_error)
   long long last_error_locus = -1;
@@ -671,7 +672,7 @@ static int flush_pending(gph_engine *e)
     const bool inkernel = multi && e->peer_rows != nullptr;
     const int fuse = sl.n > 0 && (!multi || inkernel);
     GphPeerX X{1, 0, 0, 0, nullptr, nullptr, nullptr, 0};
-    if (inkernel) X = GphPeerX{gph_comm_world(e->comm), gph_comm_rank(e->comm), e->peer_stride, 0, e->peer_rows, e->peer_flags, e->d_gather, ++e->peer_gen};
+    if (inkernel) X = GphPeerX{gph_comm_world(e->comm), gph_comm_rank(e->comm), e->peer_stride, 0, e->peer_rows, e->peer_flags, e->d_gather, gph_comm_peer_next_gen(e->comm)};
     hipLaunchKernelGGL(k_reduce_stage, dim3(GPH_RED_BLOCKS), dim3(GPH_RED_THREADS), 0, e->stream, e->ka, e->dev, nc0, nc1, e->d_part, e->d_ticket,
                        e->d_red, fuse, sl, e->pend_iteration, X);
     HIPCHK(hipGetLastError());
@@ -872,11 +873,21 @@ static void dump_one_locus(const gph_engine *e, FILE *f, long long global_locus,
 }
 
 // after a host synchronisation: the error the stages recorded, the counters
+// hipFree synchronises the device.  With the in-kernel exchange another rank's reduction kernel may be spinning for this rank's
+// next row: a free between two reduction points would then wait for a kernel that waits for us.  Such blocks are kept until the
+// engine is destroyed.
+static void eng_free(gph_engine *e, void *p)
+{
+  if (!p) return;
+  if (e->peer_rows) e->deferred_free.push_back(p);
+  else dev_free(p);
+}
+
 static int check_error(gph_engine *e)
 {
   const int code = e->G_h->error;
   if (code != 0) {
-    const long long gl = (code == 75 || code == 9999) ? -1 : e->G_h->error_locus;
+    const long long gl = e->G_h->error_locus;      /* -1: not a per-locus error (every gg_* path that raises one says so) */
     e->last_error_code = code;
     e->last_error_locus = gl;
     if (code == 75) fprintf(stderr, "gphocs_hip: synchronizeEvents found an inconsistency (Fatal Error 0075/0076)\n");
@@ -1036,6 +1047,7 @@ int gph_engine_create(const gph_config *cfg, gph_engine **out)
   e->d_gather = e->d_red;
 #endif
   memset(e->G_h, 0, sizeof(GphGlobal));
+  e->G_h->error_locus = -1;          /* (0 is a locus: an error that is not per-locus must not name it -- ADVICE round 5) */
   build_model_static(e);
   *out = e;
   return 0;
@@ -1048,6 +1060,8 @@ void gph_engine_destroy(gph_engine *e)
   dev_free((void *)e->dev.seq); dev_free((void *)e->dev.seq_off); dev_free((void *)e->dev.orig); dev_free((void *)e->dev.P); dev_free(e->dev.out); dev_free(e->dev.stats); dev_free(e->d_mutRate);
   dev_free(e->d_lrec); dev_free(e->d_lpre); dev_free(e->d_slot_of); dev_free(e->d_lr_result); dev_free(e->d_lr_gscr); dev_free(e->d_ref_page); dev_free(e->d_ref_seq);
   dev_free(e->d_part); dev_free(e->dev.err);
+  for (void *p : e->deferred_free) dev_free(p);
+  e->deferred_free.clear();
   dev_free((void *)e->dev.slog_map); dev_free(e->dev.slog); dev_free(e->dev.slog_n);
   if (e->d_gather != e->d_red) dev_free(e->d_gather);
   dev_free(e->d_red);
@@ -1088,7 +1102,9 @@ int gph_engine_set_comm(gph_engine *e, gph_comm *c)
     if (gph_comm_world(c) > 64) return GPH_EARG;
     if (dev_alloc((void **)&e->d_gather, sizeof(double) * GPH_RED_ROW * gph_comm_world(c))) return GPH_EHIP;
   }
-  e->peer_rows = nullptr; e->peer_flags = nullptr; e->peer_gen = 0; e->peer_stride = 0;
+  /* (the generation of the exchange belongs to the GROUP -- gph_comm_peer_next_gen: a second engine on the same communicator
+   * goes on where the first one stopped instead of finding flags of generations it has not reached yet) */
+  e->peer_rows = nullptr; e->peer_flags = nullptr; e->peer_stride = 0;
 #ifndef GPH_HOSTEMU
   if (c && gph_comm_world(c) > 1 && gph_comm_on_stream(c)) {
     double *rows = nullptr; unsigned long long *flags = nullptr; int32_t stride = 0;
@@ -1098,8 +1114,16 @@ int gph_engine_set_comm(gph_engine *e, gph_comm *c)
        * stream then -- a blocking stream orders itself against the legacy null stream, and a null-stream operation of the
        * other rank's host thread (hipMemset at load time) would wait for this rank's waiting kernel: a deadlock until the
        * bounded wait gives up (found with tools/probe/peer_dbg.py; the plain two-stream probe, peer_probe.cpp, runs) */
+      /* ... and the ranks' streams must sit on DIFFERENT hardware queues (a kernel that waits for a kernel queued behind it on
+       * the same queue waits for ever).  HIP keeps a pool of hardware queues PER PRIORITY level and hands streams of one level
+       * to its pool round-robin: streams of different priority levels never share a queue, so rank r takes level r mod levels
+       * -- by construction for up to `levels` thread ranks (3 on this runtime: low / normal / high), round-robin luck beyond */
       hipStream_t ns = nullptr;
-      if (hipStreamSynchronize(e->stream) != hipSuccess || hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) != hipSuccess) return GPH_EHIP;
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+      const int levels = least - greatest + 1;
+      const int prio = levels > 1 ? least - (gph_comm_rank(c) % levels) : 0;
+      if (hipStreamSynchronize(e->stream) != hipSuccess || hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, prio) != hipSuccess) return GPH_EHIP;
       (void)hipStreamDestroy(e->stream);
       e->stream = ns;
     }
@@ -1135,7 +1159,11 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
   {
     int budget = 32 * 1024;
     if (budget < (int)sizeof(GphLds) + 16 * 1024) budget = (int)sizeof(GphLds) + 16 * 1024;     /* (the big-tree builds' images alone are 9 - 44 KB) */
-    if (const char *ov = getenv("GPH_HUGE_LDS")) budget = atoi(ov);
+    if (const char *ov = getenv("GPH_HUGE_LDS")) {
+      budget = atoi(ov);
+      if (budget <= 0) { fprintf(stderr, "gphocs_hip: GPH_HUGE_LDS=%s is not a byte count\n", ov); return GPH_EARG; }
+    }
+    /* the budget covers image + block: what a workgroup can have at all is the CU's 160 KB */
     if (budget > 160 * 1024) budget = 160 * 1024;
     int hp = GPH_WAVE;     /* (a block of up to GPH_WAVE patterns always fits: the lane-per-pattern paths read LDS directly) */
     while (hp < Pmax && (int)sizeof(GphLds) + GPH_Q_BYTES(hp + 1, n, cnt16) <= budget) hp++;
@@ -1303,7 +1331,14 @@ int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *poff, const ui
       if (*q == ',') q++;
     }
   }
-  if (e->lay.lds_bytes + pad_max + (int)sizeof(GphLds) > 160 * 1024) { fprintf(stderr, "gphocs_hip: GPH_LDS_PAD is beyond the LDS\n"); return GPH_EARG; }
+  /* image + the largest launch group's block (+ an experiment's padding) must fit the CU's LDS: said with the numbers, whatever
+   * made it too big (the message used to blame GPH_LDS_PAD for a block that was too large by itself) */
+  if (e->lay.lds_bytes + pad_max + (int)sizeof(GphLds) > 160 * 1024) {
+    fprintf(stderr, "gphocs_hip: %d-byte image + %d-byte sequence block%s = %d bytes of LDS per locus, the CU has %d%s\n", (int)sizeof(GphLds),
+            e->lay.lds_bytes, pad_max ? " + GPH_LDS_PAD" : "", e->lay.lds_bytes + pad_max + (int)sizeof(GphLds), 160 * 1024,
+            getenv("GPH_HUGE_LDS") ? " (GPH_HUGE_LDS is set: lower it, the block then stays in HBM)" : "");
+    return GPH_EARG;
+  }
   for (auto k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, e->lay.lds_bytes + pad_max));
 #endif
   return 0;
@@ -1585,7 +1620,7 @@ int gph_engine_check_all(gph_engine *e, int32_t *ok, double *sumData, double *su
   e->G_h->nrec = 0;
   rc = run_stage_now(e, GS_CHECK_DONE, 0);
   if (ok) *ok = e->G_h->error != 9999;
-  if (e->G_h->error == 9999) { e->G_h->error = 0; e->G_dirty = true; rc = 0; }
+  if (e->G_h->error == 9999) { e->G_h->error = 0; e->G_h->error_locus = -1; e->G_dirty = true; rc = 0; }
   { GphRed R; R.rows = e->h_red; R.world = 1;
     if (sumData) *sumData = R.sum(0, 1);
     if (sumGen) *sumGen = R.sum(0, 2); }
@@ -1720,7 +1755,7 @@ int gph_engine_steplog_enable(gph_engine *e, const int64_t *loci, int32_t n, int
   /* (before the first initialisation nothing is in flight, and the host mirror of the chain state -- not yet pushed -- must
    * not be overwritten by a read-back) */
   if (e->initialized) { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
-  dev_free((void *)e->dev.slog_map); dev_free(e->dev.slog); dev_free(e->dev.slog_n);
+  eng_free(e, (void *)e->dev.slog_map); eng_free(e, e->dev.slog); eng_free(e, e->dev.slog_n);
   e->dev.slog_map = nullptr; e->dev.slog = nullptr; e->dev.slog_n = nullptr; e->dev.slog_cap = 0;
   e->slog_sel = n;
   if (n == 0) return 0;
@@ -1736,7 +1771,7 @@ int gph_engine_steplog_enable(gph_engine *e, const int64_t *loci, int32_t n, int
   if (dev_alloc((void **)&d_map, sizeof(int32_t) * e->L) || dev_alloc((void **)&d_log, sizeof(double) * 8 * (size_t)n * cap) ||
       dev_alloc((void **)&d_n, sizeof(int32_t) * n) ||
       h2d(e, d_map, map.data(), sizeof(int32_t) * e->L) || h2d(e, d_n, zero.data(), sizeof(int32_t) * n)) {
-    dev_free(d_map); dev_free(d_log); dev_free(d_n);
+    eng_free(e, d_map); eng_free(e, d_log); eng_free(e, d_n);
     e->slog_sel = 0;
     return GPH_EHIP;
   }
@@ -1824,12 +1859,6 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
   io->accepted = 0;
   if (finetune <= 0.0) return 0;                       /* GPhoCS.c:4606 */
   const bool owner = e->cfg.locus_begin == 0;          /* this rank holds the reference locus (genRateRef = 0) */
-  if (e->n_huge > 0) {
-    /* the serial scan stages the sequence block of the reference locus (and of a locus it re-evaluates) in LDS */
-    fprintf(stderr, "gphocs_hip: locus-mut-rate VAR with a locus of more than %d phased patterns (sequence block beyond the LDS "
-                    "budget of %s) is not supported\n", e->lay.huge_P, getenv("GPH_HUGE_LDS") ? "GPH_HUGE_LDS" : "32 KB");
-    return GPH_EARG;
-  }
   SETDEV(e);
   if (!multi_rank(e) && (!owner || e->cfg.L_total != e->L)) {
     fprintf(stderr, "gphocs_hip: UpdateLocusRate over a shard of the loci needs the all-reduce hook (gph_engine_set_allreduce)\n");
@@ -1895,6 +1924,24 @@ int gph_engine_locus_rate_update(gph_engine *e, double finetune, double alpha, g
     e->lr.o_pe = e->lr.o_prog + progb;
     e->lr.o_lf = lfb ? e->lr.o_pe + align_up(N * 8, 16) : 0;
     e->lr_lds_bytes = e->lr.o_pe + align_up(N * 8, 16) + lfb;
+    /* The scan keeps TWO sequence blocks in its dynamic LDS (the reference locus's, and the one it re-evaluates), each sized for
+     * the largest locus of the rank; loci whose block stays in HBM for the per-locus kernels ("huge", round 5) are staged here like
+     * any other (lr_load copies from HBM).  What does not fit next to the static image cannot run: ALL ranks learn it in one
+     * exchange and fail together before any kernel of the update (a rank returning alone would leave the others in the next
+     * collective -- ADVICE round 5). */
+    {
+      const int lds_max = 160 * 1024;
+      double too_big[1] = {e->lr_lds_bytes + (int)sizeof(GphLds) > lds_max ? 1.0 : 0.0};
+      if (multi_rank(e) && (rc = xreduce(e, too_big, 1, nullptr, 0))) return rc;
+      if (too_big[0] != 0.0) {
+        if (e->lr_lds_bytes + (int)sizeof(GphLds) > lds_max)
+          fprintf(stderr, "gphocs_hip: locus-mut-rate VAR: the serial scan of UpdateLocusRate needs %d bytes of LDS for two sequence "
+                          "blocks of up to %d phased patterns (%d bytes each) next to the %d-byte image; the CU has %d\n",
+                  e->lr_lds_bytes, Pmax, seqb, (int)sizeof(GphLds), lds_max);
+        memset(&e->lr, 0, sizeof e->lr);
+        return GPH_EARG;
+      }
+    }
     e->lr.ref_seq_bytes = GPH_Q_BYTES(Pr, n, y.cnt16);
     rc |= dev_alloc((void **)&e->d_lrec, sizeof(GphLrRec) * e->L);
     rc |= dev_alloc((void **)&e->d_lpre, sizeof(GphLrPre) * e->L);

@@ -93,7 +93,7 @@ GPH_HD double gg_rndnormal(GphGlobal &G)
     v = 2 * gg_rndu(G) - 1;
     s = u * u + v * v;
     if (s > 0 && s < 1) break;
-    if (++guard > 100000) { if (!G.error) G.error = 89; return 0.0; }
+    if (++guard > 100000) { if (!G.error) { G.error = 89; G.error_locus = -1; } return 0.0; }
   }
   s = sqrt(-2. * gph_log(s) / s);
   return u * s;
@@ -218,7 +218,7 @@ GPH_HD void gg_sweep_done(GphGlobal &G, const GphRed &R, int with_sync)
   G.nrec = 0;          /* first stage of an iteration */
   G.shownValid = 0;
   gg_count(G, R, 0);
-  if (with_sync && R.mn(0, 15) < 1.0 && !G.error) G.error = 75;   /* synchronizeEvents, Fatal Error 0075/0076 */
+  if (with_sync && R.mn(0, 15) < 1.0 && !G.error) { G.error = 75; G.error_locus = -1; }   /* synchronizeEvents, Fatal Error 0075/0076 */
   G.dataLogLikelihood += R.sum(0, 3);
   G.logLikelihood += R.sum(0, 4);
   G.acc[0] += (int64_t)R.sum(0, 0);
@@ -589,7 +589,7 @@ GPH_HD void gg_stage(GphGlobal &G, const GphRed &R, int stage, int arg)
     break;
   case GS_REFRESH_DONE:   /* genLogLikelihood refresh, GPhoCS.c:1749-1757: out 0 ok, 1 old, 2 new genLnL */
     gg_count(G, R, 8);
-    if (R.mn(0, 0) < 1.0 && !G.error) G.error = 75;
+    if (R.mn(0, 0) < 1.0 && !G.error) { G.error = 75; G.error_locus = -1; }
     if (arg) {
       G.logLikelihood -= R.sum(0, 1) / G.Ltot;
       G.logLikelihood += R.sum(0, 2) / G.Ltot;
@@ -597,7 +597,7 @@ GPH_HD void gg_stage(GphGlobal &G, const GphRed &R, int stage, int arg)
     break;
   case GS_CHECK_DONE:     /* checkAll, patch.c:2745-2884: out 0 ok, 1 dataLnL, 2 genLnL; statistics in section 1 */
     gg_count(G, R, 4);
-    if (R.mn(0, 0) < 1.0 && !G.error) G.error = 9999;
+    if (R.mn(0, 0) < 1.0 && !G.error) { G.error = 9999; G.error_locus = -1; }
     G.dataLogLikelihood = R.sum(0, 1);
     G.logLikelihood = (R.sum(0, 2) + R.sum(0, 1)) / G.Ltot;
     gg_totals(G, R);

@@ -99,6 +99,9 @@ int gph_comm_on_stream(const gph_comm *c);
  * every rank's kernels can address: thread ranks of one process today): a reduction point is then ONE launch per rank, as
  * with a single rank, instead of reduction + all-gather + decision stage.  Opt-in: GPH_PEER_EXCHANGE=1 (see gph_comm.cpp). */
 int gph_comm_peer_exchange(const gph_comm *c, double **rows, unsigned long long **flags, int32_t *row_stride);
+/* the generation word this rank publishes next (1, 2, ...): counted per communicator, so that a second engine on the same
+ * communicator continues the sequence the flags already hold */
+unsigned long long gph_comm_peer_next_gen(gph_comm *c);
 const char *gph_comm_kind(const gph_comm *c);
 int gph_comm_allgather_stream(gph_comm *c, const double *d_in, double *d_out, int32_t count, void *hip_stream);
 int gph_comm_allreduce_host(gph_comm *c, double *sums, int32_t nsum, double *mins, int32_t nmin);

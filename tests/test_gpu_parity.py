@@ -639,6 +639,27 @@ def test_loci_whose_sequence_block_outgrows_lds_read_it_from_hbm(G, oracle_cli, 
     compare_states(b + ".state", os_)
 
 
+@pytest.mark.parametrize("budget", [5200, 8000])
+def test_variable_locus_rates_with_sequence_blocks_in_hbm(G, oracle_cli, tmp_path, budget):
+    """round 6 (ADVICE): `locus-mut-rate VAR` with loci whose sequence block stays in HBM -- refused at the
+    first UpdateLocusRate until round 5.  The `stress` pack as a VAR chain (alpha 1.4, step 0.9), blocks forced into HBM by
+    GPH_HUGE_LDS: byte-identical to the run with every block in LDS, and equal to the oracle's serial loop (GPhoCS.c:4598-4680)"""
+    from gphocs_amd_pkg import synth
+    pk = synth.make_var_rates(G.Pack.load(os.path.join(GOLDEN, "stress.gpk")), 1.4, 0.9)
+    pack = str(tmp_path / "stress_var.gpk")
+    synth.write_pack(pk, pack)
+    a, b = str(tmp_path / "lds.rec"), str(tmp_path / "hbm.rec")
+    _records(G, pack, 12, a)
+    _records(G, pack, 12, b, env={"GPH_HUGE_LDS": str(budget)})
+    assert open(a).read() == open(b).read()
+    assert open(a + ".state").read() == open(b + ".state").read()
+    ot, os_ = tmp_path / "o.trace", tmp_path / "o.state"
+    subprocess.run([oracle_cli, "run", pack, "12", str(ot), str(os_), "11", "1"], check=True, timeout=600)
+    compare_records(b, ot)
+    compare_states(b + ".state", os_)
+    assert sum(int(l.split()[3]) for l in open(b) if " LRATE " in l) > 20
+
+
 def test_side_stream_equals_serial_launch_groups(G, tmp_path):
     """the launch group of the pattern-rich loci (P > 64) runs next to the main group on a side stream, forked from and
     joined to the engine's stream per launch point; GPH_SIDE_STREAM=0 runs the two groups one after the other:

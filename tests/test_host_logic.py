@@ -164,6 +164,29 @@ def test_loci_whose_sequence_block_outgrows_lds_read_it_from_hbm(hostemu, oracle
     compare_states(st, os_)
 
 
+@pytest.mark.parametrize("budget", [8000, 11000])
+def test_variable_locus_rates_with_sequence_blocks_in_hbm(hostemu, oracle_cli, tmp_path, monkeypatch, budget):
+    """round 6 (ADVICE): `locus-mut-rate VAR` together with loci whose sequence block stays in HBM was
+    refused at the first UpdateLocusRate; the serial scan stages every block it evaluates from HBM into its own LDS, so the only
+    limit left is that LDS (checked collectively).  The `stress` pack as a VAR chain with a large step, blocks forced into HBM:
+    records, rates and per-locus state against the oracle's serial loop (GPhoCS.c:4598-4680)"""
+    import gphocs_amd as G
+    from gphocs_amd_pkg import synth
+    R, lib = hostemu
+    monkeypatch.setenv("GPH_HUGE_LDS", str(budget))
+    pk = synth.make_var_rates(G.Pack.load(os.path.join(GOLDEN, "stress.gpk")), 1.4, 0.9)
+    pk.popName = [f"p{k}" for k in range(pk.K)] if not getattr(pk, "popName", None) else pk.popName
+    pth = str(tmp_path / "stress_var.gpk")
+    synth.write_pack(pk, pth)
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(pth, 12, str(tr), str(st), 11, lib=lib)
+    ot, os_ = tmp_path / "o.t", tmp_path / "o.s"
+    subprocess.run([oracle_cli, "run", pth, "12", str(ot), str(os_), "11", "1"], check=True, timeout=300)
+    assert compare_records(tr, ot) < 1e-12
+    compare_states(st, os_)
+    assert sum(int(l.split()[3]) for l in open(tr) if " LRATE " in l) > 20       # accepted rate proposals
+
+
 def test_pattern_counts_beyond_16_bits_against_live_oracle(hostemu, oracle_cli, tmp_path):
     """a data set with pattern counts above 65 535 (long loci): the sequence block falls back to 32-bit counts by itself;
     host build of the engine sources against the oracle's serial loop on the same pack"""
