@@ -373,6 +373,23 @@ def _load_library(path):
 
 
 # ------------------------------------------------------------------------------------ packs
+def encode_phases(counts):
+    """phase counts as the C ABI carries them (include/gphocs_hip.h: GPH_NUMPHASES): below 2^15 as they are, a power of two from
+    2^15 on as 0x8000 | exponent"""
+    a = np.asarray(counts, dtype=np.int64)
+    big = a >= 0x8000
+    if big.any():
+        ex = np.round(np.log2(np.where(big, a, 1))).astype(np.int64)
+        assert np.all((1 << ex[big]) == a[big]), "a phase count of 2^15 or more must be a power of two"
+        a = np.where(big, 0x8000 | ex, a)
+    return a.astype(np.uint16)
+
+
+def decode_phases(words):
+    w = np.asarray(words, dtype=np.int64)
+    return np.where(w < 0x8000, w, np.left_shift(1, w & 31))
+
+
 class Pack:
     """Model + processed loci (the input of gph_engine_load_loci): what the reference holds
     after readControlFile + processAlignments (GPhoCS.c:147-235).  Text format written by
@@ -453,7 +470,7 @@ class Pack:
             offs.append(offs[-1] + P)
         p.pattern_offsets = np.array(offs, dtype=np.int64)
         p.leafcodes = np.array(leaf, dtype=np.uint8).reshape(-1, p.n)
-        p.numPhases = np.array(phases, dtype=np.uint16)
+        p.numPhases = encode_phases(phases)
         p.counts = np.array(counts, dtype=np.int32)
         p.mutRates = np.array(rates)
         return p

@@ -784,9 +784,13 @@ void process_locus(const RawLocus &raw, int n, const std::vector<uint8_t> &isDip
     int64_t numPhases = 1;
     for (int h = 0; h < n; h++)
       if (perturb[h]) numPhases *= 2;
-    if (numPhases > 65535) {
-      char msg[160];
-      snprintf(msg, sizeof msg, "pattern %zu has %lld phases; the engine stores phase counts in 16 bits (max 65535)", p + 1, (long long)numPhases);
+    /* a count of 2^15 or more travels as 0x8000 | exponent in the 16-bit word (gph_types.h: GPH_PHASES; always a power of two
+     * here).  Beyond 2^24 phased rows of ONE pattern the reference itself asks malloc for >= 64 N x 2^24 bytes (76 GB at 36
+     * leaves, AlignmentProcessor.c:1068-1090): refused with the pattern named */
+    if (numPhases > ((int64_t)1 << 24)) {
+      char msg[200];
+      snprintf(msg, sizeof msg, "pattern %zu has %lld phases (more than 24 unbroken heterozygotes in one repeated column): beyond 2^24 "
+               "phased patterns for one column", p + 1, (long long)numPhases);
       out.error = msg;
       return;
     }
@@ -815,7 +819,11 @@ void process_locus(const RawLocus &raw, int n, const std::vector<uint8_t> &isDip
       out.phases.push_back(0);
       out.counts.push_back(0);
     }
-    out.phases[row0] = (uint16_t)numPhases;
+    {
+      uint16_t w = (uint16_t)numPhases;
+      if (numPhases >= 0x8000) { int ex = 0; while (((int64_t)1 << ex) < numPhases) ex++; w = (uint16_t)(0x8000 | ex); }
+      out.phases[row0] = w;
+    }
     out.counts[row0] = cnt[p];
   }
 }

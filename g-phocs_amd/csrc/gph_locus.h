@@ -806,7 +806,7 @@ GPH_DEVHOT double root_sum_generic(CP rc, int P, int q_phases, int q_count, int 
   double lnl = 0.0;
 #ifdef GPH_HOSTEMU
   for (int p = 0; p < P; p++) {
-    const int ph = sq_u16v(SQ, q_phases, p);
+    const int ph = GPH_PHASES(sq_u16v(SQ, q_phases, p));
     if (ph > 0) {
       const int nc = 4 * ph;
       double prob = 0.0;
@@ -821,7 +821,7 @@ GPH_DEVHOT double root_sum_generic(CP rc, int P, int q_phases, int q_count, int 
   for (int p0 = 0; p0 < P; p0 += GPH_WAVE) {
     const int p = p0 + GPH_LANE;
     double term = 0.0;
-    const int ph = p < P ? sq_u16v(SQ, q_phases, p) : 0;
+    const int ph = p < P ? GPH_PHASES(sq_u16v(SQ, q_phases, p)) : 0;
     if (ph > 0) {
       const int nc = 4 * ph;
       double prob = 0.0;
@@ -1381,7 +1381,7 @@ GPH_DEVHOT double lik_private_t(int o_nd, int o_seq, int P, int root, double rat
   } else {
     GPH_WAVE_FENCE();
     for (int p = lane; p < P; p += GPH_NLANES) {
-      int ph = gu16v(q_phases, p);
+      int ph = GPH_PHASES(gu16v(q_phases, p));
       if (ph > 0) {
         int nc = 4 * ph;
         double prob = 0.0;
@@ -1433,7 +1433,7 @@ GPH_DEV double lik_private(int o_nd, int o_seq, int P, int root, double rate, in
   double lnl = 0.0;
   const double *rc = scr + ((root - n) * P) * 4;
   for (p = 0; p < P; p++) {
-    int ph = gu16v(q_phases, p);
+    int ph = GPH_PHASES(gu16v(q_phases, p));
     if (ph > 0) {
       int nc = 4 * ph, c;
       double prob = 0.0;

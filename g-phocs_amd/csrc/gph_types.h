@@ -143,8 +143,13 @@ struct GphKargs {
 // group's dynamic LDS has the room (GphLayout.dyn_bytes).  The block is what decides how many loci are resident per CU
 // next to the 4.3-KB static image (LDS comes in 1280-byte granules): a 64-pattern block is 768 bytes this way, 1424 with
 // a byte per code and 32-bit counts.
-// Phase counts are 16 bits: the reference keeps an int, and 8 unbroken heterozygotes in one repeated alignment
-// column already give 2^8 = 256 phases (AlignmentProcessor.c:998-1158)
+// Phase counts are 16-bit words (the reference keeps an int; 8 unbroken heterozygotes in one repeated alignment column
+// already give 2^8 = 256 phases, AlignmentProcessor.c:998-1158).  Round 6: a count of 2^15 or more -- always a power of two
+// upstream (2^hets) -- is stored as 0x8000 | exponent, so the word covers every count an int can (GPH_PHASES decodes; only
+// the generic (pattern, base) paths can meet one: such a pattern alone has more rows than a wavefront has lanes).  The same
+// encoding travels through the C ABI's uint16_t arrays (gph_engine_load_loci, gph_loci_get).
+#define GPH_PHASES(w) ((int)(w) < 0x8000 ? (int)(w) : (1 << ((int)(w) & 31)))
+#define GPH_PHASES_ENCODE_MIN 0x8000
 #define GPH_Q_LEAF 0
 #define GPH_Q_NH(n) (((n) + 1) >> 1)
 #define GPH_Q_PHASES(P, n) (((P) * GPH_Q_NH(n) + 1) & ~1)

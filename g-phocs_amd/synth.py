@@ -239,5 +239,6 @@ def write_pack(p, path):
             o0, o1 = int(p.pattern_offsets[g]), int(p.pattern_offsets[g + 1])
             f.write(f"locus {g} {o1 - o0} {float(p.mutRates[g]).hex()}\n")
             for r in range(o0, o1):
-                f.write("".join(code[c] for c in p.leafcodes[r]) + f" {int(p.numPhases[r])} {int(p.counts[r])}\n")
+                w = int(p.numPhases[r])      # the ABI's 16-bit word: 0x8000 | exponent for counts of 2^15 or more
+                f.write("".join(code[c] for c in p.leafcodes[r]) + f" {w if w < 0x8000 else 1 << (w & 31)} {int(p.counts[r])}\n")
         f.write("end\n")

@@ -142,7 +142,9 @@ int gph_engine_set_allreduce(gph_engine *e, gph_allreduce_fn fn, void *user);
 /* native communicator (not owned by the engine; destroy it after the engine) */
 int gph_engine_set_comm(gph_engine *e, gph_comm *c);
 /* leafcodes: [Ptot][n] with 0..3 = T,C,A,G and 4 = N; numPhases non-zero on the first phase
- * of each unphased pattern (16 bits: the reference keeps an int, 2^hets); counts on the same rows; pattern_offsets[L+1] */
+ * of each unphased pattern (the reference keeps an int, 2^hets; here a 16-bit word: a count below 2^15 as it is, a count of 2^15 or
+ * more -- always a power of two -- as 0x8000 | exponent, GPH_NUMPHASES below); counts on the same rows; pattern_offsets[L+1] */
+#define GPH_NUMPHASES(w) ((int)(w) < 0x8000 ? (int)(w) : (1 << ((int)(w) & 31)))
 int gph_engine_load_loci(gph_engine *e, int64_t L, const int64_t *pattern_offsets, const uint8_t *leafcodes,
                          const uint16_t *numPhases, const int32_t *counts, const double *mutRates);
 int gph_engine_set_model(gph_engine *e, const double *theta, const double *popAge, const double *sampleAge,

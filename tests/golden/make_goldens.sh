@@ -132,5 +132,10 @@ timeout 600 $REF run q6.ctl 0 q6.init.rtrace q6.init.state -1 0 >/dev/null; rm -
 timeout 1800 $REF run q6.ctl 8 q6.rtrace q6.state 7 0 >/dev/null
 rm -f q6.seq
 
+# p6: a repeated column of 16 heterozygotes among 18 diploids = 2^16 phases of one pattern, 65 554 phased patterns in one locus
+# (make_p6.py writes the inputs): only the real binary's trace file is kept (the pack would be 2.7 MB)
+python3 make_p6.py
+timeout 900 $REF main -n 1 p6.ctl >/dev/null 2>&1
+
 # decision-level fixtures: the reference compiled with -DLOG_STEPS (oracle/_ref/gphocs_ref_log), two loci each of m3 and a7
 python3 make_logsteps.py

@@ -97,6 +97,27 @@ def test_program_writes_the_reference_trace_file(lib, name, tmp_path):
     compare_trace_files(os.path.join(GOLDEN, name + ".trace"), os.path.join(tmp_path, name + ".trace"))
 
 
+def test_phase_count_beyond_16_bits(tmp_path):
+    """round 6: golden p6 -- a REPEATED column of 16 heterozygotes among 18 diploids (no symmetry break
+    at count > 1, AlignmentProcessor.c:1767) = 2^16 phases of one pattern, 65 554 phased patterns in one locus.  Refused until
+    round 5 ("the engine stores phase counts in 16 bits"); now the word carries 0x8000 | exponent (GPH_NUMPHASES).  The front end's
+    table (phase counts decoded), and the program's trace file against the real binary's, character for character -- host build of
+    the 64-leaf configuration (the block and the conditional arrays of that locus are far beyond any LDS)"""
+    from parity_util import compare_trace_files
+    lib64 = G.load_library(R.build_hostemu(mid=True))
+    for ext in (".ctl", ".seq"):
+        shutil.copy(os.path.join(GOLDEN, "p6" + ext), tmp_path)
+    pk = G.Pack.from_control(os.path.join(tmp_path, "p6.ctl"), lib=lib64, seq_path=os.path.join(tmp_path, "p6.seq"))
+    P = np.diff(pk.pattern_offsets)
+    assert list(P) == [65554, 17]
+    ph = G.decode_phases(pk.numPhases)
+    assert int(ph.max()) == 65536 and int(pk.numPhases.max()) == (0x8000 | 16) and int(ph.sum()) == int(P.sum())
+    assert np.array_equal(G.encode_phases(ph), pk.numPhases)
+    with _in_dir(tmp_path):
+        assert lib64.gph_run_control_file(b"p6.ctl", None, 0, 0) == 0
+    assert compare_trace_files(os.path.join(GOLDEN, "p6.trace"), os.path.join(tmp_path, "p6.trace")) == 0
+
+
 def _seq_error(lib, tmp_path, mutate):
     for ext in (".ctl", ".seq"):
         shutil.copy(os.path.join(GOLDEN, "g1" + ext), tmp_path)

@@ -337,7 +337,8 @@ def test_native_library_is_the_path(G):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "y9", "r5", "b2", "n7", "j1", "j2", "j3"])
+@pytest.mark.parametrize("name", ["g1", "m3", "a7", "f3", "v8", "w2", "x8", "y9", "r5", "b2", "n7", "j1", "j2", "j3",
+                                  "p6"])    # p6: 2^16 phases of one pattern (a repeated column of 16 hets), 65 554 phased patterns in one locus
 def test_program_trace_file(name, tmp_path):
     """G-PhoCS-hip <control-file> on the MI355X: the trace file of the real G-PhoCS binary for the same
     control + sequence files (tests/golden/*.trace): parameter columns character-identical, the two log-likelihood
