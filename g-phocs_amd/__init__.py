@@ -49,6 +49,7 @@ HIPCC_LIBS = ["-ldl", "-lrt"]        # after the sources: an --as-needed linker 
 # shows as a difference between the two.
 HIPCC_VALIDATED = "roc-7.2.0 26014"
 PLAIN_LIB = "libgphocs_hip_plain.so"    # capacities of variant `m`, no -mllvm switches
+CHECKED_LIB = "libgphocs_hip_chk.so"    # capacities of variant `x`, -DGPH_BOUNDS: every index of the device code checked (tests only)
 
 # Capacity variants of the same library (same C ABI, same sources): the static LDS image of a locus is
 # sized by compile-time capacities (csrc/gph_types.h), and a tighter image means more resident
@@ -185,6 +186,11 @@ def _build_locked(verbose):
     jobs.append((os.path.join(_HERE, PLAIN_LIB), "plain",
                  HIPCC_BASE + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}",
                                "-DGPH_LOGSTEPS"]))     # + the decision-level transcript (tests/test_logsteps.py)
+    # checked build (tests only): every index of the per-locus device code against its array's extent (gph_rt.h: GPH_BOUNDS)
+    cl, ck, cb, waves, _ = VARIANTS["x"]
+    jobs.append((os.path.join(_HERE, CHECKED_LIB), "chk",
+                 HIPCC_BASE + HIPCC_TUNING + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}",
+                                              "-DGPH_BOUNDS"]))
     # every variant is one hipcc process of its own (half a minute each): a few at a time
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=max(1, min(5, (os.cpu_count() or 2) // 2))) as ex:
@@ -262,7 +268,7 @@ EXPORTS = [  # every symbol include/gphocs_hip.h declares
     "gph_engine_num_loci", "gph_engine_hbm_bytes", "gph_debug_math", "gph_engine_class_stats",
     "gph_mcmc_create", "gph_mcmc_destroy", "gph_mcmc_initialize", "gph_mcmc_set_record_file",
     "gph_mcmc_iteration", "gph_mcmc_get_state", "gph_mcmc_dump_state", "gph_mcmc_accept_counts",
-    "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_engine_last_error", "gph_engine_debug_break_chain", "gph_comm_peer_exchange", "gph_comm_peer_next_gen", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
+    "gph_mcmc_param_vals", "gph_mcmc_tau_accept_counts", "gph_mcmc_set_finetunes", "gph_mcmc_set_log_period", "gph_engine_last_error", "gph_engine_debug_break_chain", "gph_engine_debug_oob", "gph_comm_peer_exchange", "gph_comm_peer_next_gen", "gph_control_read", "gph_control_free", "gph_control_get", "gph_control_pop_name",
     "gph_control_sample_name", "gph_loci_read", "gph_loci_free", "gph_loci_arrays", "gph_run_control_file", "gph_run_control_file_ranked",
     "gph_read_trace", "gph_engine_locus_rate_update", "gph_engine_set_locus_rates", "gph_mcmc_set_locus_rate_finetune",
     "gph_mcmc_locus_rate_state", "gph_engine_set_comm", "gph_engine_host_stats", "gph_engine_set_timing",
@@ -695,6 +701,12 @@ class Sampler:
         out = np.zeros((self.end - self.begin, stride))
         self._chk(self.lib.gph_engine_unit(self.engine, op, arg, out.ctypes.data_as(C.POINTER(C.c_double)), stride), "unit")
         return out
+
+    def debug_oob(self):
+        """(first out-of-range index of a checked build or 0, 1 if the library is a checked build)"""
+        w, c = C.c_int32(), C.c_int32()
+        self._chk(self.lib.gph_engine_debug_oob(self.engine, C.byref(w), C.byref(c)), "debug_oob")
+        return w.value, c.value
 
     def hbm_bytes(self):
         b = C.c_double()

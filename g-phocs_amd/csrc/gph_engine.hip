@@ -26,6 +26,9 @@ thread_local GphLds gph_lds;
 GphLayout g_lay;
 GphModel g_model;
 GphGlobal *gph_G_emu = nullptr;
+#ifdef GPH_BOUNDS
+int gph_oob_word = 0;
+#endif
 #define GPH_KERNEL(name, ...) static void name(int gph_blk, __VA_ARGS__)
 #define GPH_SWEEP_WAVES_ 6
 #define GPH_SWEEP_ATTR
@@ -2226,9 +2229,10 @@ int gph_engine_part_(gph_engine *e, int32_t part, int32_t iteration, const doubl
 //   the MIG_BAND_START / MIG_BAND_END events of every band (UpdateTau's start_or_end list): moved events, two deltas
 int gph_engine_unit(gph_engine *e, int32_t op, int32_t arg, double *out, int32_t stride)
 {
-  if (!e || !e->initialized || !out || op < 0 || op > 7 || stride < 3 * (e->cfg.n - 1) || stride < 4) return GPH_EARG;
+  if (!e || !e->initialized || !out || op < 0 || op > 8 || stride < 3 * (e->cfg.n - 1) || stride < 4) return GPH_EARG;
   if ((op == 3 && stride < 1 + 5 * (2 * e->cfg.n - 1)) || (op == 6 && stride < 13)) return GPH_EARG;
   if ((op == 3 || op == 6) && (arg < 0 || arg >= 2 * e->cfg.n - 1)) return GPH_EARG;
+  if (op == 8 && (arg < 0 || arg > 100000)) return GPH_EARG;      /* (the checked build's self-test: arg = a node index, possibly out of range) */
   SETDEV(e);
   { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
   if (op == 2) {
@@ -2306,6 +2310,34 @@ int gph_engine_debug_break_chain(gph_engine *e, int64_t global_locus, int32_t po
   if (first[pop] < 0) return GPH_ESTATE;
   evr[first[pop]].next = -1;
   return h2d(e, dp, pg.data(), y.page_bytes);
+}
+
+// tests only: the CHECKED build's first out-of-range index (gph_rt.h: GPH_BOUNDS): source line + 100000 x file (1 gph_locus.h,
+// 2 gph_kernels.h), 8000xx the typed accessors of the image, 9000xx those of the dynamic LDS; 0 = none so far.  *checked = 0 in
+// a build without the checks (every product library).
+int gph_engine_debug_oob(gph_engine *e, int32_t *where, int32_t *checked)
+{
+  if (!e || !where || !checked) return GPH_EARG;
+  *where = 0;
+#ifndef GPH_BOUNDS
+  *checked = 0;
+  return 0;
+#else
+  *checked = 1;
+  SETDEV(e);
+  if (e->initialized) { int rcs = flush_sync(e, true); if (!rcs) rcs = finish_sync(e); if (rcs) return rcs; }
+  /* read and clear: the word belongs to the library (every engine of the process), a report must not be seen twice */
+#ifdef GPH_HOSTEMU
+  *where = gph_oob_word;
+  gph_oob_word = 0;
+#else
+  int w = 0, z = 0;
+  HIPCHK(hipMemcpyFromSymbol(&w, HIP_SYMBOL(gph_oob_word), sizeof(int)));
+  if (w != 0) HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gph_oob_word), &z, sizeof(int)));
+  *where = w;
+#endif
+  return 0;
+#endif
 }
 
 // canonical text dump (same format as oracle/gphocs_oracle_io.c go_dump_state's per-locus part)

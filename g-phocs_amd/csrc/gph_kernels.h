@@ -39,6 +39,8 @@ struct GphDev {            // device pointers (passed by value to every kernel)
 // one with its own LDS allocation (per-pattern terms array, generic mapping).  More, finer P-buckets were measured
 // and dropped: every dispatch costs about one wavefront lifetime of tail.
 
+#undef GPH_FILE_ID
+#define GPH_FILE_ID 2
 // ---------------------------------------------------------------- staging
 GPH_DEV void copy16_g2l(int lds_off, const char *src, int bytes) { gph_copy16_in(GPH_SMB + lds_off, src, bytes >> 4); }
 // HBM page <-> page part of the static LDS image: identical layout, one coalesced copy
@@ -1340,6 +1342,13 @@ GPH_DEV void kb_unit(const GphDev &D, int g, int op, int arg, double *out, int s
     const double d1 = rubber_band_ripple(1);
     const double d0 = rubber_band_ripple(0);
     if (GPH_LANE == 0) { uo[0] = nm; uo[1] = d1; uo[2] = d0; }
+  } else if (op == 8) {
+    /* self-test of the checked build (-DGPH_BOUNDS): an index one past the node records' capacity must be caught (and redirected
+     * to element 0); in a product build this op does nothing */
+#ifdef GPH_BOUNDS
+    const double x = AGE(arg);
+    if (GPH_LANE == 0) uo[0] = x;
+#endif
   } else if (op == 7) {
     /* rubberBandRipple(do / undo) over migration-band events (unit2 H): per band the MIG_BAND_START event of the target
      * population's chain 30 % into the gap to its successor, the MIG_BAND_END event 30 % into the gap to its predecessor */

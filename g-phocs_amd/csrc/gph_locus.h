@@ -81,80 +81,82 @@ template <bool GPH_GM> struct GphCtxT {
 #define NS_PUT(k, v) setpad64((k), (v))
 #endif
 
+#undef GPH_FILE_ID
+#define GPH_FILE_ID 1
 // ---------------------------------------------------------------- accessors
-#define AGE(i) (gph_lds.nd[i].age)
-#define setAGE(i, v) (gph_lds.nd[i].age = (v))
-#define SVAGE(i) (gph_lds.sv[i].age)
-#define setSVAGE(i, v) (gph_lds.sv[i].age = (v))
-#define EVT(e) (gph_lds.ev[e].time)
-#define setEVT(e, v) (gph_lds.ev[e].time = (v))
-#define MAGE(m) gf64(&GphLds::mig_age, (m))
-#define setMAGE(m, v) sf64(&GphLds::mig_age, (m), (v))
-#define COALS(p) gf64(&GphLds::coal, (p))
-#define setCOALS(p, v) sf64(&GphLds::coal, (p), (v))
-#define MIGST(b) gf64(&GphLds::migst, (b))
-#define setMIGST(b, v) sf64(&GphLds::migst, (b), (v))
-#define RBAGE(i) gf64(&GphLds::rb_age, (i))
-#define setRBAGE(i, v) sf64(&GphLds::rb_age, (i), (v))
+#define AGE(i) (gph_lds.nd[GPH_IX((i), GPH_CAP_N)].age)
+#define setAGE(i, v) (gph_lds.nd[GPH_IX((i), GPH_CAP_N)].age = (v))
+#define SVAGE(i) (gph_lds.sv[GPH_IX((i), GPH_CAP_N)].age)
+#define setSVAGE(i, v) (gph_lds.sv[GPH_IX((i), GPH_CAP_N)].age = (v))
+#define EVT(e) (gph_lds.ev[GPH_IX((e), GPH_CAP_E)].time)
+#define setEVT(e, v) (gph_lds.ev[GPH_IX((e), GPH_CAP_E)].time = (v))
+#define MAGE(m) gf64(&GphLds::mig_age, GPH_IX((m), GPH_MAX_MIGS))
+#define setMAGE(m, v) sf64(&GphLds::mig_age, GPH_IX((m), GPH_MAX_MIGS), (v))
+#define COALS(p) gf64(&GphLds::coal, GPH_IX((p), GPH_CAP_K))
+#define setCOALS(p, v) sf64(&GphLds::coal, GPH_IX((p), GPH_CAP_K), (v))
+#define MIGST(b) gf64(&GphLds::migst, GPH_IX((b), GPH_CAP_B))
+#define setMIGST(b, v) sf64(&GphLds::migst, GPH_IX((b), GPH_CAP_B), (v))
+#define RBAGE(i) gf64(&GphLds::rb_age, GPH_IX((i), GPH_CAP_RB))
+#define setRBAGE(i, v) sf64(&GphLds::rb_age, GPH_IX((i), GPH_CAP_RB), (v))
 #define FS(k) gf64(&GphLds::fscal, (k))
 #define setFS(k, v) sf64(&GphLds::fscal, (k), (v))
-#define FATH(i) RFL((int)gph_lds.nd[i].father)
-#define setFATH(i, v) (gph_lds.nd[i].father = (int16_t)(v))
-#define LEFT(i) RFL((int)gph_lds.nd[i].left)
-#define setLEFT(i, v) (gph_lds.nd[i].left = (int16_t)(v))
-#define RGHT(i) RFL((int)gph_lds.nd[i].right)
-#define setRGHT(i, v) (gph_lds.nd[i].right = (int16_t)(v))
-#define NPOP(i) RFL((int)gph_lds.nd[i].npop)
-#define setNPOP(i, v) (gph_lds.nd[i].npop = (int16_t)(v))
-#define NEV(i) gi16(&GphLds::nev, (i))
-#define setNEV(i, v) si16(&GphLds::nev, (i), (v))
-#define SVF(i) RFL((int)gph_lds.sv[i].father)
-#define SVL(i) RFL((int)gph_lds.sv[i].left)
-#define SVR(i) RFL((int)gph_lds.sv[i].right)
-#define ENEXT(e) RFL((int)gph_lds.ev[e].next)
-#define setENEXT(e, v) (gph_lds.ev[e].next = (int16_t)(v))
-#define EPREV(e) RFL((int)gph_lds.ev[e].prev)
-#define setEPREV(e, v) (gph_lds.ev[e].prev = (int16_t)(v))
-#define ENODE(e) RFL((int)gph_lds.ev[e].node)
-#define setENODE(e, v) (gph_lds.ev[e].node = (int16_t)(v))
-#define ENLIN(e) RFL((int)gph_lds.ev[e].nlin)
-#define setENLIN(e, v) (gph_lds.ev[e].nlin = (uint8_t)(v))
-#define ETYPE(e) RFL((int)gph_lds.ev[e].type)
-#define setETYPE(e, v) (gph_lds.ev[e].type = (uint8_t)(v))
-#define FIRSTEV(p) gi16(&GphLds::first, (p))
-#define setFIRSTEV(p, v) si16(&GphLds::first, (p), (v))
-#define MG(m, f) gi16(&GphLds::mig_i, (m) * MG_COUNT + (f))
-#define setMG(m, f, v) si16(&GphLds::mig_i, (m) * MG_COUNT + (f), (v))
-#define LIVING(i) gi16(&GphLds::living, (i))
-#define setLIVING(i, v) si16(&GphLds::living, (i), (v))
-#define NCOAL(p) gi16(&GphLds::ncoal, (p))
-#define setNCOAL(p, v) si16(&GphLds::ncoal, (p), (v))
-#define NMIGB(b) gi16(&GphLds::nmig, (b))
-#define setNMIGB(b, v) si16(&GphLds::nmig, (b), (v))
-#define RBI(k, i) gi16(&GphLds::rb_i, (k) * GPH_CAP_RB + (i))
-#define setRBI(k, i, v) si16(&GphLds::rb_i, (k) * GPH_CAP_RB + (i), (v))
+#define FATH(i) RFL((int)gph_lds.nd[GPH_IX((i), GPH_CAP_N)].father)
+#define setFATH(i, v) (gph_lds.nd[GPH_IX((i), GPH_CAP_N)].father = (int16_t)(v))
+#define LEFT(i) RFL((int)gph_lds.nd[GPH_IX((i), GPH_CAP_N)].left)
+#define setLEFT(i, v) (gph_lds.nd[GPH_IX((i), GPH_CAP_N)].left = (int16_t)(v))
+#define RGHT(i) RFL((int)gph_lds.nd[GPH_IX((i), GPH_CAP_N)].right)
+#define setRGHT(i, v) (gph_lds.nd[GPH_IX((i), GPH_CAP_N)].right = (int16_t)(v))
+#define NPOP(i) RFL((int)gph_lds.nd[GPH_IX((i), GPH_CAP_N)].npop)
+#define setNPOP(i, v) (gph_lds.nd[GPH_IX((i), GPH_CAP_N)].npop = (int16_t)(v))
+#define NEV(i) gi16(&GphLds::nev, GPH_IX((i), GPH_CAP_N))
+#define setNEV(i, v) si16(&GphLds::nev, GPH_IX((i), GPH_CAP_N), (v))
+#define SVF(i) RFL((int)gph_lds.sv[GPH_IX((i), GPH_CAP_N)].father)
+#define SVL(i) RFL((int)gph_lds.sv[GPH_IX((i), GPH_CAP_N)].left)
+#define SVR(i) RFL((int)gph_lds.sv[GPH_IX((i), GPH_CAP_N)].right)
+#define ENEXT(e) RFL((int)gph_lds.ev[GPH_IX((e), GPH_CAP_E)].next)
+#define setENEXT(e, v) (gph_lds.ev[GPH_IX((e), GPH_CAP_E)].next = (int16_t)(v))
+#define EPREV(e) RFL((int)gph_lds.ev[GPH_IX((e), GPH_CAP_E)].prev)
+#define setEPREV(e, v) (gph_lds.ev[GPH_IX((e), GPH_CAP_E)].prev = (int16_t)(v))
+#define ENODE(e) RFL((int)gph_lds.ev[GPH_IX((e), GPH_CAP_E)].node)
+#define setENODE(e, v) (gph_lds.ev[GPH_IX((e), GPH_CAP_E)].node = (int16_t)(v))
+#define ENLIN(e) RFL((int)gph_lds.ev[GPH_IX((e), GPH_CAP_E)].nlin)
+#define setENLIN(e, v) (gph_lds.ev[GPH_IX((e), GPH_CAP_E)].nlin = (uint8_t)(v))
+#define ETYPE(e) RFL((int)gph_lds.ev[GPH_IX((e), GPH_CAP_E)].type)
+#define setETYPE(e, v) (gph_lds.ev[GPH_IX((e), GPH_CAP_E)].type = (uint8_t)(v))
+#define FIRSTEV(p) gi16(&GphLds::first, GPH_IX((p), GPH_CAP_K))
+#define setFIRSTEV(p, v) si16(&GphLds::first, GPH_IX((p), GPH_CAP_K), (v))
+#define MG(m, f) gi16(&GphLds::mig_i, GPH_IX((m), GPH_MAX_MIGS) * MG_COUNT + (f))
+#define setMG(m, f, v) si16(&GphLds::mig_i, GPH_IX((m), GPH_MAX_MIGS) * MG_COUNT + (f), (v))
+#define LIVING(i) gi16(&GphLds::living, GPH_IX((i), GPH_MAX_MIGS))
+#define setLIVING(i, v) si16(&GphLds::living, GPH_IX((i), GPH_MAX_MIGS), (v))
+#define NCOAL(p) gi16(&GphLds::ncoal, GPH_IX((p), GPH_CAP_K))
+#define setNCOAL(p, v) si16(&GphLds::ncoal, GPH_IX((p), GPH_CAP_K), (v))
+#define NMIGB(b) gi16(&GphLds::nmig, GPH_IX((b), GPH_CAP_B))
+#define setNMIGB(b, v) si16(&GphLds::nmig, GPH_IX((b), GPH_CAP_B), (v))
+#define RBI(k, i) gi16(&GphLds::rb_i, (k) * GPH_CAP_RB + GPH_IX((i), GPH_CAP_RB))
+#define setRBI(k, i, v) si16(&GphLds::rb_i, (k) * GPH_CAP_RB + GPH_IX((i), GPH_CAP_RB), (v))
 #define ISC(k) GPH_PADGET(k)
 #define setISC(k, v) GPH_PADSET((k), (v))
 #define CBIT(i) ((int)ns_has(NS_GET(IS_CBIT0), (i)))
 // scratch
-#define DEV(inst, i) RFL((int)gph_lds.s_dev[inst][i])
-#define setDEV(inst, i, v) (gph_lds.s_dev[inst][i] = (gph_evid)(v))
-#define DCOAL(inst, i) gf64(&GphLds::s_dcoal, (inst), (i))
-#define setDCOAL(inst, i, v) sf64(&GphLds::s_dcoal, (inst), (i), (v))
-#define DMIG(inst, i) gf64(&GphLds::s_dmig, (inst), (i))
-#define setDMIG(inst, i, v) sf64(&GphLds::s_dmig, (inst), (i), (v))
-#define DPOPS(inst, i) gi16(&GphLds::s_dpops, (inst), (i))
-#define setDPOPS(inst, i, v) si16(&GphLds::s_dpops, (inst), (i), (v))
-#define DBANDS(inst, i) gi16(&GphLds::s_dbands, (inst), (i))
-#define setDBANDS(inst, i, v) si16(&GphLds::s_dbands, (inst), (i), (v))
+#define DEV(inst, i) RFL((int)gph_lds.s_dev[inst][GPH_IX((i), GPH_CAP_E)])
+#define setDEV(inst, i, v) (gph_lds.s_dev[inst][GPH_IX((i), GPH_CAP_E)] = (gph_evid)(v))
+#define DCOAL(inst, i) gf64(&GphLds::s_dcoal, (inst), GPH_IX((i), GPH_CAP_K))
+#define setDCOAL(inst, i, v) sf64(&GphLds::s_dcoal, (inst), GPH_IX((i), GPH_CAP_K), (v))
+#define DMIG(inst, i) gf64(&GphLds::s_dmig, (inst), GPH_IX((i), GPH_CAP_B))
+#define setDMIG(inst, i, v) sf64(&GphLds::s_dmig, (inst), GPH_IX((i), GPH_CAP_B), (v))
+#define DPOPS(inst, i) gi16(&GphLds::s_dpops, (inst), GPH_IX((i), GPH_CAP_K))
+#define setDPOPS(inst, i, v) si16(&GphLds::s_dpops, (inst), GPH_IX((i), GPH_CAP_K), (v))
+#define DBANDS(inst, i) gi16(&GphLds::s_dbands, (inst), GPH_IX((i), GPH_CAP_B))
+#define setDBANDS(inst, i, v) si16(&GphLds::s_dbands, (inst), GPH_IX((i), GPH_CAP_B), (v))
 #define DI(inst, k) RFL(gph_lds.s_di[inst][k])
 #define setDI(inst, k, v) (gph_lds.s_di[inst][k] = (v))
 #define SPRI(k) GPH_PADGET(IS_COUNT + CN_COUNT + (k))
 #define setSPRI(k, v) GPH_PADSET(IS_COUNT + CN_COUNT + (k), (v))
-#define SPRA(k, i) gi16(&GphLds::s_spri16, (k) * GPH_MAX_MIGS + (i))
-#define setSPRA(k, i, v) si16(&GphLds::s_spri16, (k) * GPH_MAX_MIGS + (i), (v))
-#define SPRAGE(i) gf64(&GphLds::s_sprf, (i))
-#define setSPRAGE(i, v) sf64(&GphLds::s_sprf, (i), (v))
+#define SPRA(k, i) gi16(&GphLds::s_spri16, (k) * GPH_MAX_MIGS + GPH_IX((i), GPH_MAX_MIGS))
+#define setSPRA(k, i, v) si16(&GphLds::s_spri16, (k) * GPH_MAX_MIGS + GPH_IX((i), GPH_MAX_MIGS), (v))
+#define SPRAGE(i) gf64(&GphLds::s_sprf, GPH_IX((i), GPH_MAX_MIGS + 2))
+#define setSPRAGE(i, v) sf64(&GphLds::s_sprf, GPH_IX((i), GPH_MAX_MIGS + 2), (v))
 #define SPRLN(r) gf64(&GphLds::s_sprf, GPH_MAX_MIGS + (r))
 #define setSPRLN(r, v) sf64(&GphLds::s_sprf, GPH_MAX_MIGS + (r), (v))
 #define CNT(k) GPH_PADGET(IS_COUNT + (k))
@@ -201,7 +203,7 @@ struct GphNodeS { double age; int father, left, right, npop; };
 GPH_DEVHOT GphNodeS ld_node(int node)
 {
   GphNodeS r;
-  const gph_w4 w = gph_ld16(&gph_lds.nd[node]);
+  const gph_w4 w = gph_ld16(&gph_lds.nd[GPH_IX(node, GPH_CAP_N)]);
   union { double d; uint32_t u[2]; } t;
   t.u[0] = w.x; t.u[1] = w.y;
   const int w2 = RFL((int)w.z), w3 = RFL((int)w.w);
@@ -217,7 +219,7 @@ struct GphEvS { double time; int next, prev, node, nlin, type; };
 GPH_DEVHOT GphEvS ld_ev(int ev)
 {
   GphEvS r;
-  const gph_w4 w = gph_ld16(&gph_lds.ev[ev]);
+  const gph_w4 w = gph_ld16(&gph_lds.ev[GPH_IX(ev, GPH_CAP_E)]);
   union { double d; uint32_t u[2]; } t;
   t.u[0] = w.x; t.u[1] = w.y;
   const int w2 = RFL((int)w.z), w3 = RFL((int)w.w);
@@ -944,6 +946,11 @@ GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo,
   const double qr = 1 - 4.0 * pr;
   const int lane = GPH_LANE;
   const bool act = lane < P;
+#ifdef GPH_BOUNDS
+  /* the three arrays of the step inside the locus's [2][n-1][P][4] doubles (checked build only) */
+  /* (a LEAF child has no array: its offset is whatever the caller's lane arithmetic gave and is never used) */
+  { const int ext_ = 2 * (g_lay.n - 1) * P * 4 - 4 * P + 1; po = GPH_IX(po, ext_); if (l >= g_lay.n) lo = GPH_IX(lo, ext_); if (r >= g_lay.n) ro = GPH_IX(ro, ext_); }
+#endif
   DP pc = cb + po;
   /* a child recomputed earlier in this evaluation is re-read after its stores: memory operations of one
    * wavefront are performed in order, only the compiler must not reorder them (no instruction) */

@@ -272,10 +272,18 @@ static int run_control_file(const char *ctl, const char *ctl2, int32_t device, i
     if (verbose) printf("(%.2f s, %.3f iterations/s)\n", sec, (info.burnin + info.numSamples) / (sec > 0 ? sec : 1));
   }
   fclose(trace);
+  /* a CHECKED build of the library (-DGPH_BOUNDS, tests only) says here whether an index left its array during the run */
+  int32_t oob_where = 0, oob_checked = 0;
+  (void)gph_engine_debug_oob(E, &oob_where, &oob_checked);
   gph_mcmc_destroy(M);
   gph_engine_destroy(E);
   gph_loci_free(LC);
   gph_control_free(C);
+  if (oob_checked && oob_where != 0) {
+    fprintf(stderr, "gphocs_hip: checked build: an index left its array at %d (source line + 100000 x file: 1 gph_locus.h, 2 gph_kernels.h; "
+                    "8000xx / 9000xx: typed accessors of the image / the dynamic LDS)\n", (int)oob_where);
+    return GPH_EKERNEL;
+  }
   return GPH_OK;
 }
 

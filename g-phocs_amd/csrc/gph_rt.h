@@ -75,6 +75,28 @@ typedef __attribute__((address_space(4))) const GphTauFin gph_cfin;
 #define GPH_G ((gph_cglobal *)(((gph_ckargs *)__builtin_amdgcn_kernarg_segment_ptr())->G))
 #endif
 
+// ---- GPH_BOUNDS (a CHECKED build: tests only, libgphocs_hip_chk.so and the sanitizer host builds): every index the per-locus code
+// puts into an array of the LDS image, into the dynamic LDS or into the locus's conditional arrays is compared with the array's
+// extent; the first violation leaves its source line (+ 100000 x file: 1 gph_locus.h, 2 gph_kernels.h; 900000 + k: the typed
+// accessors of the dynamic part) in a device word the host reads back (gph_engine_debug_oob), and the access goes to element 0
+// instead.  What AddressSanitizer does for the host forms, for the DEVICE forms on the MI355X (no GPU sanitizer on this pool).
+// The product build compiles GPH_IX(i, n) to i.
+#ifdef GPH_BOUNDS
+#ifdef GPH_HOSTEMU
+extern int gph_oob_word;
+inline int gph_ix_(int i, int n, int where) { if ((unsigned)i >= (unsigned)n) { if (gph_oob_word == 0) gph_oob_word = where; return 0; } return i; }
+#else
+__device__ int gph_oob_word;
+__device__ inline int gph_ix_(int i, int n, int where) { if ((unsigned)i >= (unsigned)n) { atomicCAS(&gph_oob_word, 0, where); return 0; } return i; }
+#endif
+#define GPH_IX(i, n) gph_ix_((i), (n), __LINE__ + 100000 * GPH_FILE_ID)
+#define GPH_IXW(i, n, w) gph_ix_((i), (n), (w))
+#else
+#define GPH_IX(i, n) (i)
+#define GPH_IXW(i, n, w) (i)
+#endif
+#define GPH_FILE_ID 0
+
 #ifdef GPH_HOSTEMU
 #define GPH_GLB
 #else
@@ -272,23 +294,30 @@ typedef GPH_LDS char lchar;
 // static-image accessors: `m` is a pointer to an array member of GphLds; after inlining the
 // address is a compile-time constant + index.  Integer loads that steer control flow are
 // made wave-uniform (v_readfirstlane) so that branches are scalar.
-template <class T, int NN> GPH_DEV double gf64(T (GphLds::*m)[NN], int i) { return (gph_lds.*m)[i]; }
-template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[NN], int i, double v) { (gph_lds.*m)[i] = v; }
-template <class T, int NN> GPH_DEV int gi16(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[i]); }
-template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[i] = (T)v; }
-template <class T, int NN> GPH_DEV int gi32(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[i]); }
-template <class T, int NN> GPH_DEV void si32(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[i] = (T)v; }
-template <class T, int NN> GPH_DEV int gu8(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[i]); }
-template <class T, int NN> GPH_DEV void su8(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[i] = (T)v; }
-template <class T, int NN> GPH_DEV int gu8v(T (GphLds::*m)[NN], int i) { return (gph_lds.*m)[i]; }
+template <class T, int NN> GPH_DEV double gf64(T (GphLds::*m)[NN], int i) { return (gph_lds.*m)[GPH_IXW(i, NN, 800001)]; }
+template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[NN], int i, double v) { (gph_lds.*m)[GPH_IXW(i, NN, 800002)] = v; }
+template <class T, int NN> GPH_DEV int gi16(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[GPH_IXW(i, NN, 800003)]); }
+template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[GPH_IXW(i, NN, 800004)] = (T)v; }
+template <class T, int NN> GPH_DEV int gi32(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[GPH_IXW(i, NN, 800005)]); }
+template <class T, int NN> GPH_DEV void si32(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[GPH_IXW(i, NN, 800006)] = (T)v; }
+template <class T, int NN> GPH_DEV int gu8(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[GPH_IXW(i, NN, 800007)]); }
+template <class T, int NN> GPH_DEV void su8(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[GPH_IXW(i, NN, 800008)] = (T)v; }
+template <class T, int NN> GPH_DEV int gu8v(T (GphLds::*m)[NN], int i) { return (gph_lds.*m)[GPH_IXW(i, NN, 800009)]; }
 // two-dimensional scratch arrays [2][..] (instance 0/1 of the pending stat deltas)
-template <class T, int NN> GPH_DEV double gf64(T (GphLds::*m)[2][NN], int k, int i) { return (gph_lds.*m)[k][i]; }
-template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[2][NN], int k, int i, double v) { (gph_lds.*m)[k][i] = v; }
-template <class T, int NN> GPH_DEV int gi16(T (GphLds::*m)[2][NN], int k, int i) { return RFL((gph_lds.*m)[k][i]); }
-template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[2][NN], int k, int i, int v) { (gph_lds.*m)[k][i] = (T)v; }
+template <class T, int NN> GPH_DEV double gf64(T (GphLds::*m)[2][NN], int k, int i) { return (gph_lds.*m)[GPH_IXW(k, 2, 800010)][GPH_IXW(i, NN, 800010)]; }
+template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[2][NN], int k, int i, double v) { (gph_lds.*m)[GPH_IXW(k, 2, 800011)][GPH_IXW(i, NN, 800011)] = v; }
+template <class T, int NN> GPH_DEV int gi16(T (GphLds::*m)[2][NN], int k, int i) { return RFL((gph_lds.*m)[GPH_IXW(k, 2, 800012)][GPH_IXW(i, NN, 800012)]); }
+template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[2][NN], int k, int i, int v) { (gph_lds.*m)[GPH_IXW(k, 2, 800013)][GPH_IXW(i, NN, 800013)] = (T)v; }
 // dynamic-part accessors (byte offset GPH_Q_* of the locus' sequence block): lane-varying, pruning only
+// (checked build: the byte range of the access against the dynamic LDS of this launch, g_lay.dyn_bytes)
+#define GPH_DYN(off, i, sz, w) GPH_IXW(((off) + (i) * (sz)) / (sz), (g_lay.dyn_bytes > 0 ? g_lay.dyn_bytes : 1 << 30) / (sz), 900000 + (w)) * (sz)
+#ifdef GPH_BOUNDS
+GPH_DEV double gf64(int off, int i) { return *(lf64 *)(GPH_SMB + GPH_DYN(off, i, 8, 1)); }
+GPH_DEV void sf64(int off, int i, double v) { *(lf64 *)(GPH_SMB + GPH_DYN(off, i, 8, 2)) = v; }
+#else
 GPH_DEV double gf64(int off, int i) { return ((lf64 *)(GPH_SMB + off))[i]; }
 GPH_DEV void sf64(int off, int i, double v) { ((lf64 *)(GPH_SMB + off))[i] = v; }
+#endif
 GPH_DEV int gi16(int off, int i) { return RFL(((li16 *)(GPH_SMB + off))[i]); }
 GPH_DEV void si16(int off, int i, int v) { ((li16 *)(GPH_SMB + off))[i] = (int16_t)v; }
 GPH_DEV int gi32(int off, int i) { return RFL(((li32 *)(GPH_SMB + off))[i]); }
@@ -296,8 +325,13 @@ GPH_DEV void si32(int off, int i, int v) { ((li32 *)(GPH_SMB + off))[i] = v; }
 GPH_DEV int gu8(int off, int i) { return RFL(((lu8 *)(GPH_SMB + off))[i]); }
 GPH_DEV void su8(int off, int i, int v) { ((lu8 *)(GPH_SMB + off))[i] = (uint8_t)v; }
 // lane-varying byte/int loads (no readfirstlane): pruning only
+#ifdef GPH_BOUNDS
+GPH_DEV int gu8v(int off, int i) { return *(lu8 *)(GPH_SMB + GPH_DYN(off, i, 1, 3)); }
+GPH_DEV int gu16v(int off, int i) { return *(GPH_LDS uint16_t *)(GPH_SMB + GPH_DYN(off, i, 2, 4)); }
+#else
 GPH_DEV int gu8v(int off, int i) { return ((lu8 *)(GPH_SMB + off))[i]; }
 GPH_DEV int gu16v(int off, int i) { return ((GPH_LDS uint16_t *)(GPH_SMB + off))[i]; }
+#endif
 GPH_DEV int gu16(int off, int i) { return RFL(((GPH_LDS uint16_t *)(GPH_SMB + off))[i]); }
 GPH_DEV int gi32v(int off, int i) { return ((li32 *)(GPH_SMB + off))[i]; }
 // ---- the sequence block seen by the GENERIC (pattern, base) code paths (loci with more than GPH_WAVE phased patterns, and the

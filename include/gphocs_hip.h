@@ -194,6 +194,11 @@ int gph_engine_last_error(gph_engine *e, int64_t *locus, int32_t *code);
  * (with several ranks every rank calls it: it completes a deferred synchronizeEvents pass first, which is a collective;
  * GPH_EARG on the ranks that do not hold the locus) */
 int gph_engine_debug_break_chain(gph_engine *e, int64_t global_locus, int32_t pop);
+/* tests only: libgphocs_hip_chk.so is the same library compiled with -DGPH_BOUNDS -- every index the per-locus device code puts
+ * into an array of a locus's LDS image, into its dynamic LDS or into its conditional arrays is compared with the array's extent.
+ * *checked = 1 in such a build (0 in every product library); *where = 0, or the first violation's source line + 100000 x file
+ * (read and cleared).  gph_engine_unit op 8 is the check's self-test: it reads node record `arg`. */
+int gph_engine_debug_oob(gph_engine *e, int32_t *where, int32_t *checked);
 /* debug / parity: canonical text dump of every local locus (same format as the oracle's) */
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withConditionals, int32_t append);
 /* debug / parity, kernel level: single calls of the per-locus functions with deterministic arguments on the current

@@ -69,7 +69,9 @@ def _build(out, srcs, sanitize, big, mid=False, two_walks=False):
            "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
            "-x", "c++"] + srcs + ["-lrt", "-o", tmp]
     if sanitize:
-        cmd[1:1] = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+        # + the index checks of the checked build (gph_rt.h: GPH_BOUNDS): an index that stays inside the LDS IMAGE but leaves its
+        # array is invisible to AddressSanitizer (the image is one struct)
+        cmd[1:1] = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-DGPH_BOUNDS"]
     try:
         subprocess.run(cmd, check=True)
         os.replace(tmp, out)
@@ -92,7 +94,9 @@ def run(pack_path, iters, trace, state=None, state_iter=None, with_cond=True, li
         if state and state_iter == it:
             s.dump_state(state, with_cond)
     s.set_record_file(None)
+    oob = s.debug_oob()
     s.close()
+    assert oob[0] == 0, f"checked build: index out of range at {oob[0]} (line + 100000 x file: 1 gph_locus.h, 2 gph_kernels.h)"
 
 
 if __name__ == "__main__":

@@ -554,6 +554,56 @@ def test_bench_two_real_rccl_ranks():
     assert c["accept_counts_timed"] == one["config"]["accept_counts_timed"]
 
 
+@pytest.mark.parametrize("name", ["m3", "a7", "x8", "j1", "j2", "v8", "bigp", "stress"])
+def test_checked_build_finds_no_index_out_of_range(G, oracle_cli, tmp_path, name):
+    """round 6 ("the sanitizers in the container never see the device forms"; no GPU sanitizer on this
+    pool): libgphocs_hip_chk.so is the library compiled with -DGPH_BOUNDS -- every index the DEVICE forms of the per-locus code put
+    into an array of the locus's LDS image, into its dynamic LDS or into its conditional arrays is compared with the extent of
+    that array; the first violation would leave its source line behind.  The goldens (migration, conflicts, sample ages, VAR
+    rates, 32 leaves / 16 bands, the non-caterpillar shapes, pattern-rich loci on the generic paths) run through it with the
+    golden's results and NO violation."""
+    chk = os.path.join(REPO, "g-phocs_amd", G.CHECKED_LIB)
+    assert os.path.exists(chk)
+    lib = G.load_library(chk)
+    assert lib.gph_build_id().decode().startswith("chk-")
+    pack = os.path.join(GOLDEN, name + ".gpk")
+    iters = CASES.get(name, 10)
+    s = G.Sampler(G.Pack.load(pack), lib=lib)
+    p = str(tmp_path / "chk.rec")
+    s.set_record_file(p)
+    s.initialize()
+    for it in range(iters):
+        s.iteration(it)
+    s.dump_state(p + ".state", True)
+    s.set_record_file(None)
+    where, checked = s.debug_oob()
+    s.close()
+    assert checked == 1, "not a checked build"
+    assert where == 0, f"index out of range at {where} (source line + 100000 x file: 1 gph_locus.h, 2 gph_kernels.h)"
+    if name in CASES:
+        compare_records(p, os.path.join(GOLDEN, name + ".rtrace"))
+        compare_states(p + ".state", os.path.join(GOLDEN, name + ".state"))
+    else:
+        ot, os_ = tmp_path / "o.trace", tmp_path / "o.state"
+        subprocess.run([oracle_cli, "run", pack, str(iters), str(ot), str(os_), str(iters - 1), "1"], check=True, timeout=600)
+        compare_records(p, ot)
+        compare_states(p + ".state", os_)
+    if name == "m3":
+        # the check itself: one access one past the capacity of the node records (unit op 8) must be reported with its source line
+        s = G.Sampler(G.Pack.load(pack), lib=lib)
+        s.initialize()
+        s.unit(8, 3)
+        assert s.debug_oob() == (0, 1)
+        s.unit(8, 2 * 32 - 1)
+        where, _ = s.debug_oob()
+        s.close()
+        assert 200000 < where < 300000, where          # a line of gph_kernels.h (kb_unit)
+    # a product library is not a checked build
+    s2 = G.Sampler(G.Pack.load(os.path.join(GOLDEN, "g1.gpk")))
+    assert s2.debug_oob() == (0, 0)
+    s2.close()
+
+
 @pytest.mark.parametrize("name", ["m3", "a7", "g2", "v8"])
 def test_plain_build_parity(G, tmp_path, name):
     """the control build WITHOUT the backend switches the hot path is tuned with (-disable-machine-licm,

@@ -104,11 +104,13 @@ def test_sampler_over_native_shm_comm(hostemu, tmp_path, name, iters):
     compare_records(out + ".0", str(tmp_path / "g"))
 
 
-@pytest.mark.parametrize("name,ranks", [("m3", 1), ("a7", 2), ("v8", 1), ("x8", 1), ("y9@mid", 1), ("m3@mid", 1)])
+@pytest.mark.parametrize("name,ranks", [("m3", 1), ("a7", 2), ("v8", 1), ("x8", 1), ("y9@mid", 1), ("m3@mid", 1), ("j1", 1), ("j2", 2), ("j3@mid", 1)])
 def test_engine_sources_under_asan_ubsan(hostemu, tmp_path, name, ranks):
     """the engine sources (host build) under AddressSanitizer + UndefinedBehaviorSanitizer, whole program through the
     launcher: no report (either aborts the run) and the reference's trace file.  The GPU pool offers no sanitizer, so
-    this is where out-of-bounds indices into the locus image, the chain state and the reduced rows would show."""
+    this is where out-of-bounds indices into the locus image, the chain state and the reduced rows would show.  Round 6: the
+    sanitizer builds also carry the index checks of the checked build (-DGPH_BOUNDS: an index that leaves its ARRAY but stays inside
+    the image is invisible to AddressSanitizer); the program fails when one fired."""
     import run_hostemu
     mid = name.endswith("@mid")        # the variant-h configuration (64 / 39 / 16: two-word node sets, fused walk): ADVICE round 4
     name = name.split("@")[0]

@@ -17,8 +17,9 @@ pick() { local o=""; for c in "$@"; do if have "$c"; then o="$o $c"; fi; done; e
 SETA=$(pick TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum)
 SETB=$(pick TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum TCC_TAG_STALL_sum)
 SETC=$(pick TCC_BUSY_sum TCC_REQ_sum TCC_WRITEBACK_sum TCC_EA0_RD_UNCACHED_32B_sum)
-echo "sets: A=[$SETA] B=[$SETB] C=[$SETC]"
-for S in A B C; do
+SETD=$(pick GRBM_GUI_ACTIVE GRBM_COUNT)
+echo "sets: A=[$SETA] B=[$SETB] C=[$SETC] D=[$SETD]"
+for S in ${SETS:-A B C D}; do
   eval CS=\$SET$S
   [ -z "$CS" ] && continue
   for i in $(seq 1 $N); do

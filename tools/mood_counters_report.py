@@ -10,7 +10,7 @@ import numpy as np
 
 root = sys.argv[1]
 rows = []
-for d in sorted(glob.glob(os.path.join(root, "[ABC]*"))):
+for d in sorted(glob.glob(os.path.join(root, "[ABCD]*"))):
     if not os.path.isdir(d):
         continue
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -32,7 +32,7 @@ for k in ("k_tau_eval", "k_mix_eval", "k_sweep"):
     if not rk:
         continue
     print(f"## {k}: per process (under --pmc: dispatches are serialised and a little slower than in a plain run)")
-    for s in "ABC":
+    for s in "ABCD":
         rs = [r for r in rk if r["run"].startswith(s)]
         if not rs:
             continue
@@ -45,4 +45,7 @@ for k in ("k_tau_eval", "k_mix_eval", "k_sweep"):
             for n in names:
                 v = np.array([r[n] for r in rs])
                 cc = np.corrcoef(d, v)[0, 1] if v.std() > 0 else float("nan")
+                if n == "GRBM_GUI_ACTIVE":      # summed over the 8 XCDs: the effective shader clock of the dispatch (MI355X_MICROARCH.md, DVFS)
+                    for r in sorted(rs, key=lambda r: r["dur_us"]):
+                        print(f"   {r['run']}: effective clock {r[n] / 8 / r['dur_us'] / 1e3:.3f} GHz")
                 print(f"   corr(duration, {n}) = {cc:+.2f}   spread of the counter {100 * (v.max() - v.min()) / max(v.mean(), 1e-30):.2f} %   spread of the duration {100 * (d.max() - d.min()) / d.mean():.2f} %")
