@@ -15,6 +15,9 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
+#if defined(GPH_HOSTEMU) && defined(GPH_EMU64)
+#define GPH_EMU64_IMPL      /* this translation unit holds the micro-wave scheduler (gph_emu64.h; test builds only) */
+#endif
 #include "gph_kernels.h"
 #include "gph_global.h"
 #include "gph_comm.h"
@@ -2339,6 +2342,16 @@ int gph_engine_debug_oob(gph_engine *e, int32_t *where, int32_t *checked)
   return 0;
 #endif
 }
+
+#if defined(GPH_HOSTEMU) && defined(GPH_EMU64)
+// tests only (the wave64 host build): micro-waves started and rendezvous passed by the calling thread so far
+int gph_debug_emu64_stats(long long *waves, long long *rendezvous)
+{
+  if (waves) *waves = gph_emu::tw.waves_total;
+  if (rendezvous) *rendezvous = gph_emu::tw.rendezvous_total;
+  return gph_emu::g_enabled;
+}
+#endif
 
 // canonical text dump (same format as oracle/gphocs_oracle_io.c go_dump_state's per-locus part)
 int gph_engine_dump_loci(gph_engine *e, const char *path, int32_t withCond, int32_t append)

@@ -716,7 +716,14 @@ GPH_DEV void prune_node(int node)
 #else
 #define GPH_LANE_NODES 0
 #endif
-#ifndef GPH_HOSTEMU
+// GPH_DEVFORMS: the device forms of the lane-parallel functions are compiled -- every device build, and the host build with the
+// 64-lane micro-wave (gph_emu64.h), where they run next to the one-lane host forms
+#if !defined(GPH_HOSTEMU) || defined(GPH_EMU64)
+#define GPH_DEVFORMS 1
+#else
+#define GPH_DEVFORMS 0
+#endif
+#if GPH_DEVFORMS
 // the next lane's value (lane i <- lane i + 1, the last lane gets 0): two v_mov_b32_dpp wave_shl:1 -- VALU register moves,
 // against two ds_bpermute_b32 (an LDS-pipe instruction and a crossbar round trip each; tools/probe/dpp_probe.cpp has the
 // direction check on gfx950)
@@ -774,7 +781,7 @@ GPH_DEVHOT double ordered_sum64(double term, int P)
 // of the dynamic LDS behind the sequence block, for the loci that have them inside the launch group's allocation -- the
 // host sizes that so that the terms do not cost a resident workgroup (g_lay.lds_sum, g_lay.dyn_bytes, gph_engine_load_loci).
 // Measured: -4 % vector instructions per sweep wavefront, -1.0 % sweep time.
-#if !defined(GPH_HOSTEMU)
+#if GPH_DEVFORMS
 GPH_DEVHOT double ordered_sum64_lds(double term, int P, int q_terms)
 {
   lf64 *t = (lf64 *)(GPH_SMB + q_terms);
@@ -807,6 +814,10 @@ GPH_DEVHOT double root_sum_generic(CP rc, int P, int q_phases, int q_count, int 
 {
   double lnl = 0.0;
 #ifdef GPH_HOSTEMU
+#ifdef GPH_EMU64
+  if (!gph_emu::in_wave())        /* (inside a micro-wave: the device form below) */
+#endif
+  {
   for (int p = 0; p < P; p++) {
     const int ph = GPH_PHASES(sq_u16v(SQ, q_phases, p));
     if (ph > 0) {
@@ -818,7 +829,10 @@ GPH_DEVHOT double root_sum_generic(CP rc, int P, int q_phases, int q_count, int 
   }
   for (int p = 0; p < P; p++)
     if (sq_u16v(SQ, q_phases, p) > 0) lnl += sq_f64(SQ, q_terms, p);
-#else
+  return lnl;
+  }
+#endif
+#if GPH_DEVFORMS
   (void)q_terms;
   for (int p0 = 0; p0 < P; p0 += GPH_WAVE) {
     const int p = p0 + GPH_LANE;
@@ -859,12 +873,16 @@ GPH_DEV void prune_node_r(int node, int l, int r, double pl, double pr, int cbn,
   GPH_WAVE_FENCE();
 }
 
-#ifndef GPH_HOSTEMU
+#if GPH_DEVFORMS
 // ---- lanes = patterns (P <= 64): one lane owns pattern `lane` and its 4 base entries.
 // The 4 conditionals a lane just produced stay in its registers (q0..q3): when the next node
 // processed is the parent (the usual case: a dirty path is a chain), that child is not re-read
 // from memory -- no store->load round trip on the critical path.
+#ifdef GPH_HOSTEMU
+struct alignas(16) gph_d2 { double x, y; };      /* (g++ has no ext_vector_type) */
+#else
 typedef double gph_d2 __attribute__((ext_vector_type(2)));
+#endif
 typedef GPH_GLB gph_d2 gdbl2;
 
 // factors of one child for the 4 bases of pattern `lane` (computeSubtreeConditionals_new,
@@ -978,8 +996,13 @@ GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo,
   }
 }
 
-#endif   /* !GPH_HOSTEMU */
-#if GPH_LANE_NODES
+#endif   /* GPH_DEVFORMS */
+#if GPH_LANE_NODES || defined(GPH_EMU64)
+#ifdef GPH_EMU64
+#define GPH_LIK_COMPUTE_LANES lik_compute_lanes      /* next to the host form; lik_compute() below dispatches */
+#else
+#define GPH_LIK_COMPUTE_LANES lik_compute
+#endif
 // computeLocusDataLikelihood, LocusDataLikelihood.c:426-483.  Device form: the genealogy
 // (father/left/right/age, one node per lane) and the dirty / current-buffer sets (64-bit
 // masks) are pulled into registers once; "which nodes must be recomputed" is a ballot
@@ -987,7 +1010,7 @@ GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo,
 // nodes are processed as soon as their recomputed children are done (any such order gives
 // bit-identical conditionals), copyNodeConditionals bookkeeping is applied to the masks and
 // written back once, and the per-pattern terms are added in pattern order through v_readlane.
-GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
+GPH_DEVHOT double GPH_LIK_COMPUTE_LANES(int useOld, bool warm = false)
 {
   const int n = g_lay.n, N = g_lay.N, lane = GPH_LANE;
   useOld = RFL(useOld);
@@ -1154,11 +1177,14 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
     prob += q2;
     prob += q3;
     prob = add_phases(prob, ph, q0, q1, q2, q3);
+    /* (the ballot sits in front of the branch: every lane takes part, the lanes without a term with `false` -- the mask the
+     * branch's active lanes alone would give; wave-uniform code around every cross-lane operation is what gph_emu64.h checks) */
+    const bool pow2_ = __ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0;
     if (ph > 0) {
       const int nc = 4 * ph;
       /* phase counts are powers of two upstream (2^hets): the division is an exact exponent shift */
       double avg;
-      if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
+      if (pow2_) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
       else avg = prob / nc;
       term = gph_log(avg) * GPH_PATCOUNT(q_count, lane);
     }
@@ -1173,12 +1199,18 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   STAMPB_END(4);
   return lnl;
 }
+#endif
+#if !GPH_LANE_NODES
+#ifdef GPH_EMU64
+#define GPH_LIK_COMPUTE_LIST lik_compute_list
 #else
+#define GPH_LIK_COMPUTE_LIST lik_compute
+#endif
 // computeLocusDataLikelihood, LocusDataLikelihood.c:426-483, with the recursion of
 // computeConditionalJC_new (:1559-1636) replaced by: mark the ancestors of every
 // dirty node, list the marked internal nodes parent-before-child, process the
 // list backwards.  Same set of recomputed nodes, children always before parents.
-GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
+GPH_DEVHOT double GPH_LIK_COMPUTE_LIST(int useOld, bool warm = false)
 {
   const int n = g_lay.n, N = g_lay.N;
   (void)warm;
@@ -1294,6 +1326,17 @@ GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
   return lnl;
 }
 
+#endif
+#ifdef GPH_EMU64
+// the host build with the micro-wave: the DEVICE form on 64 emulated lanes (gph_emu64.h) -- or, with GPH_EMU64=0 in the
+// environment, the one-lane list form: the two must agree bit for bit on every golden
+GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
+{
+  if (!gph_emu::enabled() || g_lay.N > gph_emu::W) return lik_compute_list(useOld, warm);
+  double r = 0.0;
+  gph_emu::run([&] { const double v = lik_compute_lanes(useOld, warm); if (GPH_LANE == 0) r = v; });
+  return r;
+}
 #endif
 
 // ---------------------------------------------------------------- stateless full evaluation
@@ -1569,7 +1612,18 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
 {
   int node, mig, pop1, num = 0, f;
   if (UNI(g_model.popAge[pop] > time + 0.0000001)) return 0;
-#if GPH_LANE_NODES
+#ifdef GPH_EMU64
+  /* the host build with the micro-wave: the lane-per-node form below on 64 emulated lanes (it recurses once: inside the wave) */
+  if (gph_emu::enabled() && g_lay.N <= gph_emu::W) {
+    int r = 0;
+    gph_emu::run([&] { const int v = edges_for_time_pop(time, pop, exc); if (GPH_LANE == 0) r = v; });
+    return r;
+  }
+#endif
+#if GPH_LANE_NODES || defined(GPH_EMU64)
+#ifdef GPH_EMU64
+  if (gph_emu::in_wave())
+#endif
   {
     const int lane = GPH_LANE;
     bool in = false;
@@ -1594,7 +1648,8 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
     GPH_SYNC();
     return num;
   }
-#elif !defined(GPH_HOSTEMU)
+#endif
+#if !GPH_LANE_NODES && !defined(GPH_HOSTEMU)
   /* the big-tree build on the device: the same membership test with a lane per node, 64 nodes a round; the candidates
    * of a round go behind those of the rounds before it (node order, as the reference lists them) */
   {
@@ -1623,7 +1678,8 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
     GPH_SYNC();
     return num;
   }
-#else
+#endif
+#ifdef GPH_HOSTEMU
   for (node = 0; node < g_lay.N; node++) {
     f = FATH(node);
     if (node == exc || UNI(AGE(node) > time) || (f >= 0 && UNI(AGE(f) <= time))) continue;

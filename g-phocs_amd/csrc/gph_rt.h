@@ -24,10 +24,28 @@
 #define GPH_DEVNI static
 #define GPH_DEVHOT inline
 #define GPH_LDS
+#ifdef GPH_EMU64
+// the host build with a 64-lane MICRO-WAVE for the device forms of the lane-parallel functions (gph_emu64.h): outside a
+// micro-wave everything below is the one-lane host build (lane 0 of 1, rendezvous = nothing)
+#include "gph_emu64.h"
+#define GPH_LANE (gph_emu::lane())
+#define GPH_NLANES (gph_emu::nlanes())
+#define GPH_SYNC() gph_emu::rendezvous(__LINE__)
+#define GPH_WAVE_FENCE() gph_emu::rendezvous(__LINE__)
+// a store to the LDS image through an accessor: everybody has computed its value | everybody has stored
+#define GPH_EMU_ST(k) gph_emu::rendezvous(800 + (k))
+// the device builtins the lane-parallel forms are written in
+#define __ballot(p) gph_emu::ballot((p), __LINE__)
+#define __builtin_amdgcn_readlane(v, l) gph_emu::readlane32((int)(v), (l), __LINE__)
+#define __builtin_amdgcn_ds_bpermute(a, v) gph_emu::bpermute((a), (int)(v), __LINE__)
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) (static_cast<void>(sizeof(char[(ctrl) == 0x130 ? 1 : -1])), gph_emu::dpp_wave_shl1((src), __LINE__))
+#else
 #define GPH_LANE 0
 #define GPH_NLANES 1
 #define GPH_SYNC() ((void)0)
 #define GPH_WAVE_FENCE() ((void)0)
+#define GPH_EMU_ST(k) ((void)0)
+#endif
 #define RFL(x) (x)
 extern thread_local char *gph_sm;
 extern thread_local GphLds gph_lds;
@@ -59,6 +77,7 @@ typedef const GphTauFin gph_cfin;
 // wavefront-scope fence emits no instruction).  Used in the pruning loop, where waiting for each
 // node's store to be acknowledged (what __syncthreads' workgroup fence does) cost ~25 % of lik_compute.
 #define GPH_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#define GPH_EMU_ST(k) ((void)0)
 #define RFL(x) __builtin_amdgcn_readfirstlane((int)(x))
 extern __shared__ __attribute__((aligned(16))) char gph_sm[];   // dynamic part: sequence block + per-pattern terms
 __shared__ GphLds gph_lds;   // static part: the locus image (gph_types.h); this header is included by one TU only
@@ -133,7 +152,13 @@ __device__ inline double gph_rfl64(double x)
 #define GPH_EACH1(k, n) if (const int k = GPH_LANE; k < (n))
 #endif
 // the value lane `i` holds of a per-lane variable (the host's single lane holds item i when it asks for it)
-#ifdef GPH_HOSTEMU
+#if defined(GPH_HOSTEMU) && defined(GPH_EMU64)
+#define GPH_LANEVAL32(v, i) (v)
+#define GPH_LANEVAL64(v, i) (v)
+#define gph_readlane64(v, l) gph_emu::readlane64((v), (l), __LINE__)
+#define gph_bcast64(v, l) gph_emu::readlane64((v), (l), __LINE__)
+#define gph_bcast32(v, l) gph_emu::readlane32((v), (l), __LINE__)
+#elif defined(GPH_HOSTEMU)
 #define GPH_LANEVAL32(v, i) (v)
 #define GPH_LANEVAL64(v, i) (v)
 #else
@@ -237,7 +262,11 @@ template <int NN> struct GphPad {
   void store(int32_t *dst, int n) const { for (int k = 0; k < n; k++) dst[k] = v[k]; }
 };
 #define GPH_PADGET(i) (r_pad.get(i))
+#ifdef GPH_EMU64
+#define GPH_PADSET(i, x) do { const int pv_ = (x); GPH_EMU_ST(1); r_pad.set((i), pv_); GPH_EMU_ST(2); } while (0)
+#else
 #define GPH_PADSET(i, x) (r_pad.set((i), (x)))
+#endif
 #else
 // (up to 64 scalars: one register; the 200-leaf build's node sets need more: scalars 64.. sit in a second register, which a
 // build that never indexes beyond 63 never materialises)
@@ -295,35 +324,35 @@ typedef GPH_LDS char lchar;
 // address is a compile-time constant + index.  Integer loads that steer control flow are
 // made wave-uniform (v_readfirstlane) so that branches are scalar.
 template <class T, int NN> GPH_DEV double gf64(T (GphLds::*m)[NN], int i) { return (gph_lds.*m)[GPH_IXW(i, NN, 800001)]; }
-template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[NN], int i, double v) { (gph_lds.*m)[GPH_IXW(i, NN, 800002)] = v; }
+template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[NN], int i, double v) { GPH_EMU_ST(3); (gph_lds.*m)[GPH_IXW(i, NN, 800002)] = v; GPH_EMU_ST(4); }
 template <class T, int NN> GPH_DEV int gi16(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[GPH_IXW(i, NN, 800003)]); }
-template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[GPH_IXW(i, NN, 800004)] = (T)v; }
+template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[NN], int i, int v) { GPH_EMU_ST(3); (gph_lds.*m)[GPH_IXW(i, NN, 800004)] = (T)v; GPH_EMU_ST(4); }
 template <class T, int NN> GPH_DEV int gi32(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[GPH_IXW(i, NN, 800005)]); }
-template <class T, int NN> GPH_DEV void si32(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[GPH_IXW(i, NN, 800006)] = (T)v; }
+template <class T, int NN> GPH_DEV void si32(T (GphLds::*m)[NN], int i, int v) { GPH_EMU_ST(3); (gph_lds.*m)[GPH_IXW(i, NN, 800006)] = (T)v; GPH_EMU_ST(4); }
 template <class T, int NN> GPH_DEV int gu8(T (GphLds::*m)[NN], int i) { return RFL((gph_lds.*m)[GPH_IXW(i, NN, 800007)]); }
-template <class T, int NN> GPH_DEV void su8(T (GphLds::*m)[NN], int i, int v) { (gph_lds.*m)[GPH_IXW(i, NN, 800008)] = (T)v; }
+template <class T, int NN> GPH_DEV void su8(T (GphLds::*m)[NN], int i, int v) { GPH_EMU_ST(3); (gph_lds.*m)[GPH_IXW(i, NN, 800008)] = (T)v; GPH_EMU_ST(4); }
 template <class T, int NN> GPH_DEV int gu8v(T (GphLds::*m)[NN], int i) { return (gph_lds.*m)[GPH_IXW(i, NN, 800009)]; }
 // two-dimensional scratch arrays [2][..] (instance 0/1 of the pending stat deltas)
 template <class T, int NN> GPH_DEV double gf64(T (GphLds::*m)[2][NN], int k, int i) { return (gph_lds.*m)[GPH_IXW(k, 2, 800010)][GPH_IXW(i, NN, 800010)]; }
-template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[2][NN], int k, int i, double v) { (gph_lds.*m)[GPH_IXW(k, 2, 800011)][GPH_IXW(i, NN, 800011)] = v; }
+template <class T, int NN> GPH_DEV void sf64(T (GphLds::*m)[2][NN], int k, int i, double v) { GPH_EMU_ST(3); (gph_lds.*m)[GPH_IXW(k, 2, 800011)][GPH_IXW(i, NN, 800011)] = v; GPH_EMU_ST(4); }
 template <class T, int NN> GPH_DEV int gi16(T (GphLds::*m)[2][NN], int k, int i) { return RFL((gph_lds.*m)[GPH_IXW(k, 2, 800012)][GPH_IXW(i, NN, 800012)]); }
-template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[2][NN], int k, int i, int v) { (gph_lds.*m)[GPH_IXW(k, 2, 800013)][GPH_IXW(i, NN, 800013)] = (T)v; }
+template <class T, int NN> GPH_DEV void si16(T (GphLds::*m)[2][NN], int k, int i, int v) { GPH_EMU_ST(3); (gph_lds.*m)[GPH_IXW(k, 2, 800013)][GPH_IXW(i, NN, 800013)] = (T)v; GPH_EMU_ST(4); }
 // dynamic-part accessors (byte offset GPH_Q_* of the locus' sequence block): lane-varying, pruning only
 // (checked build: the byte range of the access against the dynamic LDS of this launch, g_lay.dyn_bytes)
 #define GPH_DYN(off, i, sz, w) GPH_IXW(((off) + (i) * (sz)) / (sz), (g_lay.dyn_bytes > 0 ? g_lay.dyn_bytes : 1 << 30) / (sz), 900000 + (w)) * (sz)
 #ifdef GPH_BOUNDS
 GPH_DEV double gf64(int off, int i) { return *(lf64 *)(GPH_SMB + GPH_DYN(off, i, 8, 1)); }
-GPH_DEV void sf64(int off, int i, double v) { *(lf64 *)(GPH_SMB + GPH_DYN(off, i, 8, 2)) = v; }
+GPH_DEV void sf64(int off, int i, double v) { GPH_EMU_ST(5); *(lf64 *)(GPH_SMB + GPH_DYN(off, i, 8, 2)) = v; GPH_EMU_ST(6); }
 #else
 GPH_DEV double gf64(int off, int i) { return ((lf64 *)(GPH_SMB + off))[i]; }
-GPH_DEV void sf64(int off, int i, double v) { ((lf64 *)(GPH_SMB + off))[i] = v; }
+GPH_DEV void sf64(int off, int i, double v) { GPH_EMU_ST(5); ((lf64 *)(GPH_SMB + off))[i] = v; GPH_EMU_ST(6); }
 #endif
 GPH_DEV int gi16(int off, int i) { return RFL(((li16 *)(GPH_SMB + off))[i]); }
-GPH_DEV void si16(int off, int i, int v) { ((li16 *)(GPH_SMB + off))[i] = (int16_t)v; }
+GPH_DEV void si16(int off, int i, int v) { GPH_EMU_ST(5); ((li16 *)(GPH_SMB + off))[i] = (int16_t)v; GPH_EMU_ST(6); }
 GPH_DEV int gi32(int off, int i) { return RFL(((li32 *)(GPH_SMB + off))[i]); }
-GPH_DEV void si32(int off, int i, int v) { ((li32 *)(GPH_SMB + off))[i] = v; }
+GPH_DEV void si32(int off, int i, int v) { GPH_EMU_ST(5); ((li32 *)(GPH_SMB + off))[i] = v; GPH_EMU_ST(6); }
 GPH_DEV int gu8(int off, int i) { return RFL(((lu8 *)(GPH_SMB + off))[i]); }
-GPH_DEV void su8(int off, int i, int v) { ((lu8 *)(GPH_SMB + off))[i] = (uint8_t)v; }
+GPH_DEV void su8(int off, int i, int v) { GPH_EMU_ST(5); ((lu8 *)(GPH_SMB + off))[i] = (uint8_t)v; GPH_EMU_ST(6); }
 // lane-varying byte/int loads (no readfirstlane): pruning only
 #ifdef GPH_BOUNDS
 GPH_DEV int gu8v(int off, int i) { return *(lu8 *)(GPH_SMB + GPH_DYN(off, i, 1, 3)); }

@@ -13,7 +13,7 @@ import gphocs_amd as G  # noqa: E402
 HOSTEMU = os.path.join(REPO, "tests", "hostemu", "libgphocs_hostemu.so")
 
 
-def build_hostemu(sanitize=False, big=False, mid=False, two_walks=False):
+def build_hostemu(sanitize=False, big=False, mid=False, two_walks=False, wave64=False):
     """big: the reference's own caps 200 / 39 / 100 (library variant `n`: node sets of seven words, band lists in LDS) -- a
     separate host build, as the capacities are compile-time.  mid: 64 leaves / 39 populations / 16 bands, the configuration
     of library variants `g` and `h` (GPH_BIG_TREE with two-word node sets, the nibble band list, the fused trace_pair walk
@@ -24,6 +24,11 @@ def build_hostemu(sanitize=False, big=False, mid=False, two_walks=False):
     out = HOSTEMU.replace(".so", "_h.so") if big else HOSTEMU.replace(".so", "_mid.so") if mid else HOSTEMU
     if two_walks:      # -DGPH_TWO_WALKS: traceLineage(0) and traceLineage(1) as two separate walks (the many-band builds' form)
         out = out.replace(".so", "_2w.so")
+    if wave64:
+        # -DGPH_EMU64 (round 6): the DEVICE forms of lik_compute / prune_node_q / add_phases / ordered_sum64 / edges_for_time_pop on a
+        # 64-lane micro-wave of fibers (csrc/gph_emu64.h) inside the host build: what the sanitizers could not see before
+        assert not big and not mid, "the lane-per-node device forms exist up to 32 leaves"
+        out = out.replace(".so", "_w64.so")
     if sanitize:
         out = out.replace(".so", "_san.so")
 
@@ -50,7 +55,7 @@ def build_hostemu(sanitize=False, big=False, mid=False, two_walks=False):
         try:
             if fresh():
                 return out
-            r = _build(out, srcs, sanitize, big, mid, two_walks)
+            r = _build(out, srcs, sanitize, big, mid, two_walks, wave64)
             with open(side, "w") as f:
                 f.write(want + "\n")
             return r
@@ -58,13 +63,15 @@ def build_hostemu(sanitize=False, big=False, mid=False, two_walks=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build(out, srcs, sanitize, big, mid=False, two_walks=False):
+def _build(out, srcs, sanitize, big, mid=False, two_walks=False, wave64=False):
     # the engine's hard caps (library variant `x`): every golden fits, the image size does not matter on the host
     caps = ["-DGPH_CAP_LEAVES=200", "-DGPH_CAP_K=40", "-DGPH_CAP_B=100"] if big else \
            ["-DGPH_CAP_LEAVES=64", "-DGPH_CAP_K=40", "-DGPH_CAP_B=16"] if mid else ["-DGPH_CAP_LEAVES=32", "-DGPH_CAP_K=32", "-DGPH_CAP_B=16"]
     tmp = f"{out}.tmp.{os.getpid()}"
     if two_walks:
         caps = caps + ["-DGPH_TWO_WALKS"]
+    if wave64:
+        caps = caps + ["-DGPH_EMU64"]
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-DGPH_HOSTEMU", "-DGPH_LOGSTEPS"] + caps + [
            "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
            "-x", "c++"] + srcs + ["-lrt", "-o", tmp]

@@ -80,6 +80,46 @@ def test_variant_h_configuration_matches_reference_goldens(name, iters, tmp_path
     assert worst < 1e-12
 
 
+@pytest.mark.parametrize("name,iters", [("m3", 120), ("a7", 40), ("x8", 24), ("j1", 50), ("j2", 40), ("v8", 30), ("bigp", 20), ("stress", 6)])
+def test_wave64_device_forms_match_reference_goldens(oracle_cli, name, iters, tmp_path):
+    """round 6: the DEVICE forms of the lane-parallel functions -- lik_compute (ballot fix-point, a lane
+    per node and per pattern, conditionals forwarded in registers), prune_node_q / child_factor4, add_phases (DPP shifts),
+    ordered_sum64 (lane reads), the generic (pattern, base) pruning and root sum of pattern-rich loci, edges_for_time_pop
+    (ballot-ordered candidate list) -- compiled for the HOST and run on a 64-lane micro-wave of fibers (csrc/gph_emu64.h) inside
+    the host build: every cross-lane operation and every accessor store is a rendezvous of all 64 lanes, lanes that wait at
+    different sites abort.  Records and per-locus state of the real reference's goldens (bigp / stress: the live oracle), and the
+    same bytes as the one-lane list forms of the same library (GPH_EMU64=0 semantics: the plain host build)."""
+    import ctypes as C
+    import run_hostemu as R
+    import gphocs_amd as G
+    lib = G.load_library(R.build_hostemu(wave64=True))
+    w0, r0 = C.c_longlong(), C.c_longlong()
+    assert lib.gph_debug_emu64_stats(C.byref(w0), C.byref(r0)) == 1
+    pack = os.path.join(GOLDEN, name + ".gpk")
+    tr, st = tmp_path / "t", tmp_path / "s"
+    R.run(pack, iters, str(tr), str(st), iters - 1, lib=lib)
+    w1, r1 = C.c_longlong(), C.c_longlong()
+    lib.gph_debug_emu64_stats(C.byref(w1), C.byref(r1))
+    assert w1.value - w0.value > 50 * iters and r1.value - r0.value > 20 * (w1.value - w0.value), (w1.value, r1.value)
+    gold = os.path.join(GOLDEN, name + ".rtrace")
+    if os.path.exists(gold) and iters == {"m3": 120, "x8": 24}.get(name):          # the golden's own length: records and final state
+        assert compare_records(tr, gold) < 1e-12
+        compare_states(st, os.path.join(GOLDEN, name + ".state"))
+    elif os.path.exists(gold):                                                        # a prefix of the golden's records
+        mine = open(tr).read().splitlines()
+        (tmp_path / "g").write_text("".join(l + "\n" for l in open(gold).read().splitlines()[:len(mine)]))
+        assert compare_records(tr, tmp_path / "g") < 1e-12
+    else:
+        ot, os_ = tmp_path / "o.t", tmp_path / "o.s"
+        subprocess.run([oracle_cli, "run", pack, str(iters), str(ot), str(os_), str(iters - 1), "1"], check=True, timeout=600)
+        assert compare_records(tr, ot) < 1e-12
+        compare_states(st, os_)
+    # the one-lane host build: byte for byte the same records and state
+    tr1, st1 = tmp_path / "t1", tmp_path / "s1"
+    R.run(pack, iters, str(tr1), str(st1), iters - 1, lib=G.load_library(R.build_hostemu()))
+    assert open(tr).read() == open(tr1).read() and open(st).read() == open(st1).read()
+
+
 def test_c_abi_library_exports_every_declared_symbol():
     """build the real HIP library (hipcc cross-compiles without a GPU) and check that every function
     declared in include/gphocs_hip.h is exported (no compute calls: there is no GPU here)"""
