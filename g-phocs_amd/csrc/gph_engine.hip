@@ -1114,7 +1114,16 @@ int gph_engine_set_comm(gph_engine *e, gph_comm *c)
 #ifndef GPH_HOSTEMU
   if (c && gph_comm_world(c) > 1 && gph_comm_on_stream(c)) {
     double *rows = nullptr; unsigned long long *flags = nullptr; int32_t stride = 0;
-    if (gph_comm_peer_exchange(c, &rows, &flags, &stride) && stride >= GPH_RED_ROW) {
+    int least_ = 0, greatest_ = 0;
+    if (hipDeviceGetStreamPriorityRange(&least_, &greatest_) != hipSuccess) { least_ = greatest_ = 0; }
+    const int levels_ = least_ - greatest_ + 1;
+    if (gph_comm_peer_exchange(c, &rows, &flags, &stride) && stride >= GPH_RED_ROW && gph_comm_world(c) > levels_) {
+      /* more thread ranks than stream priority levels: two ranks would share a hardware-queue pool and could end up behind
+       * each other (tools/peer_exchange_stress.py: world 4 gave up 4 times in 10) -- the event-ordered gather instead */
+      if (gph_comm_rank(c) == 0)
+        fprintf(stderr, "gphocs_hip: the in-kernel exchange is offered for up to %d thread ranks on one device (one stream priority level "
+                        "each); %d ranks use the event-ordered gather\n", levels_, gph_comm_world(c));
+    } else if (gph_comm_peer_exchange(c, &rows, &flags, &stride) && stride >= GPH_RED_ROW) {
       e->peer_rows = rows; e->peer_flags = flags; e->peer_stride = stride;
       /* a reduction kernel of this engine may WAIT for another rank's kernel: the engine's stream must not be a blocking
        * stream then -- a blocking stream orders itself against the legacy null stream, and a null-stream operation of the

@@ -483,18 +483,17 @@ def test_in_kernel_exchange_makes_a_reduction_point_one_launch(tmp_path):
     exchange them INSIDE the reduction kernel's last block -- a slot per rank and generation parity, release / acquire on a
     generation word, a bounded wait -- and run the decision stage there on everybody's rows in rank order: as many launches
     per iteration as a single rank, no separate gather, no k_global launch.  Records byte-equal to the event-ordered gather
-    (reduction + copies + decision stage) and equal to the single-rank golden.  In a process of its own: a kernel that waits
-    for another stream's kernel wants its streams on hardware queues of their own (GPU_MAX_HW_QUEUES)."""
+    (reduction + copies + decision stage) and equal to the single-rank golden.  In a process of its own (a kernel that waits
+    for another stream's kernel needs the two streams on different hardware queues: see below)."""
     import json
     name, iters = "m3", CASES["m3"]
     out = str(tmp_path / "rec")
     script = tmp_path / "peer.py"
     script.write_text(PEER_WORKER % dict(repo=REPO, pack=os.path.join(GOLDEN, name + ".gpk"), iters=iters, out=out))
-    for attempt in range(2):
-        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
-        # (the bounded wait gave up -- Fatal Error 9997: the two ranks' streams shared a hardware queue in that process; once more)
-        if r.returncode == 0 or "9997" not in r.stderr:
-            break
+    # round 6: rank r's stream is created at priority level r mod 3 and HIP keeps a hardware-queue pool per level, so two or three
+    # thread ranks cannot land behind each other on one queue -- no retry, no GPU_MAX_HW_QUEUES (tools/peer_exchange_stress.py:
+    # 10 / 10 fresh processes at world 2 and 3 after stream churn; world 4 shares a level and failed 4 / 10: profiles/r06_peer_exchange_stress.json)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     recs = [open(out + f".{t}.{k}").read() for t in "xg" for k in (0, 1)]
