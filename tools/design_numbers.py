@@ -10,14 +10,14 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(REPO, "profiles")
 tag = sys.argv[1]
-b = json.load(open(f"{P}/r05_bench_{tag}.json"))
-s12 = json.load(open(f"{P}/r05_bench_{tag}_12500loci.json"))
+b = json.load(open(f"{P}/r06_bench_{tag}.json"))
+s12 = json.load(open(f"{P}/r06_bench_{tag}_12500loci.json"))
 t = json.load(open(f"{P}/traffic_k_sweep.json"))
 r = b["roofline"]
-ks = next(row for row in csv.DictReader(open(f"{P}/r05_bench_kernel_stats_{tag}.csv")) if row["Name"].startswith("k_sweep"))
-c2, c3 = json.load(open(f"{P}/r05_config2_bench.json")), json.load(open(f"{P}/r05_config3_bench.json"))
-c5 = json.load(open(f"{P}/r05_config5_bench.json"))
-e2e = json.load(open(f"{P}/r05_e2e_100k.json"))
+ks = next(row for row in csv.DictReader(open(f"{P}/r06_bench_kernel_stats_{tag}.csv")) if row["Name"].startswith("k_sweep"))
+c2, c3 = json.load(open(f"{P}/r06_config2_bench.json")), json.load(open(f"{P}/r06_config3_bench.json"))
+c5 = json.load(open(f"{P}/r06_config5_bench.json"))
+e2e = json.load(open(f"{P}/r06_e2e_100k.json")) if os.path.exists(f"{P}/r06_e2e_100k.json") else json.load(open(f"{P}/r05_e2e_100k.json"))
 sec = r["secondary"]
 M = lambda v: f"{v / 1e6:.1f} M"
 rep = {
@@ -31,6 +31,11 @@ rep = {
     "T_MIXF": f"{sec['k_mix_eval']['frac']:.2f}", "T_MIX": f"{sec['k_mix_eval']['avg_launch_ms']:.3f}",
     "S_EVALS": M(s12["value"]), "S_MS": f"{s12['ms_per_step']:.2f}", "S_SWEEP": f"{s12['roofline']['avg_launch_ms']:.2f}",
     "E_PROG": f"{e2e['program_wall_seconds']:.1f}", "B_BEST": f"{b['cpu_baseline']['value'] / 1e6:.2f}",
+    "B_THR": str(b["cpu_baseline"]["cores"]), "B_ONE": f"{b['cpu_baseline']['by_threads']['1']['value'] / 1e6:.2f}",
+    "T_TAUB": f"{(t['secondary']['k_tau_eval']['fetch_bytes'] + t['secondary']['k_tau_eval']['write_bytes']) / 1e9:.2f}",
+    "T_MIXB": f"{(t['secondary']['k_mix_eval']['fetch_bytes'] + t['secondary']['k_mix_eval']['write_bytes']) / 1e9:.2f}",
+    "SOAK_EVALS": f"{json.load(open(f'{P}/r06_soak.json'))['legs'][0]['evals_per_s'] / 1e6:.1f}",
+    "AB_LINE": open(f"{P}/r06_ab_sparse_shadow.txt").read().split("SUMMARY: ")[1].strip() if os.path.exists(f"{P}/r06_ab_sparse_shadow.txt") else "(pending)",
 }
 for k, c in (("C2", c2), ("C3", c3), ("C5", c5)):
     rep[k + "_EVALS"] = M(c["evals_per_s"]); rep[k + "_ITS"] = f"{c['iters_per_s']:.1f}"; rep[k + "_MS"] = f"{c['ms_per_iteration']:.2f}"
@@ -44,7 +49,8 @@ body, row = tpl.split("<!-- ROW -->\n")
 d = open(os.path.join(REPO, "DESIGN.md")).read()
 a, b = d.index("<!-- SECTION8 BEGIN"), d.index("<!-- SECTION8 END -->")
 d = d[:d.index("\n", a) + 1] + body.strip("\n") + "\n" + d[b:]
-a, b = d.index("<!-- ROW1 BEGIN -->\n") + len("<!-- ROW1 BEGIN -->\n"), d.index("<!-- ROW1 END -->")
-d = d[:a] + row.strip("\n") + "\n" + d[b:]
+if "<!-- ROW1 BEGIN -->" in d:
+    a, b = d.index("<!-- ROW1 BEGIN -->\n") + len("<!-- ROW1 BEGIN -->\n"), d.index("<!-- ROW1 END -->")
+    d = d[:a] + row.strip("\n") + "\n" + d[b:]
 open(os.path.join(REPO, "DESIGN.md"), "w").write(d)
 print(len(d), "bytes;", {k: rep[k] for k in ("V_EVALS", "V_MS", "V_SWEEP", "V_FRAC", "C2_EVALS", "C3_EVALS", "C5_EVALS", "S_MS")})
