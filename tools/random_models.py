@@ -4,6 +4,11 @@ migration bands incl. ancestral endpoints, random sample counts, an optional anc
 
     random_models.py diff  N OUTDIR [--summary FILE]   N models: real reference (oracle/_ref/gphocs_ref) vs oracle/gphocs_oracle,
                                                        records and final per-locus state byte for byte (build container only)
+    random_models.py gpu   N OUTDIR [--summary FILE]   N models on the MI355X: control + sequence file through the library's own front
+                                                       end, the HIP engine against the ORACLE run live (the GPU box has no reference;
+                                                       the oracle equals it on these very models: `diff`) -- records (accept counters
+                                                       exact, sums over loci <= 1e-10) and final per-locus state byte for byte; a model
+                                                       the oracle aborts on must fail in the same iteration
     random_models.py fixtures DIR K...                 models K... as committed fixtures: <DIR>/rKK.gpk (the reference's pack) +
                                                        rKK.rtrace (the reference's records) + rKK.json (the model)
 
@@ -145,6 +150,72 @@ def diff(n, outdir, summary):
     return bad
 
 
+def gpu(n, outdir, summary):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import gphocs_amd as G
+    from gphocs_amd_pkg import synth
+    from parity_util import compare_records, compare_states
+    os.makedirs(outdir, exist_ok=True)
+    subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "oracle"], check=True, capture_output=True)
+    rows, bad = [], 0
+    for k in range(n):
+        name, cfg, run = generate(k, outdir)
+        it = run["iters"]
+        pk = G.Pack.from_control(os.path.join(outdir, name + ".ctl"), seq_path=os.path.join(outdir, name + ".seq"))
+        pth = os.path.join(outdir, name + ".gpk")
+        synth.write_pack(pk, pth)
+        o = subprocess.run([ORA, "run", pth, str(it), name + ".o.rtrace", name + ".o.state", str(it - 1), "1"], cwd=outdir, capture_output=True, timeout=1800)
+        s = G.Sampler(pk, lib=G.load_library(dims=(pk.n, pk.K, pk.B)))
+        tr, st = os.path.join(outdir, name + ".h.rtrace"), os.path.join(outdir, name + ".h.state")
+        s.set_record_file(tr)
+        failed = None
+        try:
+            try:
+                s.initialize()
+            except RuntimeError:
+                failed = -1
+            for q in range(it if failed is None else 0):
+                try:
+                    s.iteration(q)
+                except RuntimeError:
+                    failed = q
+                    break
+            if failed is None:
+                s.dump_state(st, True)
+        finally:
+            s.set_record_file(None)
+            s.close()
+        ok, why = True, ""
+        try:
+            if o.returncode != 0:
+                its = [int(l.split()[1]) for l in open(os.path.join(outdir, name + ".o.rtrace")) if l.startswith("IT ")]
+                last = max(its) if its else -1
+                assert failed is not None and failed in (last, last + 1), f"oracle aborts in {last}, the engine {failed}"
+            else:
+                assert failed is None, f"the engine failed in iteration {failed}"
+                compare_records(tr, os.path.join(outdir, name + ".o.rtrace"))
+                compare_states(st, os.path.join(outdir, name + ".o.state"))
+        except AssertionError as ex:
+            ok, why = False, str(ex)[:300]
+        bad += not ok
+        rows.append(dict(model=name, pops=len(cfg["pops"]), leaves=int(pk.n), bands=len(cfg["bands"]),
+                         bands_with_ancestral_end=sum(1 for a, b in cfg["bands"] if len(a) > 1 or len(b) > 1),
+                         tree=json.dumps(cfg["tree"]).replace('"', "").replace(" ", ""), oracle_aborts=o.returncode != 0, engine_failed_in=failed,
+                         equal=ok, why=why))
+        print(rows[-1], flush=True)
+    out = dict(what="random model shapes on the MI355X: HIP engine (C ABI) against the oracle run live on the same pack: accept counters exact, "
+                    "sums over loci <= 1e-10, final per-locus state byte for byte; oracle aborts must be matched in the same iteration",
+               models=n, failures=bad, with_ancestral_band_ends=sum(1 for r in rows if r["bands_with_ancestral_end"]),
+               oracle_aborts=sum(1 for r in rows if r["oracle_aborts"]), rows=rows)
+    if summary:
+        with open(summary, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+    print(f"{n} models, {bad} failures")
+    return bad
+
+
 def fixtures(ids, d):
     """models `ids` as committed fixtures: the reference's pack and records (partial, when the reference aborts), the model"""
     os.makedirs(d, exist_ok=True)
@@ -171,6 +242,8 @@ if __name__ == "__main__":
     a = sys.argv
     if len(a) >= 4 and a[1] == "diff":
         sys.exit(1 if diff(int(a[2]), a[3], a[a.index("--summary") + 1] if "--summary" in a else None) else 0)
+    if len(a) >= 4 and a[1] == "gpu":
+        sys.exit(1 if gpu(int(a[2]), a[3], a[a.index("--summary") + 1] if "--summary" in a else None) else 0)
     if len(a) >= 4 and a[1] == "fixtures":
         fixtures([int(x) for x in a[3:]], a[2])
         sys.exit(0)
