@@ -974,6 +974,13 @@ GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo,
    * wavefront are performed in order, only the compiler must not reorder them (no instruction) */
   GPH_WAVE_FENCE();
   double g0, g1, g2, g3;
+#ifndef GPH_NOMASK_PRUNE
+  /* round 6: the step's loads, fp64 arithmetic and store under EXEC = the lanes that own a pattern.  The lanes beyond P used
+   * to compute on repeated data and throw the result away -- no instruction less, but 64 instead of P lanes of fp64 units
+   * switching in a kernel the chip clocks down (2.27 GHz under k_sweep, 2.41 under the evaluate kernels): masked, -0.6 % sweep
+   * time in two interleaved A/B pairs (profiles/r06_ab_mask_prune.txt).  No cross-lane operation inside. */
+  if (act) {
+#endif
   if (l == prev) {
     child_inplace4(q0, q1, q2, q3, pl, ql);
     child_generic4<DP, DP2>(r, cb, ro, pr, qr, lc, g0, g1, g2, g3, q_leaf);
@@ -988,12 +995,19 @@ GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo,
   q1 = q1 * g1;
   q2 = q2 * g2;
   q3 = q3 * g3;
+#ifndef GPH_NOMASK_PRUNE
+  {
+#else
   if (act) {
+#endif
     DP2 o2 = (DP2)(pc + 4 * lane);
     gph_d2 a = {q0, q1}, b = {q2, q3};
     o2[0] = a;
     o2[1] = b;
   }
+#ifndef GPH_NOMASK_PRUNE
+  }
+#endif
 }
 
 #endif   /* GPH_DEVFORMS */
