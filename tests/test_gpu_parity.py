@@ -71,6 +71,33 @@ def test_against_reference_goldens(G, name, tmp_path):
     print(f"{name}: worst accumulator rel diff {worst:.3e}, evals {cnt['evals']}")
 
 
+@pytest.mark.parametrize("variant", ["l", "m", "x", "g", "h", "b", "n"])
+@pytest.mark.parametrize("name", ["j1", "j2", "j3"])
+def test_new_model_shapes_on_every_capacity_variant(G, name, variant, tmp_path):
+    """round 6: the goldens with balanced / mixed population trees and ancestral band ends fit the smallest library (variant s or
+    m), so the lane-per-node forms of 32 leaves (x), the list-driven multi-word forms of the big-tree builds (g, h), the
+    many-band forms (b: live-band list in LDS, model read from HBM) and the reference's own caps (n) would never meet a band that
+    starts above its target population's age.  Each variant is loaded explicitly and must reproduce the real reference's records
+    and per-locus state (variant s / m run them in test_against_reference_goldens)."""
+    pk = G.Pack.load(os.path.join(GOLDEN, name + ".gpk"))
+    cl, ck, cb = G.VARIANTS[variant][:3]
+    if pk.n > cl or pk.K > ck or pk.B > cb:
+        pytest.skip(f"{name} ({pk.n} leaves, {pk.K} populations, {pk.B} bands) does not fit variant {variant}")
+    lib = G.load_library(G.lib_path(variant))
+    it = CASES[name]
+    s = G.Sampler(pk, lib=lib)
+    tr, st = tmp_path / "t", tmp_path / "s"
+    s.set_record_file(str(tr))
+    s.initialize()
+    for k in range(it):
+        s.iteration(k)
+    s.dump_state(str(st), True)
+    s.set_record_file(None)
+    s.close()
+    compare_records(tr, os.path.join(GOLDEN, name + ".rtrace"))
+    compare_states(st, os.path.join(GOLDEN, name + ".state"))
+
+
 def test_against_live_oracle(G, oracle_cli, tmp_path):
     """a case that is NOT a committed fixture length: 77 iterations of m4 vs the oracle run live"""
     pack = os.path.join(GOLDEN, "m4.gpk")
