@@ -50,6 +50,7 @@ HIPCC_LIBS = ["-ldl", "-lrt"]        # after the sources: an --as-needed linker 
 HIPCC_VALIDATED = "roc-7.2.0 26014"
 PLAIN_LIB = "libgphocs_hip_plain.so"    # capacities of variant `m`, no -mllvm switches
 CHECKED_LIB = "libgphocs_hip_chk.so"    # capacities of variant `x`, -DGPH_BOUNDS: every index of the device code checked (tests only)
+CHECKED_LIB_BIG = "libgphocs_hip_chkb.so"   # the same with the capacities of variant `b`: the big-tree (multi-word node sets, list-driven order) and many-band forms
 
 # Capacity variants of the same library (same C ABI, same sources): the static LDS image of a locus is
 # sized by compile-time capacities (csrc/gph_types.h), and a tighter image means more resident
@@ -189,6 +190,10 @@ def _build_locked(verbose):
     # checked build (tests only): every index of the per-locus device code against its array's extent (gph_rt.h: GPH_BOUNDS)
     cl, ck, cb, waves, _ = VARIANTS["x"]
     jobs.append((os.path.join(_HERE, CHECKED_LIB), "chk",
+                 HIPCC_BASE + HIPCC_TUNING + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}",
+                                              "-DGPH_BOUNDS"]))
+    cl, ck, cb, waves, _ = VARIANTS["b"]
+    jobs.append((os.path.join(_HERE, CHECKED_LIB_BIG), "chkb",
                  HIPCC_BASE + HIPCC_TUNING + [f"-DGPH_CAP_LEAVES={cl}", f"-DGPH_CAP_K={ck}", f"-DGPH_CAP_B={cb}", f"-DGPH_SWEEP_WAVES={waves}",
                                               "-DGPH_BOUNDS"]))
     # every variant is one hipcc process of its own (half a minute each): a few at a time

@@ -612,7 +612,7 @@ def test_bench_two_real_rccl_ranks():
     assert c["accept_counts_timed"] == one["config"]["accept_counts_timed"]
 
 
-@pytest.mark.parametrize("name", ["m3", "a7", "x8", "j1", "j2", "v8", "bigp", "stress"])
+@pytest.mark.parametrize("name", ["m3", "a7", "x8", "j1", "j2", "v8", "bigp", "stress", "y9@big", "b2@big", "j1@big", "a7@big"])
 def test_checked_build_finds_no_index_out_of_range(G, oracle_cli, tmp_path, name):
     """round 6 ("the sanitizers in the container never see the device forms"; no GPU sanitizer on this
     pool): libgphocs_hip_chk.so is the library compiled with -DGPH_BOUNDS -- every index the DEVICE forms of the per-locus code put
@@ -620,10 +620,13 @@ def test_checked_build_finds_no_index_out_of_range(G, oracle_cli, tmp_path, name
     that array; the first violation would leave its source line behind.  The goldens (migration, conflicts, sample ages, VAR
     rates, 32 leaves / 16 bands, the non-caterpillar shapes, pattern-rich loci on the generic paths) run through it with the
     golden's results and NO violation."""
-    chk = os.path.join(REPO, "g-phocs_amd", G.CHECKED_LIB)
+    # @big: the checked build with variant b's capacities (64 leaves / 39 populations / 100 bands): the big-tree and many-band forms
+    big = name.endswith("@big")
+    name = name.split("@")[0]
+    chk = os.path.join(REPO, "g-phocs_amd", G.CHECKED_LIB_BIG if big else G.CHECKED_LIB)
     assert os.path.exists(chk)
     lib = G.load_library(chk)
-    assert lib.gph_build_id().decode().startswith("chk-")
+    assert lib.gph_build_id().decode().startswith("chkb-" if big else "chk-")
     pack = os.path.join(GOLDEN, name + ".gpk")
     iters = CASES.get(name, 10)
     s = G.Sampler(G.Pack.load(pack), lib=lib)
@@ -646,7 +649,7 @@ def test_checked_build_finds_no_index_out_of_range(G, oracle_cli, tmp_path, name
         subprocess.run([oracle_cli, "run", pack, str(iters), str(ot), str(os_), str(iters - 1), "1"], check=True, timeout=600)
         compare_records(p, ot)
         compare_states(p + ".state", os_)
-    if name == "m3":
+    if name == "m3" and not big:
         # the check itself: one access one past the capacity of the node records (unit op 8) must be reported with its source line
         s = G.Sampler(G.Pack.load(pack), lib=lib)
         s.initialize()
