@@ -1011,7 +1011,14 @@ GPH_DEVHOT void prune_node_q(int l, int r, double pl, double pr, int po, int lo,
 }
 
 #endif   /* GPH_DEVFORMS */
-#if GPH_LANE_NODES || defined(GPH_EMU64)
+// GPH_EMU_LANES: the host build with the micro-wave AND one node per lane (up to 32 leaves): the lane-per-node device forms run
+// on it; with the big-tree capacities the micro-wave runs the list-driven device forms instead
+#if defined(GPH_EMU64) && !GPH_BIG_TREE
+#define GPH_EMU_LANES 1
+#else
+#define GPH_EMU_LANES 0
+#endif
+#if GPH_LANE_NODES || GPH_EMU_LANES
 #ifdef GPH_EMU64
 #define GPH_LIK_COMPUTE_LANES lik_compute_lanes      /* next to the host form; lik_compute() below dispatches */
 #else
@@ -1267,8 +1274,12 @@ GPH_DEVHOT double GPH_LIK_COMPUTE_LIST(int useOld, bool warm = false)
     k = RGHT(node);
     if (k >= n && ns_has(need, k)) si16(&GphLds::s_stack, sp++, k);
   }
-#if !defined(GPH_HOSTEMU) && GPH_BIG_TREE
+#if GPH_DEVFORMS && GPH_BIG_TREE
+#ifdef GPH_EMU64
+  if (P <= GPH_WAVE && gph_emu::in_wave()) {
+#else
   if (P <= GPH_WAVE) {
+#endif
     /* the big-tree build on the device, at most one pattern per lane: the ORDER of the recomputation comes from the
      * list above (there is no lane per node to schedule it by ballots), everything else is the vector form of the
      * smaller builds -- every edge probability of the evaluation in one vector exp (lanes = child nodes, two rounds),
@@ -1310,10 +1321,11 @@ GPH_DEVHOT double GPH_LIK_COMPUTE_LIST(int useOld, bool warm = false)
     prob += q2;
     prob += q3;
     prob = add_phases(prob, ph, q0, q1, q2, q3);
+    const bool pow2_ = __ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0;      /* (in front of the branch: see the lane-per-node form) */
     if (ph > 0) {
       const int nc = 4 * ph;
       double avg;
-      if (__ballot(ph > 0 && (ph & (ph - 1)) != 0) == 0) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
+      if (pow2_) avg = __builtin_ldexp(prob, -(2 + __builtin_ctz(ph)));
       else avg = prob / nc;
       term = gph_log(avg) * GPH_PATCOUNT(q_count, lane);
     }
@@ -1346,10 +1358,19 @@ GPH_DEVHOT double GPH_LIK_COMPUTE_LIST(int useOld, bool warm = false)
 // environment, the one-lane list form: the two must agree bit for bit on every golden
 GPH_DEVHOT double lik_compute(int useOld, bool warm = false)
 {
+#if GPH_EMU_LANES
   if (!gph_emu::enabled() || g_lay.N > gph_emu::W) return lik_compute_list(useOld, warm);
   double r = 0.0;
   gph_emu::run([&] { const double v = lik_compute_lanes(useOld, warm); if (GPH_LANE == 0) r = v; });
   return r;
+#else
+  /* big-tree capacities: the list-driven form ITSELF on the micro-wave -- its wave-uniform part on every lane, its device block
+   * (edge probabilities on a lane per child node, a lane per pattern, register forwarding) as on the gfx950 builds g / h / b / n */
+  if (!gph_emu::enabled()) return lik_compute_list(useOld, warm);
+  double r = 0.0;
+  gph_emu::run([&] { const double v = lik_compute_list(useOld, warm); if (GPH_LANE == 0) r = v; });
+  return r;
+#endif
 }
 #endif
 
@@ -1627,14 +1648,14 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
   int node, mig, pop1, num = 0, f;
   if (UNI(g_model.popAge[pop] > time + 0.0000001)) return 0;
 #ifdef GPH_EMU64
-  /* the host build with the micro-wave: the lane-per-node form below on 64 emulated lanes (it recurses once: inside the wave) */
-  if (gph_emu::enabled() && g_lay.N <= gph_emu::W) {
+  /* the host build with the micro-wave: the device form below on 64 emulated lanes (it recurses once: inside the wave) */
+  if (gph_emu::enabled() && (GPH_BIG_TREE || g_lay.N <= gph_emu::W)) {
     int r = 0;
     gph_emu::run([&] { const int v = edges_for_time_pop(time, pop, exc); if (GPH_LANE == 0) r = v; });
     return r;
   }
 #endif
-#if GPH_LANE_NODES || defined(GPH_EMU64)
+#if GPH_LANE_NODES || GPH_EMU_LANES
 #ifdef GPH_EMU64
   if (gph_emu::in_wave())
 #endif
@@ -1663,9 +1684,12 @@ GPH_DEV int edges_for_time_pop(double time, int pop, int exc)
     return num;
   }
 #endif
-#if !GPH_LANE_NODES && !defined(GPH_HOSTEMU)
+#if GPH_BIG_TREE && GPH_DEVFORMS
   /* the big-tree build on the device: the same membership test with a lane per node, 64 nodes a round; the candidates
    * of a round go behind those of the rounds before it (node order, as the reference lists them) */
+#ifdef GPH_EMU64
+  if (gph_emu::in_wave())
+#endif
   {
     const int lane = GPH_LANE;
     for (int base = 0; base < g_lay.N; base += GPH_NLANES) {

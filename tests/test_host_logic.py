@@ -80,7 +80,8 @@ def test_variant_h_configuration_matches_reference_goldens(name, iters, tmp_path
     assert worst < 1e-12
 
 
-@pytest.mark.parametrize("name,iters", [("m3", 120), ("a7", 40), ("x8", 24), ("j1", 50), ("j2", 40), ("v8", 30), ("bigp", 20), ("stress", 6)])
+@pytest.mark.parametrize("name,iters", [("m3", 120), ("a7", 40), ("x8", 24), ("j1", 50), ("j2", 40), ("v8", 30), ("bigp", 20), ("stress", 6),
+                                        ("y9@mid", 16), ("j1@mid", 30), ("b2@big", 24)])
 def test_wave64_device_forms_match_reference_goldens(oracle_cli, name, iters, tmp_path):
     """round 6: the DEVICE forms of the lane-parallel functions -- lik_compute (ballot fix-point, a lane
     per node and per pattern, conditionals forwarded in registers), prune_node_q / child_factor4, add_phases (DPP shifts),
@@ -92,7 +93,12 @@ def test_wave64_device_forms_match_reference_goldens(oracle_cli, name, iters, tm
     import ctypes as C
     import run_hostemu as R
     import gphocs_amd as G
-    lib = G.load_library(R.build_hostemu(wave64=True))
+    # @mid / @big: the capacities of library variants g / h (64 leaves, 39 populations) and b / n (200 leaves, 100 bands): there the
+    # micro-wave runs the LIST-DRIVEN device forms of the big-tree builds (edge probabilities on a lane per child node through LDS,
+    # a lane per pattern with register forwarding, multi-word node sets, the 64-nodes-a-round candidate test of the SPR)
+    kind = dict(mid=name.endswith("@mid"), big=name.endswith("@big"))
+    name = name.split("@")[0]
+    lib = G.load_library(R.build_hostemu(wave64=True, **kind))
     w0, r0 = C.c_longlong(), C.c_longlong()
     assert lib.gph_debug_emu64_stats(C.byref(w0), C.byref(r0)) == 1
     pack = os.path.join(GOLDEN, name + ".gpk")
@@ -102,7 +108,7 @@ def test_wave64_device_forms_match_reference_goldens(oracle_cli, name, iters, tm
     lib.gph_debug_emu64_stats(C.byref(w1), C.byref(r1))
     assert w1.value - w0.value > 50 * iters and r1.value - r0.value > 20 * (w1.value - w0.value), (w1.value, r1.value)
     gold = os.path.join(GOLDEN, name + ".rtrace")
-    if os.path.exists(gold) and iters == {"m3": 120, "x8": 24}.get(name):          # the golden's own length: records and final state
+    if os.path.exists(gold) and iters == {"m3": 120, "x8": 24, "y9": 16, "b2": 24}.get(name):          # the golden's own length: records and final state
         assert compare_records(tr, gold) < 1e-12
         compare_states(st, os.path.join(GOLDEN, name + ".state"))
     elif os.path.exists(gold):                                                        # a prefix of the golden's records
@@ -116,7 +122,7 @@ def test_wave64_device_forms_match_reference_goldens(oracle_cli, name, iters, tm
         compare_states(st, os_)
     # the one-lane host build: byte for byte the same records and state
     tr1, st1 = tmp_path / "t1", tmp_path / "s1"
-    R.run(pack, iters, str(tr1), str(st1), iters - 1, lib=G.load_library(R.build_hostemu()))
+    R.run(pack, iters, str(tr1), str(st1), iters - 1, lib=G.load_library(R.build_hostemu(**kind)))
     assert open(tr).read() == open(tr1).read() and open(st).read() == open(st1).read()
 
 
