@@ -125,16 +125,16 @@ def test_engine_sources_under_asan_ubsan(hostemu, tmp_path, name, ranks):
         shutil.copy(os.path.join(GOLDEN, name + ext), tmp_path)
     want = os.path.join(GOLDEN, name + ".trace")
     if w64:
-        # the micro-wave under the sanitizers runs a tenth of the speed of the plain host build: the first 24 iterations of the chain
-        # (the trace file's first 24 rows) keep the CPU suite within minutes
+        # the micro-wave under the sanitizers runs a tenth of the speed of the plain host build: the first 12 iterations of the chain
+        # (the trace file's first 12 rows) keep the CPU suite within minutes
         import re
         ctl = os.path.join(tmp_path, name + ".ctl")
         txt = open(ctl).read()
-        txt2 = re.sub(r"(mcmc-iterations\s+)\d+", lambda m: m.group(1) + "24", txt)
+        txt2 = re.sub(r"(mcmc-iterations\s+)\d+", lambda m: m.group(1) + "12", txt)
         assert re.search(r"mcmc-iterations\s+\d+", txt)
         open(ctl, "w").write(txt2)
         want = os.path.join(tmp_path, "want.trace")
-        open(want, "w").write("".join(l + "\n" for l in open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()[:25]))
+        open(want, "w").write("".join(l + "\n" for l in open(os.path.join(GOLDEN, name + ".trace")).read().splitlines()[:13]))
     env = dict(os.environ, GPHOCS_HIP_LIB=san, LD_PRELOAD=":".join(rt), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     args = [exe] + (["-g", str(ranks)] if ranks > 1 else []) + [name + ".ctl"]
